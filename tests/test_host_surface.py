@@ -1,0 +1,93 @@
+"""Host-side surface (rule strings, tables, packed layout, seeds) against values captured from the reference's
+own JavaScript (tests/golden/reference_host.json, made by tests/golden/capture_reference_host.js)."""
+import numpy as np
+import pytest
+
+from cellularautomatons3d_amd import host
+
+
+def test_rules_components_to_values(golden):
+    for s, want in golden["rules_components"].items():
+        assert host.rules_components_to_values(s) == want, s
+
+
+def test_rules_components_parse_quirks():
+    # parseInt failures are dropped; 'a-b-c' uses the first two parts; empty string yields nothing.
+    assert host.rules_components_to_values("") == []
+    assert host.rules_components_to_values("x,3") == [3]
+    assert host.rules_components_to_values("-5") == []
+    assert host.rules_components_to_values("2-") == []
+    assert host.rules_components_to_values("1-2-9") == [1, 2]
+    assert host.rules_components_to_values("3abc") == [3]
+    assert host.rules_components_to_values("5-3") == []
+    assert host.rules_components_to_values("25-30") == [25, 26, 26, 26, 26, 26]
+
+
+def test_grid_size_formatter(golden):
+    for v, want in golden["grid_size_formatter"].items():
+        assert host.grid_size_ui_formatter(int(v)) == want
+
+
+def test_neighbourhood_tables_and_luts(golden):
+    for rc in golden["rule_configs"]:
+        np.testing.assert_array_equal(host.NEIGHBOURHOOD_MAP[rc["neighbourhood"]], rc["main_offsets"])
+        np.testing.assert_array_equal(host.NEIGHBOURHOOD_MAP["edges"], rc["edges_offsets"])
+        np.testing.assert_array_equal(host.NEIGHBOURHOOD_MAP["corners"], rc["corners_offsets"])
+        s = rc["strings"]
+        born, survive = host.recalculate_rules_values(s["born"], s["survive"], s["bornEdges"], s["surviveEdges"],
+                                                       s["bornCorners"], s["surviveCorners"])
+        np.testing.assert_array_equal(born, rc["born"])
+        np.testing.assert_array_equal(survive, rc["survive"])
+        assert born.dtype == np.uint32 and rc["lut_ctor"] == "Uint32Array"
+        assert host.NEIGHBOURHOOD_MAP[rc["neighbourhood"]].dtype == np.int32 and rc["offsets_ctor"] == "Int32Array"
+
+
+def test_default_luts_known_positions():
+    born, survive = host.recalculate_rules_values()
+    assert list(np.nonzero(survive)[0]) == [0, 1, 2, 3, 4, 5, 6, 53, 80]
+    assert list(np.nonzero(born)[0]) == [1, 3, 53, 80]
+
+
+def test_initial_state(golden):
+    for G, rec in golden["initial_state"].items():
+        G = int(G)
+        st = host.initial_state(G)
+        assert st.size == rec["cell_state_0"]["length"] and rec["ctor"] == "Uint32Array"
+        nz = [[int(i), int(st[i])] for i in np.nonzero(st)[0]]
+        assert nz == rec["cell_state_0"]["nonzero"] == rec["cell_state_1"]["nonzero"]
+
+
+def test_random_initial_state_replays_reference_draws(golden):
+    for G, rec in golden["random_state"].items():
+        draws = iter(rec["draws"])
+        st = host.initial_state(int(G), random_initial_state=True, random=lambda: next(draws))
+        nz = [[int(i), int(st[i])] for i in np.nonzero(st)[0]]
+        assert nz == rec["cell_state_0"]["nonzero"]
+
+
+def test_cluster_idx(golden):
+    for rec in golden["cluster_idx"]:
+        assert host.get_cluster_idx_from_grid_coordinates(rec["G"], *rec["cell"]) == rec["idx"]
+
+
+def test_dispatch_shape(golden):
+    for G, rec in golden["dispatch"].items():
+        d = [c for c in rec["calls"] if c[0] == "dispatch"]
+        assert all(tuple(c[1:]) == host.dispatch_shape(int(G)) for c in d)
+        binds = [c[2] for c in rec["calls"] if c[0] == "bind" and c[1] == 1]
+        assert binds == ["cs0_in0_out1", "cs1_in1_out0", "cs0_in0_out1"]  # ping-pong: step k reads buf[k % 2]
+
+
+def test_bind_group_wiring(golden):
+    assert golden["cell_bind_groups"] == [
+        [{"binding": 0, "buffer": "cell_state_0"}, {"binding": 1, "buffer": "cell_state_1"}],
+        [{"binding": 0, "buffer": "cell_state_1"}, {"binding": 1, "buffer": "cell_state_0"}],
+    ]
+    assert [e["buffer"] for e in golden["rules_bind_group"]] == [
+        "neighbourhood buffer", "edges neighbourhood buffer", "corners neighbourhood buffer",
+        "survive rules buffer", "born rules buffer"]
+
+
+def test_bad_grid():
+    with pytest.raises(ValueError):
+        host.words_per_buffer(48)

@@ -1,0 +1,519 @@
+// C-ABI layer (include/ca3d.h): engine object, device buffers, ping-pong stepping, slab sub-steps, stats.
+// Replaces the WebGPU calls of main_pathtraced.js listed per entry point in the header. No CPU fallback.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "ca3d_internal.h"
+
+using namespace ca3d;
+
+namespace
+{
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char *fmt, ...)
+{
+	char buf[512];
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(buf, sizeof buf, fmt, ap);
+	va_end(ap);
+	g_last_error = buf;
+	return code;
+}
+
+#define HIP_TRY(expr)                                                                                          \
+	do                                                                                                         \
+	{                                                                                                          \
+		hipError_t e_ = (expr);                                                                                \
+		if (e_ != hipSuccess)                                                                                  \
+			return fail(e_ == hipErrorOutOfMemory ? CA3D_ERR_OUT_OF_MEMORY : CA3D_ERR_DEVICE, "%s: %s", #expr, \
+			            hipGetErrorString(e_));                                                                \
+	} while (0)
+
+} // namespace
+
+struct ca3d_engine
+{
+	int device = 0;
+	hipStream_t own_stream = nullptr;
+	hipStream_t stream = nullptr; // active (own or caller's)
+	hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+	bool ev_valid = false;
+
+	bool configured = false;
+	uint32_t G = 0;
+	int layout = CA3D_LAYOUT_PACKED32;
+	bool slab = false;
+	uint32_t z0 = 0, nz = 0, ghost = 0;
+	uint32_t nplanes = 0;   // planes per buffer including ghosts
+	size_t plane_words = 0; // u32 per z-plane
+	uint32_t *buf[2] = {nullptr, nullptr};
+	bool has_state = false;
+	uint64_t step = 0;
+
+	CanonRules rules;
+	int variant = 0;
+	int use_graph = 1;
+
+	// hipGraph of an even number of full-grid steps starting from buffer 0 (invalidated on any change)
+	hipGraphExec_t graph_exec = nullptr;
+	uint32_t graph_steps = 0;
+
+	ca3d_stats stats{};
+	const char *kernel_name = "";
+
+	size_t buffer_words() const { return plane_words * nplanes; }
+	size_t state_words() const { return plane_words * (slab ? nz : G); }
+	double cells_per_plane() const { return (double)G * G; }
+	double bytes_per_cell_step() const { return layout == CA3D_LAYOUT_PACKED32 ? 0.25 : 8.0; }
+};
+
+namespace
+{
+
+void drop_graph(ca3d_engine *h)
+{
+	if (h->graph_exec)
+	{
+		hipGraphExecDestroy(h->graph_exec);
+		h->graph_exec = nullptr;
+		h->graph_steps = 0;
+	}
+}
+
+void free_buffers(ca3d_engine *h)
+{
+	drop_graph(h);
+	for (int i = 0; i < 2; i++)
+	{
+		if (h->buf[i]) hipFree(h->buf[i]);
+		h->buf[i] = nullptr;
+	}
+	h->configured = false;
+	h->has_state = false;
+	h->step = 0;
+}
+
+int bind_device(ca3d_engine *h)
+{
+	HIP_TRY(hipSetDevice(h->device));
+	return CA3D_OK;
+}
+
+int allocate(ca3d_engine *h)
+{
+	const size_t bytes = h->buffer_words() * sizeof(uint32_t);
+	for (int i = 0; i < 2; i++)
+	{
+		hipError_t e = hipMalloc((void **)&h->buf[i], bytes);
+		if (e != hipSuccess)
+		{
+			free_buffers(h);
+			return fail(CA3D_ERR_OUT_OF_MEMORY, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+		}
+	}
+	HIP_TRY(hipMemsetAsync(h->buf[0], 0, bytes, h->stream));
+	HIP_TRY(hipMemsetAsync(h->buf[1], 0, bytes, h->stream));
+	h->configured = true;
+	return CA3D_OK;
+}
+
+// One step reading buffer `src` over output planes [lo, hi).
+int enqueue_step(ca3d_engine *h, int src, uint32_t lo, uint32_t hi, hipStream_t s)
+{
+	PlaneRange pr;
+	pr.G = h->G;
+	pr.nplanes = h->nplanes;
+	pr.zbase = h->slab ? (int32_t)h->z0 - (int32_t)h->ghost : 0;
+	pr.lo = lo;
+	pr.hi = hi;
+	pr.wrap_full = h->slab ? 0u : 1u;
+	hipError_t e;
+	if (h->layout == CA3D_LAYOUT_PACKED32)
+	{
+		PackedLaunch l{h->buf[src], h->buf[src ^ 1], pr, &h->rules, h->variant};
+		e = launch_packed_step(l, s, &h->kernel_name);
+	}
+	else
+	{
+		UnpackedLaunch l{h->buf[src], h->buf[src ^ 1], pr, &h->rules};
+		e = launch_unpacked_step(l, s, &h->kernel_name);
+	}
+	if (e != hipSuccess) return fail(CA3D_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(e));
+	return CA3D_OK;
+}
+
+int check_ready(ca3d_engine *h)
+{
+	if (!h) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL engine handle");
+	if (!h->configured) return fail(CA3D_ERR_NOT_CONFIGURED, "ca3d_configure has not been called");
+	if (!h->rules.valid) return fail(CA3D_ERR_NOT_CONFIGURED, "ca3d_set_rules has not been called");
+	if (!h->has_state) return fail(CA3D_ERR_NOT_CONFIGURED, "ca3d_upload_state has not been called");
+	return CA3D_OK;
+}
+
+constexpr uint32_t kGraphSteps = 64;
+
+int build_graph(ca3d_engine *h)
+{
+	// Capture kGraphSteps ping-pong steps starting at buffer 0. Launch boundaries stay (one kernel per step, as
+	// the reference dispatches) but the host cost per step drops from ~4 us to the graph's amortised cost.
+	hipGraph_t graph = nullptr;
+	HIP_TRY(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+	int rc = CA3D_OK;
+	for (uint32_t k = 0; k < kGraphSteps && rc == CA3D_OK; k++) rc = enqueue_step(h, (int)(k & 1u), 0, h->G, h->stream);
+	hipError_t e = hipStreamEndCapture(h->stream, &graph);
+	if (rc != CA3D_OK) { if (graph) hipGraphDestroy(graph); return rc; }
+	if (e != hipSuccess) return fail(CA3D_ERR_DEVICE, "hipStreamEndCapture: %s", hipGetErrorString(e));
+	e = hipGraphInstantiate(&h->graph_exec, graph, nullptr, nullptr, 0);
+	hipGraphDestroy(graph);
+	if (e != hipSuccess) { h->graph_exec = nullptr; return fail(CA3D_ERR_DEVICE, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
+	h->graph_steps = kGraphSteps;
+	return CA3D_OK;
+}
+
+} // namespace
+
+extern "C"
+{
+
+int ca3d_abi_version(void) { return CA3D_ABI_VERSION; }
+
+const char *ca3d_last_error(void) { return g_last_error.c_str(); }
+
+int ca3d_device_count(int *out_count)
+{
+	if (!out_count) return fail(CA3D_ERR_INVALID_ARGUMENT, "out_count is NULL");
+	int n = 0;
+	hipError_t e = hipGetDeviceCount(&n);
+	if (e != hipSuccess) { *out_count = 0; return fail(CA3D_ERR_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+	*out_count = n;
+	return CA3D_OK;
+}
+
+int ca3d_create(int device, ca3d_t **out)
+{
+	if (!out) return fail(CA3D_ERR_INVALID_ARGUMENT, "out is NULL");
+	*out = nullptr;
+	int n = 0;
+	hipError_t e = hipGetDeviceCount(&n);
+	if (e != hipSuccess || n <= 0)
+		return fail(CA3D_ERR_DEVICE, "no HIP device available (%s); this engine has no CPU fallback",
+		            e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+	if (device < 0 || device >= n) return fail(CA3D_ERR_INVALID_ARGUMENT, "device %d out of range [0,%d)", device, n);
+	ca3d_engine *h = new (std::nothrow) ca3d_engine();
+	if (!h) return fail(CA3D_ERR_OUT_OF_MEMORY, "out of host memory");
+	h->device = device;
+	HIP_TRY(hipSetDevice(device));
+	hipDeviceProp_t prop;
+	HIP_TRY(hipGetDeviceProperties(&prop, device));
+	if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+	{
+		delete h;
+		return fail(CA3D_ERR_UNSUPPORTED, "device %d is %s; this library carries gfx950 (MI355X) code objects only", device, prop.gcnArchName);
+	}
+	HIP_TRY(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+	h->stream = h->own_stream;
+	HIP_TRY(hipEventCreate(&h->ev_start));
+	HIP_TRY(hipEventCreate(&h->ev_stop));
+	*out = h;
+	return CA3D_OK;
+}
+
+int ca3d_destroy(ca3d_t *h)
+{
+	if (!h) return CA3D_OK;
+	hipSetDevice(h->device);
+	hipStreamSynchronize(h->stream);
+	free_buffers(h);
+	if (h->ev_start) hipEventDestroy(h->ev_start);
+	if (h->ev_stop) hipEventDestroy(h->ev_stop);
+	if (h->own_stream) hipStreamDestroy(h->own_stream);
+	delete h;
+	return CA3D_OK;
+}
+
+static int configure_common(ca3d_t *h, uint32_t g, int layout)
+{
+	if (!h) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL engine handle");
+	if (layout != CA3D_LAYOUT_PACKED32 && layout != CA3D_LAYOUT_UNPACKED) return fail(CA3D_ERR_INVALID_ARGUMENT, "unknown layout %d", layout);
+	if (g == 0) return fail(CA3D_ERR_INVALID_ARGUMENT, "grid size must be positive");
+	if (layout == CA3D_LAYOUT_PACKED32 && (g % 32u)) return fail(CA3D_ERR_INVALID_ARGUMENT, "packed layout needs a grid size that is a multiple of 32 (got %u)", g);
+	if (layout == CA3D_LAYOUT_UNPACKED && (g % 4u)) return fail(CA3D_ERR_INVALID_ARGUMENT, "unpacked layout needs a grid size that is a multiple of 4 (got %u)", g);
+	if (g > 8192u) return fail(CA3D_ERR_UNSUPPORTED, "grid size %u exceeds the supported maximum 8192", g);
+	int rc = bind_device(h);
+	if (rc) return rc;
+	HIP_TRY(hipStreamSynchronize(h->stream));
+	free_buffers(h);
+	h->G = g;
+	h->layout = layout;
+	h->plane_words = layout == CA3D_LAYOUT_PACKED32 ? (size_t)(g / 32u) * g : (size_t)g * g;
+	return CA3D_OK;
+}
+
+int ca3d_configure(ca3d_t *h, uint32_t gx, uint32_t gy, uint32_t gz, int layout)
+{
+	if (gx != gy || gy != gz) return fail(CA3D_ERR_UNSUPPORTED, "only cubic grids exist in the reference (got %ux%ux%u)", gx, gy, gz);
+	int rc = configure_common(h, gx, layout);
+	if (rc) return rc;
+	h->slab = false;
+	h->z0 = 0;
+	h->nz = gx;
+	h->ghost = 0;
+	h->nplanes = gx;
+	return allocate(h);
+}
+
+int ca3d_configure_slab(ca3d_t *h, uint32_t g, int layout, uint32_t z0, uint32_t nz, uint32_t ghost)
+{
+	int rc = configure_common(h, g, layout);
+	if (rc) return rc;
+	if (nz == 0 || z0 + nz > g) return fail(CA3D_ERR_INVALID_ARGUMENT, "slab [%u, %u) is outside the grid of %u planes", z0, z0 + nz, g);
+	if (ghost == 0 || ghost > nz) return fail(CA3D_ERR_INVALID_ARGUMENT, "ghost depth must be in [1, nz] (got %u, nz %u)", ghost, nz);
+	if (layout == CA3D_LAYOUT_UNPACKED && (g & (g - 1u))) return fail(CA3D_ERR_UNSUPPORTED, "unpacked slabs need a power-of-two grid size: the legacy kernel's -1 wrap is a torus only then");
+	h->slab = true;
+	h->z0 = z0;
+	h->nz = nz;
+	h->ghost = ghost;
+	h->nplanes = nz + 2u * ghost;
+	return allocate(h);
+}
+
+int ca3d_set_rules(ca3d_t *h, const int32_t *main_offsets, uint32_t n_main, const int32_t *edges_offsets, uint32_t n_edges,
+                   const int32_t *corners_offsets, uint32_t n_corners, const uint32_t survive[CA3D_LUT_LEN],
+                   const uint32_t born[CA3D_LUT_LEN])
+{
+	if (!h) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL engine handle");
+	CanonRules r;
+	std::string err;
+	int rc = canonicalize_rules(main_offsets, n_main, edges_offsets, n_edges, corners_offsets, n_corners, survive, born, &r, &err);
+	if (rc) return fail(rc, "%s", err.c_str());
+	rc = bind_device(h);
+	if (rc) return rc;
+	drop_graph(h);
+	h->rules = r;
+	if (h->configured)
+		h->kernel_name = h->layout == CA3D_LAYOUT_PACKED32 ? packed_kernel_name(h->rules, h->G, h->variant) : "ca_unpacked_literal";
+	return CA3D_OK;
+}
+
+int ca3d_upload_state(ca3d_t *h, const uint32_t *words, size_t n_words)
+{
+	if (!h) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL engine handle");
+	if (!h->configured) return fail(CA3D_ERR_NOT_CONFIGURED, "ca3d_configure has not been called");
+	if (!words) return fail(CA3D_ERR_INVALID_ARGUMENT, "words is NULL");
+	if (n_words != h->state_words()) return fail(CA3D_ERR_INVALID_ARGUMENT, "state has %zu words, expected %zu", n_words, h->state_words());
+	int rc = bind_device(h);
+	if (rc) return rc;
+	const size_t off = h->slab ? (size_t)h->ghost * h->plane_words : 0;
+	const size_t bytes = n_words * sizeof(uint32_t);
+	// Same data into both ping-pong buffers (main_pathtraced.js:1361-1362); ghosts are cleared.
+	if (h->slab)
+	{
+		HIP_TRY(hipMemsetAsync(h->buf[0], 0, h->buffer_words() * sizeof(uint32_t), h->stream));
+		HIP_TRY(hipMemsetAsync(h->buf[1], 0, h->buffer_words() * sizeof(uint32_t), h->stream));
+	}
+	HIP_TRY(hipMemcpyAsync(h->buf[0] + off, words, bytes, hipMemcpyHostToDevice, h->stream));
+	HIP_TRY(hipMemcpyAsync(h->buf[1] + off, h->buf[0] + off, bytes, hipMemcpyDeviceToDevice, h->stream));
+	HIP_TRY(hipStreamSynchronize(h->stream));
+	h->step = 0;
+	h->has_state = true;
+	return CA3D_OK;
+}
+
+int ca3d_read_state(ca3d_t *h, uint32_t *words, size_t n_words)
+{
+	if (!h) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL engine handle");
+	if (!h->configured || !h->has_state) return fail(CA3D_ERR_NOT_CONFIGURED, "no state to read: configure and upload first");
+	if (!words) return fail(CA3D_ERR_INVALID_ARGUMENT, "words is NULL");
+	if (n_words != h->state_words()) return fail(CA3D_ERR_INVALID_ARGUMENT, "state has %zu words, expected %zu", n_words, h->state_words());
+	int rc = bind_device(h);
+	if (rc) return rc;
+	const size_t off = h->slab ? (size_t)h->ghost * h->plane_words : 0;
+	HIP_TRY(hipMemcpyAsync(words, h->buf[h->step & 1u] + off, n_words * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+	HIP_TRY(hipStreamSynchronize(h->stream));
+	return CA3D_OK;
+}
+
+int ca3d_step(ca3d_t *h, uint32_t n_steps)
+{
+	int rc = check_ready(h);
+	if (rc) return rc;
+	if (h->slab) return fail(CA3D_ERR_INVALID_ARGUMENT, "engine is a slab: use ca3d_slab_step and refresh the ghosts between batches");
+	rc = bind_device(h);
+	if (rc) return rc;
+	if (n_steps == 0) return CA3D_OK;
+	HIP_TRY(hipEventRecord(h->ev_start, h->stream));
+	uint32_t left = n_steps;
+	uint64_t launches = 0;
+	// Graph replays need the batch to start at buffer 0; take single steps until parity and count allow it.
+	while (left)
+	{
+		if (h->use_graph && (h->step & 1u) == 0 && left >= kGraphSteps)
+		{
+			if (!h->graph_exec)
+			{
+				rc = build_graph(h);
+				if (rc) return rc;
+			}
+			HIP_TRY(hipGraphLaunch(h->graph_exec, h->stream));
+			h->step += h->graph_steps;
+			left -= h->graph_steps;
+			launches += h->graph_steps;
+			continue;
+		}
+		rc = enqueue_step(h, (int)(h->step & 1u), 0, h->G, h->stream);
+		if (rc) return rc;
+		h->step++;
+		left--;
+		launches++;
+	}
+	HIP_TRY(hipEventRecord(h->ev_stop, h->stream));
+	h->ev_valid = true;
+	h->stats.steps = n_steps;
+	h->stats.kernel_launches = launches;
+	h->stats.cell_steps = (double)n_steps * h->cells_per_plane() * h->G;
+	h->stats.algorithmic_bytes = h->stats.cell_steps * h->bytes_per_cell_step();
+	return CA3D_OK;
+}
+
+int ca3d_slab_step(ca3d_t *h, uint32_t n_steps)
+{
+	int rc = check_ready(h);
+	if (rc) return rc;
+	if (!h->slab) return fail(CA3D_ERR_INVALID_ARGUMENT, "engine is not a slab: use ca3d_step");
+	if (n_steps > h->ghost) return fail(CA3D_ERR_INVALID_ARGUMENT, "%u sub-steps exceed the ghost depth %u", n_steps, h->ghost);
+	rc = bind_device(h);
+	if (rc) return rc;
+	if (n_steps == 0) return CA3D_OK;
+	HIP_TRY(hipEventRecord(h->ev_start, h->stream));
+	const uint32_t L = h->nplanes, K = h->ghost;
+	double planes_done = 0;
+	for (uint32_t s = 1; s <= n_steps; s++)
+	{
+		// Valid region shrinks by one plane per side per sub-step. The packed kernel's bottom face is dead
+		// (z == -1 is dropped), so the slab that owns global plane 0 never needs its low ghost.
+		uint32_t lo = s, hi = L - s;
+		if (h->layout == CA3D_LAYOUT_PACKED32 && h->z0 == 0) lo = K;
+		rc = enqueue_step(h, (int)(h->step & 1u), lo, hi, h->stream);
+		if (rc) return rc;
+		h->step++;
+		planes_done += hi - lo;
+	}
+	HIP_TRY(hipEventRecord(h->ev_stop, h->stream));
+	h->ev_valid = true;
+	h->stats.steps = n_steps;
+	h->stats.kernel_launches = n_steps;
+	h->stats.cell_steps = (double)n_steps * h->cells_per_plane() * h->nz; // owned cells only: ghost recompute is overhead
+	h->stats.algorithmic_bytes = h->stats.cell_steps * h->bytes_per_cell_step();
+	(void)planes_done;
+	return CA3D_OK;
+}
+
+int ca3d_slab_region(ca3d_t *h, int region, void **device_ptr, size_t *n_bytes)
+{
+	if (!h || !device_ptr || !n_bytes) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL argument");
+	if (!h->configured || !h->slab) return fail(CA3D_ERR_NOT_CONFIGURED, "engine is not configured as a slab");
+	uint32_t *base = h->buf[h->step & 1u];
+	const size_t pw = h->plane_words;
+	const uint32_t K = h->ghost, nz = h->nz;
+	size_t first = 0, count = K;
+	switch (region)
+	{
+	case CA3D_SLAB_SEND_LOW: first = K; break;
+	case CA3D_SLAB_SEND_HIGH: first = nz; break; // K + nz - K
+	case CA3D_SLAB_RECV_LOW: first = 0; break;
+	case CA3D_SLAB_RECV_HIGH: first = (size_t)K + nz; break;
+	case CA3D_SLAB_OWNED: first = K; count = nz; break;
+	default: return fail(CA3D_ERR_INVALID_ARGUMENT, "unknown slab region %d", region);
+	}
+	*device_ptr = base + first * pw;
+	*n_bytes = count * pw * sizeof(uint32_t);
+	return CA3D_OK;
+}
+
+int ca3d_synchronize(ca3d_t *h)
+{
+	if (!h) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL engine handle");
+	int rc = bind_device(h);
+	if (rc) return rc;
+	HIP_TRY(hipStreamSynchronize(h->stream));
+	return CA3D_OK;
+}
+
+int ca3d_set_stream(ca3d_t *h, void *hip_stream)
+{
+	if (!h) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL engine handle");
+	int rc = bind_device(h);
+	if (rc) return rc;
+	HIP_TRY(hipStreamSynchronize(h->stream));
+	drop_graph(h);
+	h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+	h->ev_valid = false;
+	return CA3D_OK;
+}
+
+int ca3d_device_buffer(ca3d_t *h, int which, void **device_ptr, size_t *n_bytes)
+{
+	if (!h || !device_ptr || !n_bytes) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL argument");
+	if (!h->configured) return fail(CA3D_ERR_NOT_CONFIGURED, "ca3d_configure has not been called");
+	if (which != 0 && which != 1) return fail(CA3D_ERR_INVALID_ARGUMENT, "buffer index must be 0 or 1");
+	*device_ptr = h->buf[which];
+	*n_bytes = h->buffer_words() * sizeof(uint32_t);
+	return CA3D_OK;
+}
+
+int ca3d_get_info(ca3d_t *h, ca3d_info *out)
+{
+	if (!h || !out) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL argument");
+	memset(out, 0, sizeof *out);
+	out->grid_size = h->G;
+	out->layout = h->layout;
+	out->z0 = h->z0;
+	out->nz = h->nz;
+	out->ghost = h->ghost;
+	out->step = h->step;
+	out->state_words = h->configured ? h->state_words() : 0;
+	out->current_buffer = (int32_t)(h->step & 1u);
+	out->device = h->device;
+	const char *name = "";
+	if (h->configured && h->rules.valid)
+		name = h->layout == CA3D_LAYOUT_PACKED32 ? packed_kernel_name(h->rules, h->G, h->variant) : "ca_unpacked_literal";
+	snprintf(out->kernel_name, sizeof out->kernel_name, "%s", name);
+	return CA3D_OK;
+}
+
+int ca3d_get_stats(ca3d_t *h, ca3d_stats *out)
+{
+	if (!h || !out) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL argument");
+	if (!h->ev_valid) return fail(CA3D_ERR_NOT_CONFIGURED, "no step batch has been issued yet");
+	int rc = bind_device(h);
+	if (rc) return rc;
+	HIP_TRY(hipEventSynchronize(h->ev_stop));
+	float ms = 0.f;
+	HIP_TRY(hipEventElapsedTime(&ms, h->ev_start, h->ev_stop));
+	h->stats.gpu_ms = ms;
+	*out = h->stats;
+	return CA3D_OK;
+}
+
+int ca3d_set_option(ca3d_t *h, const char *name, int64_t value)
+{
+	if (!h || !name) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL argument");
+	if (!strcmp(name, "graph")) { h->use_graph = value ? 1 : 0; return CA3D_OK; }
+	if (!strcmp(name, "variant"))
+	{
+		if (value < 0 || value > 1) return fail(CA3D_ERR_INVALID_ARGUMENT, "variant must be 0 (auto) or 1 (generic kernel)");
+		drop_graph(h);
+		h->variant = (int)value;
+		return CA3D_OK;
+	}
+	return fail(CA3D_ERR_INVALID_ARGUMENT, "unknown option '%s'", name);
+}
+
+} // extern "C"

@@ -1,0 +1,115 @@
+// Internal declarations shared by the C-ABI layer and the HIP kernels. Not installed; the public surface is
+// include/ca3d.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "ca3d.h"
+
+namespace ca3d
+{
+
+// ---------------------------------------------------------------------------------------------- rule programs
+//
+// A born/survive LUT slice (27 slots of one rule-set) is a boolean function of the bit-sliced neighbour count.
+// The host compiles it (Quine-McCluskey with the unreachable counts as don't-cares) into a short OR-of-cubes
+// program which the kernels interpret with wave-uniform control flow: the LUT never reaches the GPU.
+constexpr int kMaxCubes = 16;
+
+struct RuleProg
+{
+	uint32_t n;      // cubes used
+	uint32_t invert; // 0 or 0xFFFFFFFF: the cubes cover the complement
+	// bits 0-4: care mask over count planes, bits 8-12: required plane value where cared
+	uint32_t cubes[kMaxCubes];
+};
+
+struct RuleSetProg
+{
+	RuleProg born, survive;
+};
+
+struct PackedRuleArgs
+{
+	RuleSetProg set[3]; // main, edges, corners
+};
+
+enum MainKind : int
+{
+	MAIN_VN = 0,
+	MAIN_VN2D = 1,
+	MAIN_MOORE = 2,
+	MAIN_MOORE2D = 3,
+	MAIN_EDGES = 4,
+	MAIN_CORNERS = 5,
+	MAIN_GENERIC = 6
+};
+
+constexpr int kMaxOffsets = 26; // per list; a count must stay inside its 27-slot LUT slice
+
+struct OffsetLists
+{
+	uint32_t n[3];
+	uint8_t code[3][32]; // (dx+1) | (dy+1) << 2 | (dz+1) << 4
+};
+
+struct CanonRules
+{
+	bool valid = false;
+	// packed layout
+	MainKind main = MAIN_GENERIC;
+	bool need[3] = {false, false, false}; // whether the rule-set's count influences the result at all
+	bool fast = false;                    // the three lists are the named class unions -> class kernels
+	OffsetLists lists{};
+	PackedRuleArgs prog{};
+	// unpacked layout: main list + slots 0..26 with `> 0`
+	uint32_t unpacked_survive = 0, unpacked_born = 0; // bit k = LUT[k] > 0
+	// raw copies (returned for diagnostics)
+	uint32_t survive_raw[CA3D_LUT_LEN]{}, born_raw[CA3D_LUT_LEN]{};
+};
+
+// rules.cpp
+int canonicalize_rules(const int32_t *main_offs, uint32_t n_main, const int32_t *edge_offs, uint32_t n_edge,
+                       const int32_t *corner_offs, uint32_t n_corner, const uint32_t *survive,
+                       const uint32_t *born, CanonRules *out, std::string *err);
+// Minimal OR-of-cubes cover of `onset` over `nvars` count planes; counts > max_count are don't-cares.
+void compile_rule_prog(uint32_t onset_mask, uint32_t max_count, RuleProg *out);
+
+// ---------------------------------------------------------------------------------------------- launch params
+
+// A step over output planes [lo, hi) of an array of `nplanes` z-planes; plane j holds global z = zbase + j
+// (mod G). Full grid: zbase 0, nplanes G, wrap_full 1. See oracle/ca_oracle.c for the same convention.
+struct PlaneRange
+{
+	uint32_t G;
+	uint32_t nplanes;
+	int32_t zbase;
+	uint32_t lo, hi;
+	uint32_t wrap_full;
+};
+
+struct PackedLaunch
+{
+	const uint32_t *in;
+	uint32_t *out;
+	PlaneRange pr;
+	const CanonRules *rules;
+	int variant; // -1 auto
+};
+
+struct UnpackedLaunch
+{
+	const uint32_t *in;
+	uint32_t *out;
+	PlaneRange pr;
+	const CanonRules *rules;
+};
+
+// ca_packed.hip / ca_unpacked.hip
+hipError_t launch_packed_step(const PackedLaunch &l, hipStream_t stream, const char **kernel_name);
+const char *packed_kernel_name(const CanonRules &r, uint32_t G, int variant);
+hipError_t launch_unpacked_step(const UnpackedLaunch &l, hipStream_t stream, const char **kernel_name);
+
+} // namespace ca3d

@@ -1,0 +1,138 @@
+"""`Engine`: the rule / grid / step surface of the reference host (main_pathtraced.js) over the C ABI.
+
+Method names follow the reference's host methods: `restart_sim` (_restartSim, 624-637), `compute_pass`
+(_computePass, 1796-1809), `setup_storage_buffers` (_setupStorageBuffers, 1228-1382).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _capi, host
+from ._capi import Ca3dError, Info, Stats  # noqa: F401
+
+_u32p = C.POINTER(C.c_uint32)
+_i32p = C.POINTER(C.c_int32)
+
+
+def _as_u32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
+def _as_i32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+class Engine:
+    """One engine = one GPU, one HIP stream, two ping-pong state buffers."""
+
+    def __init__(self, device: int = 0):
+        self._lib = _capi.load()
+        h = C.c_void_p()
+        _capi.check(self._lib.ca3d_create(int(device), C.byref(h)))
+        self._h = h
+        self.grid_size = 0
+        self.layout = _capi.LAYOUT_PACKED32
+
+    # -- lifetime ---------------------------------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.ca3d_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- configuration ----------------------------------------------------------------------------------
+    def configure(self, grid_size: int, layout: int = _capi.LAYOUT_PACKED32) -> None:
+        _capi.check(self._lib.ca3d_configure(self._h, grid_size, grid_size, grid_size, layout))
+        self.grid_size, self.layout = grid_size, layout
+
+    def configure_slab(self, grid_size: int, z0: int, nz: int, ghost: int, layout: int = _capi.LAYOUT_PACKED32) -> None:
+        _capi.check(self._lib.ca3d_configure_slab(self._h, grid_size, layout, z0, nz, ghost))
+        self.grid_size, self.layout = grid_size, layout
+
+    def set_rules(self, main_offsets, edges_offsets, corners_offsets, survive, born) -> None:
+        m, e, c = _as_i32(main_offsets), _as_i32(edges_offsets), _as_i32(corners_offsets)
+        s, b = _as_u32(survive), _as_u32(born)
+        if s.size != _capi.LUT_LEN or b.size != _capi.LUT_LEN:
+            raise ValueError("survive/born must hold 81 entries")
+        _capi.check(self._lib.ca3d_set_rules(
+            self._h, m.ctypes.data_as(_i32p), m.size, e.ctypes.data_as(_i32p), e.size,
+            c.ctypes.data_as(_i32p), c.size, s.ctypes.data_as(_u32p), b.ctypes.data_as(_u32p)))
+
+    def set_rule_strings(self, neighbourhood: str = host.DEFAULTS["neighbourhood"],
+                         born: str = host.DEFAULTS["bornRulesString"], survive: str = host.DEFAULTS["surviveRulesString"],
+                         born_edges: str = "27", survive_edges: str = "27",
+                         born_corners: str = "27", survive_corners: str = "27") -> None:
+        """`_recalculateRulesValues` + the rule part of `_setupStorageBuffers`."""
+        b, s = host.recalculate_rules_values(born, survive, born_edges, survive_edges, born_corners, survive_corners)
+        self.set_rules(host.NEIGHBOURHOOD_MAP[neighbourhood], host.NEIGHBOURHOOD_MAP["edges"],
+                       host.NEIGHBOURHOOD_MAP["corners"], s, b)
+
+    def restart_sim(self, grid_size: int, neighbourhood: str, born: str, survive: str, born_edges: str = "27",
+                    survive_edges: str = "27", born_corners: str = "27", survive_corners: str = "27",
+                    random_initial_state: bool = False, random=None) -> None:
+        """`_restartSim` (624-637): apply parameters, reset the step counter, rebuild rules and state."""
+        self.configure(grid_size)
+        self.set_rule_strings(neighbourhood, born, survive, born_edges, survive_edges, born_corners, survive_corners)
+        self.upload_state(host.initial_state(grid_size, random_initial_state, random))
+
+    # -- state ----------------------------------------------------------------------------------------------
+    def upload_state(self, words) -> None:
+        w = _as_u32(words).ravel()
+        _capi.check(self._lib.ca3d_upload_state(self._h, w.ctypes.data_as(_u32p), w.size))
+
+    def read_state(self) -> np.ndarray:
+        out = np.empty(self.info().state_words, dtype=np.uint32)
+        _capi.check(self._lib.ca3d_read_state(self._h, out.ctypes.data_as(_u32p), out.size))
+        return out
+
+    # -- stepping -------------------------------------------------------------------------------------------
+    def step(self, n_steps: int = 1) -> None:
+        _capi.check(self._lib.ca3d_step(self._h, n_steps))
+
+    compute_pass = step
+
+    def slab_step(self, n_steps: int) -> None:
+        _capi.check(self._lib.ca3d_slab_step(self._h, n_steps))
+
+    def slab_region(self, region: int):
+        p, n = C.c_void_p(), C.c_size_t()
+        _capi.check(self._lib.ca3d_slab_region(self._h, region, C.byref(p), C.byref(n)))
+        return int(p.value), int(n.value)
+
+    def device_buffer(self, which: int):
+        p, n = C.c_void_p(), C.c_size_t()
+        _capi.check(self._lib.ca3d_device_buffer(self._h, which, C.byref(p), C.byref(n)))
+        return int(p.value), int(n.value)
+
+    def synchronize(self) -> None:
+        _capi.check(self._lib.ca3d_synchronize(self._h))
+
+    def set_stream(self, hip_stream: Optional[int]) -> None:
+        _capi.check(self._lib.ca3d_set_stream(self._h, C.c_void_p(hip_stream or 0)))
+
+    def set_option(self, name: str, value: int) -> None:
+        _capi.check(self._lib.ca3d_set_option(self._h, name.encode(), int(value)))
+
+    def info(self) -> Info:
+        i = Info()
+        _capi.check(self._lib.ca3d_get_info(self._h, C.byref(i)))
+        return i
+
+    def stats(self) -> Stats:
+        s = Stats()
+        _capi.check(self._lib.ca3d_get_stats(self._h, C.byref(s)))
+        return s

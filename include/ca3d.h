@@ -1,0 +1,151 @@
+/*
+ * ca3d.h — C ABI of the MI355X-native engine for the two hot paths of lightest/cellularautomatons3d:
+ * the 3D cellular-automaton step and (see ca3d_render*) the per-pixel volume renderer.
+ *
+ * This is the drop-in boundary: the reference drives its kernels through the browser's WebGPU API from
+ * main_pathtraced.js; each entry point below names the reference call sites it replaces. Plain C, opaque handle,
+ * plain pointers and sizes. Every function returns 0 (CA3D_OK) or a negative ca3d_status; ca3d_last_error()
+ * gives the message for the calling thread. Caller-owned host buffers are fully consumed before a call
+ * returns. Calls on one handle are not thread-safe (the reference host is a single JS thread). One engine
+ * owns one HIP stream on one device; work is enqueued asynchronously exactly like the reference's
+ * queue.submit — only ca3d_read_state / ca3d_synchronize / the stats getters wait for the GPU.
+ *
+ * There is no CPU fallback: without a usable HIP device ca3d_create fails with CA3D_ERR_DEVICE.
+ */
+#ifndef CA3D_H
+#define CA3D_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CA3D_ABI_VERSION 1
+#define CA3D_LUT_LEN 81 /* 3 rule-sets x 27 slots (main_pathtraced.js:10, 155-159) */
+
+typedef struct ca3d_engine ca3d_t;
+
+enum ca3d_status
+{
+	CA3D_OK = 0,
+	CA3D_ERR_INVALID_ARGUMENT = -1,
+	CA3D_ERR_NOT_CONFIGURED = -2, /* call order: configure -> set_rules -> upload_state -> step */
+	CA3D_ERR_DEVICE = -3,         /* HIP error, or no GPU */
+	CA3D_ERR_OUT_OF_MEMORY = -4,
+	CA3D_ERR_UNSUPPORTED = -5
+};
+
+enum ca3d_layout
+{
+	CA3D_LAYOUT_PACKED32 = 0, /* 32 x-adjacent cells per u32: shaders/compute_clustered.wgsl (the live kernel) */
+	CA3D_LAYOUT_UNPACKED = 1  /* one u32 (0/1) per cell, toroidal: shaders/compute.wgsl (legacy kernel) */
+};
+
+int ca3d_abi_version(void);
+const char *ca3d_last_error(void);
+int ca3d_device_count(int *out_count);
+
+/* navigator.gpu.requestAdapter / requestDevice (main_pathtraced.js:222-225). */
+int ca3d_create(int device, ca3d_t **out);
+int ca3d_destroy(ca3d_t *h);
+
+/*
+ * Grid uniform + state buffers (main_pathtraced.js:1204-1217, 635, 1241, 1314-1326). The reference always
+ * writes a cubic [G,G,G]; gx == gy == gz is required. PACKED32: G a positive multiple of 32
+ * (_gridSizeUIFormatter, 675-693). UNPACKED: G a positive multiple of 4 (workgroup 4x4x4, compute.wgsl:50).
+ * Drops any previous state and resets the step counter (as _restartSim, 624-637).
+ */
+int ca3d_configure(ca3d_t *h, uint32_t gx, uint32_t gy, uint32_t gz, int layout);
+
+/*
+ * Z-slab of a G^3 grid for multi-GPU runs (no reference counterpart): this engine owns global
+ * planes [z0, z0+nz) and keeps `ghost` planes below and above them. ghost >= 1. After every ca3d_slab_step
+ * batch the host refreshes the ghosts (ca3d_slab_region + its transport, e.g. RCCL send/recv).
+ * UNPACKED slabs need a power-of-two G (the legacy kernel's -1 wrap is only a torus then).
+ */
+int ca3d_configure_slab(ca3d_t *h, uint32_t g, int layout, uint32_t z0, uint32_t nz, uint32_t ghost);
+
+/*
+ * Rule buffers exactly as the reference uploads them (main_pathtraced.js:1330-1369) and binds them
+ * (1647-1673: 0 main offsets, 1 edges offsets, 2 corners offsets, 3 survive, 4 born). Offset lists are flat
+ * xyz triples of i32 (n_* = number of i32, a multiple of 3, every component in {-1,0,1}; duplicates and
+ * (0,0,0) are legal and count as the reference kernel would count them). survive/born: 81 u32, slots
+ * 0-26 main, 27-53 edges, 54-80 corners. PACKED32 treats an entry as set iff it == 1
+ * (compute_clustered.wgsl:232); UNPACKED uses the main list and slots 0-26 with `> 0` (compute.wgsl:160-166).
+ */
+int ca3d_set_rules(ca3d_t *h,
+                   const int32_t *main_offsets, uint32_t n_main,
+                   const int32_t *edges_offsets, uint32_t n_edges,
+                   const int32_t *corners_offsets, uint32_t n_corners,
+                   const uint32_t survive[CA3D_LUT_LEN], const uint32_t born[CA3D_LUT_LEN]);
+
+/*
+ * queue.writeBuffer(cell_state_0 / cell_state_1) (main_pathtraced.js:1361-1362): the same words go to both
+ * ping-pong buffers and the step counter restarts at 0. n_words must equal the state size:
+ * PACKED32 (G/32)*G*G, UNPACKED G^3 (slab: the owned planes only; ghosts are filled by the halo exchange).
+ */
+int ca3d_upload_state(ca3d_t *h, const uint32_t *words, size_t n_words);
+
+/* Read-back of the current state = buffer [step % 2] (no reference counterpart: parity checks, checkpoints). */
+int ca3d_read_state(ca3d_t *h, uint32_t *words, size_t n_words);
+
+/*
+ * _computePass (main_pathtraced.js:1796-1809) n_steps times: step k reads buffer k % 2, writes buffer
+ * (k+1) % 2; afterwards the current state is buffer [total_steps % 2] and the other buffer holds the state one
+ * step earlier, as in the reference. Asynchronous.
+ */
+int ca3d_step(ca3d_t *h, uint32_t n_steps);
+
+/* Slab mode: n_steps <= ghost sub-steps on a shrinking plane range; then the ghosts must be refreshed. */
+int ca3d_slab_step(ca3d_t *h, uint32_t n_steps);
+
+enum ca3d_slab_region_id
+{
+	CA3D_SLAB_SEND_LOW = 0,  /* first `ghost` owned planes  -> lower neighbour's high ghost */
+	CA3D_SLAB_SEND_HIGH = 1, /* last `ghost` owned planes   -> upper neighbour's low ghost  */
+	CA3D_SLAB_RECV_LOW = 2,  /* this engine's low ghost planes  */
+	CA3D_SLAB_RECV_HIGH = 3, /* this engine's high ghost planes */
+	CA3D_SLAB_OWNED = 4      /* all owned planes */
+};
+/* Device pointer + byte size of a region of the CURRENT buffer (changes with step parity). */
+int ca3d_slab_region(ca3d_t *h, int region, void **device_ptr, size_t *n_bytes);
+
+int ca3d_synchronize(ca3d_t *h);
+
+/* Interop: run on a caller-owned hipStream_t (e.g. torch's current stream); NULL restores the engine's own. */
+int ca3d_set_stream(ca3d_t *h, void *hip_stream);
+/* Device pointer of ping-pong buffer `which` (0/1) — whole allocation including ghosts. */
+int ca3d_device_buffer(ca3d_t *h, int which, void **device_ptr, size_t *n_bytes);
+
+typedef struct ca3d_info
+{
+	uint32_t grid_size;
+	int32_t layout;
+	uint32_t z0, nz, ghost; /* slab (full grid: 0, G, 0) */
+	uint64_t step;          /* steps since the last upload */
+	uint64_t state_words;   /* words ca3d_upload_state / ca3d_read_state expect */
+	int32_t current_buffer; /* step % 2 */
+	int32_t device;
+	char kernel_name[64]; /* kernel variant the current rules select */
+} ca3d_info;
+int ca3d_get_info(ca3d_t *h, ca3d_info *out);
+
+typedef struct ca3d_stats
+{
+	uint64_t steps;          /* steps in the last ca3d_step / ca3d_slab_step batch */
+	uint64_t kernel_launches; /* kernel launches that batch issued */
+	double gpu_ms;           /* hipEvent time around the batch on the engine's stream (waits for it) */
+	double cell_steps;       /* cells updated x steps */
+	double algorithmic_bytes; /* 0.25 B (PACKED32) or 8 B (UNPACKED) per cell-step: SURVEY 8(d) */
+} ca3d_stats;
+int ca3d_get_stats(ca3d_t *h, ca3d_stats *out);
+
+/* Tuning knobs (not part of the reference surface): "graph" 0/1 hipGraph batching, "variant" kernel override. */
+int ca3d_set_option(ca3d_t *h, const char *name, int64_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CA3D_H */

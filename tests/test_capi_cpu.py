@@ -1,0 +1,56 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/ca3d.h declares, and refuses to
+run without a GPU instead of falling back to anything."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from cellularautomatons3d_amd import _capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "ca3d.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(ca3d_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _capi.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 15
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert sorted(n for n, _, _ in _capi.SYMBOLS) == declared
+
+
+def test_abi_version():
+    assert _capi.load().ca3d_abi_version() == 1
+
+
+def test_no_cpu_fallback_when_no_gpu():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    lib = _capi.load()
+    h = C.c_void_p()
+    rc = lib.ca3d_create(0, C.byref(h))
+    assert rc == -3 and not h.value
+    assert b"no CPU fallback" in lib.ca3d_last_error()
+    with pytest.raises(_capi.Ca3dError):
+        from cellularautomatons3d_amd import Engine
+
+        Engine(0)
+
+
+def test_product_does_not_reference_oracle():
+    # The oracle is test infrastructure: nothing in the package or the C sources may import, link or call it.
+    pkg = os.path.join(ROOT, "cellularautomatons3d_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".js", ".c", "Makefile")):
+                txt = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "libca3d_oracle" not in txt and "oracle_lib" not in txt and "ca3d_oracle_" not in txt, f

@@ -1,0 +1,270 @@
+"""GPU parity: the HIP CA step, called through the C ABI, against the CPU oracle — bit-exact."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from cellularautomatons3d_amd import Ca3dError, host
+from gpu_common import RULESETS, rules, set_rules
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from cellularautomatons3d_amd import Engine
+
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+@pytest.mark.parametrize("G", [32, 64, 96, 128, 256])
+@pytest.mark.parametrize("name", list(RULESETS))
+def test_one_and_many_steps_random_fill(eng, G, name):
+    r = rules(name)
+    eng.configure(G)
+    set_rules(eng, r)
+    for rounds in (0, 3):
+        st = host.random_fill(host.words_per_buffer(G), seed=0xCA3D0001 + G, and_rounds=rounds)
+        eng.upload_state(st)
+        eng.step(1)
+        want1 = ol.packed_step(G, st, r)
+        np.testing.assert_array_equal(eng.read_state(), want1)
+        eng.step(4)
+        np.testing.assert_array_equal(eng.read_state(), ol.packed_run(G, want1, r, 4))
+        assert eng.info().step == 5
+
+
+@pytest.mark.parametrize("G", [128, 256])
+@pytest.mark.parametrize("name", list(RULESETS))
+def test_generic_kernel_equals_class_kernel(eng, G, name):
+    r = rules(name)
+    eng.configure(G)
+    set_rules(eng, r)
+    st = host.random_fill(host.words_per_buffer(G), seed=11)
+    eng.upload_state(st)
+    assert b"class" in eng.info().kernel_name
+    eng.step(3)
+    a = eng.read_state()
+    eng.set_option("variant", 1)
+    try:
+        eng.upload_state(st)
+        assert eng.info().kernel_name == b"ca_packed_generic"
+        eng.step(3)
+        b = eng.read_state()
+    finally:
+        eng.set_option("variant", 0)
+    np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(a, ol.packed_run(G, st, r, 3))
+
+
+def test_arbitrary_offset_lists(eng):
+    rng = np.random.default_rng(3)
+    for G in (32, 128):
+        eng.configure(G)
+        for _ in range(5):
+            lists = [rng.integers(-1, 2, size=3 * int(rng.integers(0, 12))).astype(np.int32) for _ in range(3)]
+            r = ol.Rules(lists[0], lists[1], lists[2], (rng.random(81) < 0.3).astype(np.uint32), (rng.random(81) < 0.3).astype(np.uint32))
+            set_rules(eng, r)
+            st = host.random_fill(host.words_per_buffer(G), seed=int(rng.integers(1 << 30)))
+            eng.upload_state(st)
+            eng.step(2)
+            np.testing.assert_array_equal(eng.read_state(), ol.packed_run(G, st, r, 2))
+
+
+def test_lut_entry_must_equal_one(eng):
+    G = 128
+    r = rules("vn2d")
+    r.born = r.born.copy()
+    r.born[1] = 2  # not == 1: never born (compute_clustered.wgsl:232)
+    eng.configure(G)
+    set_rules(eng, r)
+    eng.upload_state(host.cells_to_words(G, [(5, 5, 5)]))
+    eng.step(1)
+    assert ol.popcount(eng.read_state()) == 0
+
+
+def test_default_seed_population_and_hashes(eng):
+    want = {32: "8ebd1f9c c3f1930e 6b170f5a 7815260a dec86ca6 afa3b49c b79051df 23672217".split(),
+            64: "eaf84574 2a89e9f6 08947442 7e303b52 44d3c10e 3ca0f014 548cafef ae46dc87".split()}
+    for G in (32, 64, 128):
+        eng.restart_sim(G, "von neumann", "1,3", "0-6")
+        pops, hashes = [], []
+        for _ in range(8):
+            eng.compute_pass(1)
+            st = eng.read_state()
+            pops.append(ol.popcount(st))
+            hashes.append("%08x" % ol.fnv1a32(st))
+        assert pops == [7, 13, 43, 49, 79, 133, 259, 313]
+        if G in want:
+            assert hashes == want[G]
+
+
+@pytest.mark.parametrize("axis", [0, 1, 2])
+def test_boundary_asymmetry(eng, axis):
+    for G in (32, 128):
+        eng.configure(G)
+        set_rules(eng, ol.Rules.from_strings("von neumann", "1", ""))
+
+        def cell(v):
+            c = [5, 5, 5]
+            c[axis] = v
+            return tuple(c)
+
+        eng.upload_state(host.cells_to_words(G, [cell(0)]))
+        eng.step(1)
+        st = eng.read_state()
+        assert ol.popcount(st) == 6 and host.get_cell(G, st, *cell(G - 1)) == 1
+        eng.upload_state(host.cells_to_words(G, [cell(G - 1)]))
+        eng.step(1)
+        st = eng.read_state()
+        assert ol.popcount(st) == 5 and host.get_cell(G, st, *cell(0)) == 0
+
+
+def test_ping_pong_buffers(eng):
+    # After n steps buffer n % 2 is current and the other one holds state n-1 (main_pathtraced.js:1580-1609).
+    import ctypes as C
+
+    G = 128
+    r = rules("clustered")
+    eng.configure(G)
+    set_rules(eng, r)
+    st = host.random_fill(host.words_per_buffer(G), seed=21)
+    eng.upload_state(st)
+    eng.step(3)
+    assert eng.info().current_buffer == 1
+    s2, s3 = ol.packed_run(G, st, r, 2), ol.packed_run(G, st, r, 3)
+    np.testing.assert_array_equal(eng.read_state(), s3)
+    import torch
+
+    p, n = eng.device_buffer(0)
+    eng.synchronize()
+    other = torch.empty(n // 4, dtype=torch.int32, device="cuda:0")
+    rt = C.CDLL("libamdhip64.so")
+    rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    assert rt.hipMemcpy(other.data_ptr(), p, n, 3) == 0
+    np.testing.assert_array_equal(other.cpu().numpy().view(np.uint32), s2)
+
+
+def test_config2_256_cubed_1000_steps(eng):
+    """BASELINE config 2: 256^3, default rule, 1000 steps, compared at steps 1, 2, 10, 100, 1000."""
+    G = 256
+    r = rules("default")
+    eng.configure(G)
+    set_rules(eng, r)
+    st = host.random_fill(host.words_per_buffer(G), seed=0xCA3D0001, and_rounds=4)
+    eng.upload_state(st)
+    cur, done = st, 0
+    for target in (1, 2, 10, 100, 1000):
+        eng.step(target - done)
+        cur = ol.packed_run(G, cur, r, target - done)
+        done = target
+        np.testing.assert_array_equal(eng.read_state(), cur)
+    assert eng.info().step == 1000 and eng.info().current_buffer == 0
+
+
+def test_config2_single_seed_200_steps(eng):
+    G = 256
+    eng.restart_sim(G, "von neumann", "1,3", "0-6")
+    eng.step(200)
+    want = ol.packed_run(G, host.initial_state(G), rules("default"), 200)
+    np.testing.assert_array_equal(eng.read_state(), want)
+
+
+@pytest.mark.parametrize("name", ["default", "clustered"])
+def test_512_cubed_against_oracle(eng, name):
+    G = 512
+    r = rules(name)
+    eng.configure(G)
+    set_rules(eng, r)
+    st = host.random_fill(host.words_per_buffer(G), seed=5)
+    eng.upload_state(st)
+    eng.step(2)
+    np.testing.assert_array_equal(eng.read_state(), ol.packed_run(G, st, r, 2))
+
+
+def test_512_translation_equivariance(eng):
+    # Size-independent property: away from the faces the rule commutes with translation by whole words / rows /
+    # planes, so a shifted seed pattern evolves into the shifted result.
+    G = 512
+    r = rules("clustered")
+    eng.configure(G)
+    set_rules(eng, r)
+    rng = np.random.default_rng(1)
+    cells = [(int(200 + rng.integers(0, 24)), int(200 + rng.integers(0, 24)), int(200 + rng.integers(0, 24))) for _ in range(600)]
+    dx, dy, dz = 64, 37, 101
+
+    def run(cs):
+        eng.upload_state(host.cells_to_words(G, cs))
+        eng.step(6)
+        return eng.read_state().reshape(G, G, G // 32)
+
+    a = run(cells)
+    b = run([(x + dx, y + dy, z + dz) for (x, y, z) in cells])
+    assert a.any()
+    np.testing.assert_array_equal(np.roll(a, (dz, dy, dx // 32), axis=(0, 1, 2)), b)
+
+
+def test_1024_cubed_one_step(eng):
+    G = 1024
+    r = rules("default")
+    eng.configure(G)
+    set_rules(eng, r)
+    st = host.random_fill(host.words_per_buffer(G), seed=9)
+    eng.upload_state(st)
+    eng.step(1)
+    np.testing.assert_array_equal(eng.read_state(), ol.packed_step(G, st, r))
+
+
+def test_graph_and_eager_agree(eng):
+    G = 256
+    r = rules("clustered")
+    eng.configure(G)
+    set_rules(eng, r)
+    st = host.random_fill(host.words_per_buffer(G), seed=77, and_rounds=1)
+    eng.upload_state(st)
+    eng.step(1)      # odd parity first: forces single steps before graph replays
+    eng.step(64 + 64 + 5)
+    a = eng.read_state()
+    eng.set_option("graph", 0)
+    try:
+        eng.upload_state(st)
+        eng.step(134)
+        b = eng.read_state()
+    finally:
+        eng.set_option("graph", 1)
+    np.testing.assert_array_equal(a, b)
+
+
+def test_error_behaviour(eng):
+    from cellularautomatons3d_amd import Engine
+
+    e = Engine(0)
+    try:
+        with pytest.raises(Ca3dError) as ei:
+            e.step(1)
+        assert ei.value.code == -2
+        with pytest.raises(Ca3dError):
+            e.configure(48)  # not a multiple of 32
+        e.configure(64)
+        with pytest.raises(Ca3dError) as ei:
+            e.upload_state(np.zeros(5, dtype=np.uint32))
+        assert ei.value.code == -1
+        with pytest.raises(Ca3dError) as ei:
+            e.step(1)  # rules missing
+        assert ei.value.code == -2
+        vn = host.NEIGHBOURHOOD_MAP["von neumann"]
+        b, s = host.recalculate_rules_values()
+        with pytest.raises(Ca3dError):
+            e.set_rules(vn[:5], vn, vn, s, b)  # not xyz triples
+        with pytest.raises(Ca3dError) as ei:
+            e.set_rules(np.array([2, 0, 0], dtype=np.int32), vn, vn, s, b)  # outside the 3x3x3 shell
+        assert ei.value.code == -5
+        e.set_rules(vn, host.NEIGHBOURHOOD_MAP["edges"], host.NEIGHBOURHOOD_MAP["corners"], s, b)
+        with pytest.raises(Ca3dError):
+            e.step(1)  # no state yet
+        e.upload_state(host.initial_state(64))
+        e.step(0)
+        assert e.info().step == 0
+    finally:
+        e.close()

@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Gcells/s of the bit-packed CA step (BASELINE.json metric), one process per GPU.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+      bench.py --gpus N --steps K --warmup W
+
+A "step" is one CA step (one dispatch of the reference's compute pass) over the whole grid. N = 1 runs the 512^3
+packed grid the metric is quoted on; N > 1 runs the 1024^3 grid Z-slabbed over the ranks (per-GPU cell count at
+N = 8 equals the N = 1 workload) with the ghost planes exchanged by RCCL. The state is resident in HBM before the
+timed region; the timed region is bracketed by barrier + synchronize and the max over ranks is taken.
+
+Prints ONE JSON line on rank 0 with `roofline` (algorithmic bytes per launch / measured launch duration against
+the 8 TB/s HBM peak) and, at N = 1, `cpu_baseline` (the CPU oracle timed on this host's cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+RULES = {
+    "default": dict(neighbourhood="von neumann", born="1,3", survive="0-6"),
+    "clustered": dict(neighbourhood="moore", born="5-7", survive="4-7", born_edges="4", survive_edges="3-5",
+                      born_corners="3", survive_corners="2-4"),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2048)
+    ap.add_argument("--warmup", type=int, default=256)
+    ap.add_argument("--grid", type=int, default=0, help="grid edge (default: 512 at N=1, 1024 at N>1)")
+    ap.add_argument("--rule", choices=sorted(RULES), default="default")
+    ap.add_argument("--density-rounds", type=int, default=0, help="AND rounds of the hashed fill: density 2^-(1+r)")
+    ap.add_argument("--ghost", type=int, default=8, help="ghost planes per side = steps between halo exchanges (N>1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--check", action="store_true", help="verify the final state against the oracle (small grids)")
+    return ap.parse_args()
+
+
+def cpu_baseline(G, rule_kw, seconds):
+    """The CPU oracle (a port: the reference has no CPU path) on this host's cores, bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    from cellularautomatons3d_amd import host
+
+    threads = min(os.cpu_count() or 1, 16)
+    r = ol.Rules.from_strings(**rule_kw)
+    st = host.random_fill(host.words_per_buffer(G), seed=0xCA3D0001)
+    st = ol.packed_step(G, st, r, threads)  # thread-pool start-up + page faults outside the timing
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        st = ol.packed_step(G, st, r, threads)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds or n >= 400:
+            break
+    return {"value": round(G ** 3 * n / dt / 1e9, 4), "unit": "Gcells/s", "cores": threads, "kind": "port",
+            "sample": f"{n} steps of the {G}^3 packed grid, rule '{rule_kw.get('neighbourhood')}', oracle/ca_oracle.c word-parallel form, {dt:.1f} s"}
+
+
+def pmc_traffic(kernel, G):
+    """HBM bytes per launch from a committed rocprofv3 PMC run (profiles/pmc_traffic.json), or None."""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(p):
+        return None
+    try:
+        d = json.load(open(p))
+        return d.get(f"{kernel}@{G}", {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+
+    from cellularautomatons3d_amd import Engine, host, slab
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {a.gpus} does not match WORLD_SIZE {world}")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    G = a.grid or (512 if world == 1 else 1024)
+    rule_kw = RULES[a.rule]
+    b, s = host.recalculate_rules_values(rule_kw.get("born", "1,3"), rule_kw.get("survive", "0-6"), rule_kw.get("born_edges", "27"),
+                                          rule_kw.get("survive_edges", "27"), rule_kw.get("born_corners", "27"), rule_kw.get("survive_corners", "27"))
+    offs = (host.NEIGHBOURHOOD_MAP[rule_kw["neighbourhood"]], host.NEIGHBOURHOOD_MAP["edges"], host.NEIGHBOURHOOD_MAP["corners"])
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    full = host.random_fill(host.words_per_buffer(G), seed=0xCA3D0001, and_rounds=a.density_rounds)
+    pw = (G // 32) * G
+    if world == 1:
+        eng = Engine(local_rank)
+        eng.configure(G)
+        eng.set_rules(*offs, s, b)
+        eng.upload_state(full)
+        run = eng.step
+        core = eng
+    else:
+        se = slab.SlabEngine(G, rank, world, ghost=a.ghost, device=local_rank)
+        se.engine.set_rules(*offs, s, b)
+        se.engine.upload_state(full[se.z0 * pw:(se.z0 + se.nz) * pw])
+        run = se.run
+        core = se.engine
+
+    if a.warmup > 0:
+        run(a.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    run(a.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    st = core.stats()
+    info = core.info()
+    kernel = info.kernel_name.decode()
+    cells = float(G) ** 3
+    value = cells * a.steps / dt / 1e9
+
+    ok = None
+    if a.check:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import numpy as np
+        import oracle_lib as ol
+
+        want = ol.packed_run(G, full, ol.Rules.from_strings(**rule_kw), a.warmup + a.steps)
+        got = core.read_state()
+        lo = 0 if world == 1 else se.z0 * pw
+        ok = bool(np.array_equal(got, want[lo:lo + got.size]))
+
+    if rank == 0:
+        # dominant kernel: HIP events on the engine's stream around the last step batch (get_stats), divided by the
+        # launches in it; algorithmic bytes per launch = 0.25 B x cells the launch updates.
+        launch_ms = st.gpu_ms / max(1, st.kernel_launches)
+        bytes_per_launch = st.algorithmic_bytes / max(1, st.kernel_launches)
+        achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+        out = {
+            "metric": "Gcells/s CA step at 512^3" if G == 512 else f"Gcells/s CA step at {G}^3",
+            "value": round(value, 3), "unit": "Gcells/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt * 1e3 / a.steps, 6), "higher_is_better": True,
+            "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": f"{G}^3 uint32-packed grid, rule '{a.rule}' ({rule_kw['neighbourhood']} B{rule_kw['born']}/S{rule_kw['survive']}), "
+                                   f"hashed fill seed 0xCA3D0001 density {2.0 ** -(1 + a.density_rounds):g}, one CA step per bench step",
+                       "grid": G, "layout": "packed32", "rule": a.rule,
+                       "parallelism": "1 GPU" if world == 1 else f"z-slab x{world}, ghost {a.ghost} planes, RCCL send/recv every {a.ghost} steps"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(kernel, G),
+                         "kernel": kernel, "launch_us": round(launch_ms * 1e3, 3),
+                         "algorithmic_bytes_per_launch": bytes_per_launch, "launches_timed": int(st.kernel_launches)},
+        }
+        if ok is not None:
+            out["oracle_match"] = ok
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(G, rule_kw, a.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if ok is False:
+        raise SystemExit("state does not match the oracle")
+
+
+if __name__ == "__main__":
+    main()

@@ -57,6 +57,7 @@ SYMBOLS = [
     ("ca3d_slab_region", C.c_int, [_H, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     ("ca3d_synchronize", C.c_int, [_H]),
     ("ca3d_set_stream", C.c_int, [_H, C.c_void_p]),
+    ("ca3d_use_own_stream", C.c_int, [_H]),
     ("ca3d_device_buffer", C.c_int, [_H, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     ("ca3d_get_info", C.c_int, [_H, C.POINTER(Info)]),
     ("ca3d_get_stats", C.c_int, [_H, C.POINTER(Stats)]),

@@ -354,7 +354,7 @@ int ca3d_step(ca3d_t *h, uint32_t n_steps)
 	// Graph replays need the batch to start at buffer 0; take single steps until parity and count allow it.
 	while (left)
 	{
-		if (h->use_graph && (h->step & 1u) == 0 && left >= kGraphSteps)
+		if (h->use_graph && h->stream != nullptr && (h->step & 1u) == 0 && left >= kGraphSteps)
 		{
 			if (!h->graph_exec)
 			{
@@ -453,7 +453,19 @@ int ca3d_set_stream(ca3d_t *h, void *hip_stream)
 	if (rc) return rc;
 	HIP_TRY(hipStreamSynchronize(h->stream));
 	drop_graph(h);
-	h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+	h->stream = (hipStream_t)hip_stream;
+	h->ev_valid = false;
+	return CA3D_OK;
+}
+
+int ca3d_use_own_stream(ca3d_t *h)
+{
+	if (!h) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL engine handle");
+	int rc = bind_device(h);
+	if (rc) return rc;
+	HIP_TRY(hipStreamSynchronize(h->stream));
+	drop_graph(h);
+	h->stream = h->own_stream;
 	h->ev_valid = false;
 	return CA3D_OK;
 }

@@ -121,8 +121,12 @@ class Engine:
     def synchronize(self) -> None:
         _capi.check(self._lib.ca3d_synchronize(self._h))
 
-    def set_stream(self, hip_stream: Optional[int]) -> None:
-        _capi.check(self._lib.ca3d_set_stream(self._h, C.c_void_p(hip_stream or 0)))
+    def set_stream(self, hip_stream: int) -> None:
+        """Run on a caller-owned hipStream_t; 0 is HIP's legacy default stream."""
+        _capi.check(self._lib.ca3d_set_stream(self._h, C.c_void_p(int(hip_stream))))
+
+    def use_own_stream(self) -> None:
+        _capi.check(self._lib.ca3d_use_own_stream(self._h))
 
     def set_option(self, name: str, value: int) -> None:
         _capi.check(self._lib.ca3d_set_option(self._h, name.encode(), int(value)))

@@ -1,0 +1,151 @@
+"""Z-slab decomposition of the grid across GPUs and the ghost-plane exchange (no reference
+counterpart — the reference is a single-GPU browser demo).
+
+One process per GPU. Rank k of P owns global planes [k*G/P, (k+1)*G/P) plus `ghost` planes below and above.
+A plane of the packed layout is contiguous (z is the slowest index), so a halo is one contiguous message of
+`ghost * G*G/8` bytes per direction. The exchange follows the kernel's boundary semantics:
+
+* PACKED32 (compute_clustered.wgsl:104 `<= G`): the -z face is dead, the +z face wraps to plane 0. The chain is
+  open at the bottom and closed at the top — rank P-1's high ghost is rank 0's first planes, rank 0's low ghost
+  is never read, and nobody sends rank P-1's last planes upward.
+* UNPACKED (compute.wgsl, toroidal): a true ring in both directions.
+
+With `ghost` = K planes the ranks exchange once per K steps and recompute the overlap (K sub-steps on a
+shrinking plane range), because one RCCL send/recv round costs more than one slab step.
+
+The transport is torch.distributed point-to-point (backend "nccl" = RCCL over xGMI on GPU tensors, "gloo" on
+CPU tensors in the tests), posted as one batch so RCCL groups the sends and receives.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+from ._capi import LAYOUT_PACKED32, LAYOUT_UNPACKED, SLAB_OWNED, SLAB_RECV_HIGH, SLAB_RECV_LOW, SLAB_SEND_HIGH, SLAB_SEND_LOW
+
+TAG_TO_HIGH_GHOST = 0  # a rank's first owned planes travelling down to its lower neighbour's high ghost
+TAG_TO_LOW_GHOST = 1   # a rank's last owned planes travelling up to its upper neighbour's low ghost
+
+
+@dataclass(frozen=True)
+class HaloPlan:
+    send_low_to: Optional[int]     # who receives my first `ghost` owned planes (into its high ghost)
+    send_high_to: Optional[int]    # who receives my last `ghost` owned planes (into its low ghost)
+    recv_low_from: Optional[int]   # who fills my low ghost
+    recv_high_from: Optional[int]  # who fills my high ghost
+
+
+def slab_bounds(grid_size: int, world: int, rank: int) -> Tuple[int, int]:
+    """(z0, nz) of rank's slab; the grid must split evenly."""
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError("bad rank/world")
+    if grid_size % world:
+        raise ValueError(f"grid of {grid_size} planes does not split evenly over {world} ranks")
+    nz = grid_size // world
+    return rank * nz, nz
+
+
+def halo_plan(rank: int, world: int, layout: int = LAYOUT_PACKED32) -> HaloPlan:
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError("bad rank/world")
+    below = (rank - 1) % world
+    above = (rank + 1) % world
+    if layout == LAYOUT_UNPACKED:
+        return HaloPlan(send_low_to=below, send_high_to=above, recv_low_from=below, recv_high_from=above)
+    if layout != LAYOUT_PACKED32:
+        raise ValueError("unknown layout")
+    top, bottom = rank == world - 1, rank == 0
+    return HaloPlan(
+        send_low_to=below,                        # rank 0's first planes wrap to the top rank's high ghost
+        send_high_to=None if top else above,      # z = -1 is dead: rank 0 never reads a low ghost
+        recv_low_from=None if bottom else below,
+        recv_high_from=above,                     # top rank: plane G wraps to plane 0 = rank 0
+    )
+
+
+def exchange_halos(regions: Dict[str, "object"], plan: HaloPlan, rank: int, group=None) -> None:
+    """Refresh the ghost planes. `regions` maps 'send_low', 'send_high', 'recv_low', 'recv_high' to torch tensors
+    (views of the current state buffer). Sends are posted low-then-high and receives high-then-low so that the
+    two messages a pair of ranks may exchange in one direction (world == 2) match in order under RCCL, which
+    ignores tags; gloo uses the tags."""
+    import torch.distributed as dist
+
+    ops: List = []
+    if plan.send_low_to is not None:
+        if plan.send_low_to == rank:
+            regions["recv_high"].copy_(regions["send_low"])
+        else:
+            ops.append(dist.P2POp(dist.isend, regions["send_low"], plan.send_low_to, group, TAG_TO_HIGH_GHOST))
+    if plan.send_high_to is not None:
+        if plan.send_high_to == rank:
+            regions["recv_low"].copy_(regions["send_high"])
+        else:
+            ops.append(dist.P2POp(dist.isend, regions["send_high"], plan.send_high_to, group, TAG_TO_LOW_GHOST))
+    if plan.recv_high_from is not None and plan.recv_high_from != rank:
+        ops.append(dist.P2POp(dist.irecv, regions["recv_high"], plan.recv_high_from, group, TAG_TO_HIGH_GHOST))
+    if plan.recv_low_from is not None and plan.recv_low_from != rank:
+        ops.append(dist.P2POp(dist.irecv, regions["recv_low"], plan.recv_low_from, group, TAG_TO_LOW_GHOST))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+
+
+class _DevicePtr:
+    """Exposes engine-owned device memory to torch through the CUDA array interface (no copy)."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (nbytes // 4,), "typestr": "<i4", "data": (ptr, False), "version": 2}
+
+
+def device_tensor(ptr: int, nbytes: int, device: int):
+    import torch
+
+    return torch.as_tensor(_DevicePtr(ptr, nbytes), device=f"cuda:{device}")
+
+
+class SlabEngine:
+    """One rank's slab on one GPU: an `Engine` in slab mode plus the halo exchange.
+
+    The engine runs on torch's current HIP stream so that RCCL operations posted through torch.distributed are
+    ordered with the step kernels by torch's own stream/event bookkeeping.
+    """
+
+    def __init__(self, grid_size: int, rank: int, world: int, ghost: int, layout: int = LAYOUT_PACKED32,
+                 device: int = 0, group=None, engine=None):
+        import torch
+
+        from .engine import Engine
+
+        self.rank, self.world, self.ghost, self.layout, self.group = rank, world, ghost, layout, group
+        self.grid_size = grid_size
+        self.z0, self.nz = slab_bounds(grid_size, world, rank)
+        self.plan = halo_plan(rank, world, layout)
+        self.device = device
+        torch.cuda.set_device(device)
+        self.engine = engine or Engine(device)
+        self.engine.configure_slab(grid_size, self.z0, self.nz, ghost, layout)
+        self.engine.set_stream(torch.cuda.current_stream().cuda_stream)
+        self._regions = [None, None]
+
+    def _current_regions(self):
+        parity = self.engine.info().current_buffer
+        if self._regions[parity] is None:
+            names = {"send_low": SLAB_SEND_LOW, "send_high": SLAB_SEND_HIGH, "recv_low": SLAB_RECV_LOW,
+                     "recv_high": SLAB_RECV_HIGH, "owned": SLAB_OWNED}
+            self._regions[parity] = {k: device_tensor(*self.engine.slab_region(v), self.device) for k, v in names.items()}
+        return self._regions[parity]
+
+    def exchange(self) -> None:
+        exchange_halos(self._current_regions(), self.plan, self.rank, self.group)
+
+    def run(self, n_steps: int) -> None:
+        """n CA steps: [exchange ghosts, up to `ghost` sub-steps] repeated. Asynchronous on the GPU."""
+        left = n_steps
+        while left > 0:
+            k = min(self.ghost, left)
+            self.exchange()
+            self.engine.slab_step(k)
+            left -= k
+
+    def close(self) -> None:
+        self.engine.close()

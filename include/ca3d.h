@@ -114,8 +114,10 @@ int ca3d_slab_region(ca3d_t *h, int region, void **device_ptr, size_t *n_bytes);
 
 int ca3d_synchronize(ca3d_t *h);
 
-/* Interop: run on a caller-owned hipStream_t (e.g. torch's current stream); NULL restores the engine's own. */
+/* Interop: run on a caller-owned hipStream_t (e.g. torch's current stream). NULL is HIP's legacy default stream
+ * (what torch uses unless told otherwise), not "none". ca3d_use_own_stream goes back to the engine's stream. */
 int ca3d_set_stream(ca3d_t *h, void *hip_stream);
+int ca3d_use_own_stream(ca3d_t *h);
 /* Device pointer of ping-pong buffer `which` (0/1) — whole allocation including ghosts. */
 int ca3d_device_buffer(ca3d_t *h, int which, void **device_ptr, size_t *n_bytes);
 

@@ -320,6 +320,37 @@ int ca3d_oracle_unpacked_step(uint32_t G, const uint32_t *in, uint32_t *out,
 	return 0;
 }
 
+/* compute.wgsl on an array of z-planes with ghosts (power-of-two G only, where the kernel is a true torus):
+ * the z-neighbour of local plane j is j+dz, physically adjacent; x and y wrap as in the full grid. */
+int ca3d_oracle_unpacked_step_planes(uint32_t G, const uint32_t *in, uint32_t *out, uint32_t nplanes,
+                                     uint32_t lo, uint32_t hi, const int32_t *offs, uint32_t n_offs,
+                                     const uint32_t *survive, uint32_t n_survive,
+                                     const uint32_t *born, uint32_t n_born)
+{
+	if (G == 0 || (G & (G - 1u)) || lo > hi || hi > nplanes) return -1;
+	const size_t plane = (size_t)G * G;
+	for (uint32_t j = lo; j < hi; j++)
+		for (uint32_t y = 0; y < G; y++)
+			for (uint32_t x = 0; x < G; x++)
+			{
+				uint32_t count = 0;
+				for (uint32_t i = 0; i + 2 < n_offs; i += 3)
+				{
+					const uint32_t nx = (uint32_t)((int32_t)x + offs[i]) % G;
+					const uint32_t ny = (uint32_t)((int32_t)y + offs[i + 1]) % G;
+					const int64_t nj = (int64_t)j + offs[i + 2];
+					if (nj < 0 || nj >= (int64_t)nplanes) return -4;
+					count += in[(size_t)nj * plane + (size_t)ny * G + nx];
+				}
+				const size_t idx = (size_t)j * plane + (size_t)y * G + x;
+				const uint32_t st = in[idx];
+				const uint32_t sv = survive[count < n_survive ? count : n_survive - 1];
+				const uint32_t bv = born[count < n_born ? count : n_born - 1];
+				out[idx] = (st == 1u && sv > 0u) ? 1u : ((st == 0u && bv > 0u) ? 1u : 0u);
+			}
+	return 0;
+}
+
 /* ------------------------------------------------------------------------------------------------ helpers */
 
 uint32_t ca3d_oracle_fnv1a32(const uint8_t *bytes, size_t n)

@@ -118,6 +118,20 @@ def unpacked_step(G, state, offs, survive, born, nthreads=0):
     return out
 
 
+def unpacked_step_planes(G, planes, lo, hi, offs, survive, born):
+    a, ap = _u32(planes)
+    o, op = _i32(offs)
+    s, sp = _u32(survive)
+    b, bp = _u32(born)
+    nplanes = a.size // (G * G)
+    out = np.zeros_like(a)
+    rc = lib().ca3d_oracle_unpacked_step_planes(C.c_uint32(G), ap, out.ctypes.data_as(u32p), C.c_uint32(nplanes),
+                                                C.c_uint32(lo), C.c_uint32(hi), op, C.c_uint32(o.size),
+                                                sp, C.c_uint32(s.size), bp, C.c_uint32(b.size))
+    assert rc == 0, rc
+    return out
+
+
 def fnv1a32(arr):
     a = np.ascontiguousarray(arr)
     return int(lib().ca3d_oracle_fnv1a32(a.ctypes.data, a.nbytes))

@@ -1,0 +1,100 @@
+"""Slab mode of the HIP engine on one GPU: P engines in one process stand for P ranks, ghosts are moved with
+device copies that follow the product halo plan; the result must equal the single-grid run and the oracle."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from cellularautomatons3d_amd import LAYOUT_PACKED32, LAYOUT_UNPACKED, host, slab
+from gpu_common import rules, set_rules
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_slabs(G, P, K, steps, r, layout, full):
+    import torch
+    from cellularautomatons3d_amd import Engine
+
+    pw = (G // 32) * G if layout == LAYOUT_PACKED32 else G * G
+    engs = []
+    for k in range(P):
+        e = Engine(0)
+        z0, nz = slab.slab_bounds(G, P, k)
+        e.configure_slab(G, z0, nz, K, layout)
+        set_rules(e, r)
+        e.upload_state(full[z0 * pw:(z0 + nz) * pw])
+        engs.append(e)
+    names = {"send_low": 0, "send_high": 1, "recv_low": 2, "recv_high": 3}
+    left = steps
+    while left > 0:
+        k = min(K, left)
+        for e in engs:
+            e.synchronize()
+        regs = [{n: slab.device_tensor(*e.slab_region(i), 0) for n, i in names.items()} for e in engs]
+        for rk in range(P):
+            plan = slab.halo_plan(rk, P, layout)
+            if plan.send_low_to is not None:
+                regs[plan.send_low_to]["recv_high"].copy_(regs[rk]["send_low"])
+            if plan.send_high_to is not None:
+                regs[plan.send_high_to]["recv_low"].copy_(regs[rk]["send_high"])
+        torch.cuda.synchronize()
+        for e in engs:
+            e.slab_step(k)
+        left -= k
+    out = np.concatenate([e.read_state() for e in engs])
+    for e in engs:
+        e.close()
+    return out
+
+
+@pytest.mark.parametrize("P,K,steps", [(1, 2, 5), (2, 1, 3), (2, 4, 9), (4, 3, 7), (8, 2, 4)])
+@pytest.mark.parametrize("name", ["default", "clustered"])
+def test_packed_slabs_equal_full_grid(P, K, steps, name):
+    G = 128
+    r = rules(name)
+    full = host.random_fill(host.words_per_buffer(G), seed=31)
+    got = _run_slabs(G, P, K, steps, r, LAYOUT_PACKED32, full)
+    np.testing.assert_array_equal(got, ol.packed_run(G, full, r, steps))
+
+
+def test_unpacked_slabs_equal_full_grid():
+    G, P, K, steps = 32, 2, 2, 5
+    r = ol.Rules.from_strings("moore", "5-7", "4-9")
+    full = (host.random_fill(G ** 3, seed=8) & 1).astype(np.uint32)
+    got = _run_slabs(G, P, K, steps, r, LAYOUT_UNPACKED, full)
+    cur = full
+    for _ in range(steps):
+        cur = ol.unpacked_step(G, cur, r.main, r.survive, r.born)
+    np.testing.assert_array_equal(got, cur)
+
+
+def test_slab_engine_single_rank_uses_product_exchange():
+    G = 256
+    r = rules("clustered")
+    full = host.random_fill(host.words_per_buffer(G), seed=2)
+    se = slab.SlabEngine(G, 0, 1, ghost=4)
+    set_rules(se.engine, r)
+    se.engine.upload_state(full)
+    se.run(10)
+    got = se.engine.read_state()
+    se.close()
+    np.testing.assert_array_equal(got, ol.packed_run(G, full, r, 10))
+
+
+def test_slab_step_limits():
+    from cellularautomatons3d_amd import Ca3dError, Engine
+
+    e = Engine(0)
+    try:
+        with pytest.raises(Ca3dError):
+            e.configure_slab(128, 0, 64, 0)
+        with pytest.raises(Ca3dError):
+            e.configure_slab(128, 96, 64, 1)
+        e.configure_slab(128, 0, 64, 2)
+        set_rules(e, rules("default"))
+        e.upload_state(np.zeros(64 * 128 * 4, dtype=np.uint32))
+        with pytest.raises(Ca3dError):
+            e.slab_step(3)
+        with pytest.raises(Ca3dError):
+            e.step(1)
+    finally:
+        e.close()

@@ -37,6 +37,13 @@ class Stats(C.Structure):
     ]
 
 
+class RenderStats(C.Structure):
+    _fields_ = [
+        ("gpu_ms", C.c_double), ("primary_rays", C.c_uint64), ("shadow_rays", C.c_uint64),
+        ("primary_cell_visits", C.c_uint64), ("shadow_cell_visits", C.c_uint64),
+    ]
+
+
 #: every symbol include/ca3d.h declares: (name, restype, argtypes)
 _u32p = C.POINTER(C.c_uint32)
 _i32p = C.POINTER(C.c_int32)
@@ -62,6 +69,8 @@ SYMBOLS = [
     ("ca3d_get_info", C.c_int, [_H, C.POINTER(Info)]),
     ("ca3d_get_stats", C.c_int, [_H, C.POINTER(Stats)]),
     ("ca3d_set_option", C.c_int, [_H, C.c_char_p, C.c_int64]),
+    ("ca3d_render", C.c_int, [_H, C.POINTER(C.c_float), C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("ca3d_get_render_stats", C.c_int, [_H, C.POINTER(RenderStats)]),
 ]
 
 _lib = None

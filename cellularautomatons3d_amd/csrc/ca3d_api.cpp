@@ -67,6 +67,17 @@ struct ca3d_engine
 	ca3d_stats stats{};
 	const char *kernel_name = "";
 
+	// renderer targets: presentation + two history pairs (light RGBA16F, depth RG16F), swapped per frame
+	uint32_t rw = 0, rh = 0;
+	uint32_t *r_present = nullptr;
+	void *r_light[2] = {nullptr, nullptr};
+	uint32_t *r_depth[2] = {nullptr, nullptr};
+	unsigned long long *r_counters = nullptr;
+	int r_swap = 0;
+	hipEvent_t rev_start = nullptr, rev_stop = nullptr;
+	bool rev_valid = false;
+	ca3d_render_stats rstats{};
+
 	size_t buffer_words() const { return plane_words * nplanes; }
 	size_t state_words() const { return plane_words * (slab ? nz : G); }
 	double cells_per_plane() const { return (double)G * G; }
@@ -84,6 +95,20 @@ void drop_graph(ca3d_engine *h)
 		h->graph_exec = nullptr;
 		h->graph_steps = 0;
 	}
+}
+
+void free_render_targets(ca3d_engine *h)
+{
+	if (h->r_present) hipFree(h->r_present);
+	for (int i = 0; i < 2; i++)
+	{
+		if (h->r_light[i]) hipFree(h->r_light[i]);
+		if (h->r_depth[i]) hipFree(h->r_depth[i]);
+		h->r_light[i] = nullptr;
+		h->r_depth[i] = nullptr;
+	}
+	h->r_present = nullptr;
+	h->rw = h->rh = 0;
 }
 
 void free_buffers(ca3d_engine *h)
@@ -221,6 +246,8 @@ int ca3d_create(int device, ca3d_t **out)
 	h->stream = h->own_stream;
 	HIP_TRY(hipEventCreate(&h->ev_start));
 	HIP_TRY(hipEventCreate(&h->ev_stop));
+	HIP_TRY(hipEventCreate(&h->rev_start));
+	HIP_TRY(hipEventCreate(&h->rev_stop));
 	*out = h;
 	return CA3D_OK;
 }
@@ -231,6 +258,10 @@ int ca3d_destroy(ca3d_t *h)
 	hipSetDevice(h->device);
 	hipStreamSynchronize(h->stream);
 	free_buffers(h);
+	free_render_targets(h);
+	if (h->r_counters) hipFree(h->r_counters);
+	if (h->rev_start) hipEventDestroy(h->rev_start);
+	if (h->rev_stop) hipEventDestroy(h->rev_stop);
 	if (h->ev_start) hipEventDestroy(h->ev_start);
 	if (h->ev_stop) hipEventDestroy(h->ev_stop);
 	if (h->own_stream) hipStreamDestroy(h->own_stream);
@@ -511,6 +542,81 @@ int ca3d_get_stats(ca3d_t *h, ca3d_stats *out)
 	HIP_TRY(hipEventElapsedTime(&ms, h->ev_start, h->ev_stop));
 	h->stats.gpu_ms = ms;
 	*out = h->stats;
+	return CA3D_OK;
+}
+
+int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t height, uint32_t spp,
+                uint8_t *presentation_rgba8, uint16_t *light_rgba16f, uint16_t *depth_rg16f)
+{
+	if (!h) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL engine handle");
+	if (!h->configured || !h->has_state) return fail(CA3D_ERR_NOT_CONFIGURED, "no state to render: configure and upload first");
+	if (h->slab || h->layout != CA3D_LAYOUT_PACKED32) return fail(CA3D_ERR_UNSUPPORTED, "the renderer reads the packed full grid (pathtraced_fragment_clustered.wgsl)");
+	if (!uniforms) return fail(CA3D_ERR_INVALID_ARGUMENT, "uniforms is NULL");
+	if (width == 0 || height == 0 || width > 16384u || height > 16384u) return fail(CA3D_ERR_INVALID_ARGUMENT, "bad target size %ux%u", width, height);
+	if (spp != 1 && spp != 4) return fail(CA3D_ERR_INVALID_ARGUMENT, "spp must be 1 or 4");
+	int rc = bind_device(h);
+	if (rc) return rc;
+	const size_t px = (size_t)width * height;
+	if (width != h->rw || height != h->rh)
+	{
+		// _createResolutionDependentAssests (main_pathtraced.js:729-779)
+		HIP_TRY(hipStreamSynchronize(h->stream));
+		free_render_targets(h);
+		HIP_TRY(hipMalloc((void **)&h->r_present, px * 4));
+		for (int i = 0; i < 2; i++)
+		{
+			HIP_TRY(hipMalloc(&h->r_light[i], px * 8));
+			HIP_TRY(hipMalloc((void **)&h->r_depth[i], px * 4));
+			HIP_TRY(hipMemsetAsync(h->r_light[i], 0, px * 8, h->stream));
+			HIP_TRY(hipMemsetAsync(h->r_depth[i], 0, px * 4, h->stream));
+		}
+		h->rw = width;
+		h->rh = height;
+		h->r_swap = 0;
+	}
+	if (!h->r_counters) HIP_TRY(hipMalloc((void **)&h->r_counters, 3 * sizeof(unsigned long long)));
+	HIP_TRY(hipMemsetAsync(h->r_counters, 0, 3 * sizeof(unsigned long long), h->stream));
+	RenderLaunch l;
+	l.cells = h->buf[h->step & 1u];
+	l.G = h->G;
+	l.W = width;
+	l.H = height;
+	l.spp = spp;
+	l.uniforms = uniforms;
+	l.presentation = h->r_present;
+	l.light = h->r_light[h->r_swap];
+	l.depth = h->r_depth[h->r_swap];
+	l.counters = h->r_counters;
+	HIP_TRY(hipEventRecord(h->rev_start, h->stream));
+	hipError_t e = launch_render(l, h->stream);
+	if (e != hipSuccess) return fail(CA3D_ERR_DEVICE, "render launch failed: %s", hipGetErrorString(e));
+	HIP_TRY(hipEventRecord(h->rev_stop, h->stream));
+	h->rev_valid = true;
+	h->rstats.primary_rays = (uint64_t)px * spp;
+	if (presentation_rgba8) HIP_TRY(hipMemcpyAsync(presentation_rgba8, h->r_present, px * 4, hipMemcpyDeviceToHost, h->stream));
+	if (light_rgba16f) HIP_TRY(hipMemcpyAsync(light_rgba16f, h->r_light[h->r_swap], px * 8, hipMemcpyDeviceToHost, h->stream));
+	if (depth_rg16f) HIP_TRY(hipMemcpyAsync(depth_rg16f, h->r_depth[h->r_swap], px * 4, hipMemcpyDeviceToHost, h->stream));
+	if (presentation_rgba8 || light_rgba16f || depth_rg16f) HIP_TRY(hipStreamSynchronize(h->stream));
+	h->r_swap ^= 1;
+	return CA3D_OK;
+}
+
+int ca3d_get_render_stats(ca3d_t *h, ca3d_render_stats *out)
+{
+	if (!h || !out) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL argument");
+	if (!h->rev_valid) return fail(CA3D_ERR_NOT_CONFIGURED, "ca3d_render has not been called yet");
+	int rc = bind_device(h);
+	if (rc) return rc;
+	HIP_TRY(hipEventSynchronize(h->rev_stop));
+	float ms = 0.f;
+	HIP_TRY(hipEventElapsedTime(&ms, h->rev_start, h->rev_stop));
+	unsigned long long c[3] = {0, 0, 0};
+	HIP_TRY(hipMemcpy(c, h->r_counters, sizeof c, hipMemcpyDeviceToHost));
+	h->rstats.gpu_ms = ms;
+	h->rstats.shadow_rays = c[0];
+	h->rstats.primary_cell_visits = c[1];
+	h->rstats.shadow_cell_visits = c[2];
+	*out = h->rstats;
 	return CA3D_OK;
 }
 

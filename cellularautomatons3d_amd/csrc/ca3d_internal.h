@@ -107,6 +107,20 @@ struct UnpackedLaunch
 	const CanonRules *rules;
 };
 
+struct RenderLaunch
+{
+	const uint32_t *cells; // packed state, current buffer
+	uint32_t G, W, H, spp;
+	const float *uniforms; // host pointer, >= 84 floats
+	uint32_t *presentation; // device RGBA8 or null
+	void *light;            // device RGBA16F or null
+	uint32_t *depth;        // device RG16F or null
+	unsigned long long *counters; // device, 3 counters, or null
+};
+
+// render.hip
+hipError_t launch_render(const RenderLaunch &l, hipStream_t stream);
+
 // ca_packed.hip / ca_unpacked.hip
 hipError_t launch_packed_step(const PackedLaunch &l, hipStream_t stream, const char **kernel_name);
 const char *packed_kernel_name(const CanonRules &r, uint32_t G, int variant);

@@ -121,12 +121,38 @@ __device__ __forceinline__ u32 eval_prog(const RuleProg &pr, const u32 *p)
 	return acc ^ pr.invert;
 }
 
+// Same for the 4 words a thread owns: the cube is fetched and decoded once (scalar work) per 4 words.
+template <int NP, int NPA>
+__device__ __forceinline__ void eval_prog4(const RuleProg &pr, const u32 (&p)[4][NPA], u32 (&acc)[4])
+{
+	u32 r[4] = {0, 0, 0, 0};
+	for (u32 c = 0; c < pr.n; c++)
+	{
+		const u32 cube = pr.cubes[c];
+		u32 e[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+#pragma unroll
+		for (int i = 0; i < NP; i++)
+		{
+			if (cube & (1u << i))
+			{
+				const u32 inv = (cube & (0x100u << i)) ? 0u : 0xFFFFFFFFu;
+#pragma unroll
+				for (int w = 0; w < 4; w++) e[w] = bitop3<(TA & (TB ^ TC))>(e[w], p[w][i], inv);
+			}
+		}
+#pragma unroll
+		for (int w = 0; w < 4; w++) r[w] |= e[w];
+	}
+#pragma unroll
+	for (int w = 0; w < 4; w++) acc[w] |= r[w] ^ pr.invert;
+}
+
 __device__ __forceinline__ u32 next_state(u32 alive, u32 S, u32 B)
 {
 	return bitop3<((TA & TB) | (~TA & TC)) & 0xFF>(alive, S, B); // alive ? survive : born
 }
 
-// ---- plane / row addressing shared by all packed kernels -----------------------------------------------
+// ---- plane / row addressing for the generic kernel -------------------------------------------------------
 struct Nbr
 {
 	const u32 *plane[3]; // z-1, z, z+1 (dead planes point at a valid plane and carry mask 0)
@@ -135,13 +161,19 @@ struct Nbr
 	u32 ymask[3];
 };
 
+__device__ __forceinline__ int global_z(const PlaneRange &pr, u32 j)
+{
+	int zg = pr.zbase + (int)j; // zbase in (-G, G), j <= G + 2*ghost: one conditional fold each way is enough
+	if (zg < 0) zg += (int)pr.G;
+	if (zg >= (int)pr.G) zg -= (int)pr.G;
+	return zg;
+}
+
 __device__ __forceinline__ Nbr neighbours(const u32 *in, const PlaneRange &pr, u32 C, u32 j, u32 y)
 {
 	Nbr n;
 	const size_t plane_words = (size_t)C * pr.G;
-	int zg = (pr.zbase + (int)j) % (int)pr.G; // global z of plane j (zbase may be negative)
-	if (zg < 0) zg += (int)pr.G;
-	const bool below_dead = zg == 0; // z-1 == -1 is dropped by the >= 0 test (compute_clustered.wgsl:104)
+	const bool below_dead = global_z(pr, j) == 0; // z-1 == -1 is dropped by the >= 0 test (compute_clustered.wgsl:104)
 	const u32 jb = below_dead ? j : j - 1;
 	const u32 ja = (pr.wrap_full && j + 1 == pr.nplanes) ? 0u : j + 1; // z == G passes `<= G` and wraps to 0
 	n.plane[0] = in + jb * plane_words;
@@ -159,6 +191,7 @@ __device__ __forceinline__ Nbr neighbours(const u32 *in, const PlaneRange &pr, u
 	return n;
 }
 
+// ---------------------------------------------------------------------------------------------- class kernel
 // One row segment of 4 words plus the word on either side (x-1 of word 0 is dead at cx0 == 0; x+1 of the last
 // word of the row wraps to word 0 of the same row).
 struct Seg
@@ -167,34 +200,62 @@ struct Seg
 	u32 lo, hi;
 };
 
-template <bool LR>
-__device__ __forceinline__ Seg load_seg(const Nbr &n, int dy, int dz, u32 C, u32 cx0)
+__device__ __forceinline__ u32 seg_l(const Seg &s, int i) { return from_left(s.w[i], i ? s.w[i - 1] : s.lo); }
+__device__ __forceinline__ u32 seg_r(const Seg &s, int i) { return from_right(i < 3 ? s.w[i + 1] : s.hi, s.w[i]); }
+
+struct TileGeom
 {
-	const u32 *row = n.plane[dz + 1] + (size_t)n.yrow[dy + 1] * C;
-	const u32 m = n.zmask[dz + 1] & n.ymask[dy + 1];
-	const uint4 v = *reinterpret_cast<const uint4 *>(row + cx0);
+	u32 CV;              // uint4 per row (C / 4)
+	int cv_shift;        // log2(CV) or -1
+	u32 tiles_per_plane; // 256-thread tiles per plane
+	int tpp_shift;       // log2(tiles_per_plane) or -1
+	u32 use_shfl;        // rows sit inside one wave: edge words come from neighbour lanes
+};
+
+// Per-thread constants of the (y, cx) position.
+struct Pos
+{
+	u32 off[3];   // word offset of the segment inside a plane for rows y-1, y, y+1
+	u32 ymask[3];
+	u32 lo_rel, hi_rel; // word offset of the edge words relative to the row start (load path)
+	u32 row0[3];        // row starts
+	u32 lo_mask;        // 0 at cx0 == 0
+	int src_lo, src_hi; // source lanes (shuffle path)
+	bool shfl;
+};
+
+template <bool LR>
+__device__ __forceinline__ Seg load_seg(const u32 *plane, const Pos &ps, int r, u32 zmask)
+{
+	const u32 m = zmask & ps.ymask[r];
+	const uint4 v = *reinterpret_cast<const uint4 *>(plane + ps.off[r]);
 	Seg s;
 	s.w[0] = v.x & m;
 	s.w[1] = v.y & m;
 	s.w[2] = v.z & m;
 	s.w[3] = v.w & m;
+	s.lo = 0;
+	s.hi = 0;
 	if (LR)
 	{
-		const u32 lo = row[cx0 == 0 ? 0u : cx0 - 1];
-		const u32 hi = row[cx0 + 4 == C ? 0u : cx0 + 4];
-		s.lo = cx0 == 0 ? 0u : (lo & m);
-		s.hi = hi & m;
-	}
-	else
-	{
-		s.lo = 0;
-		s.hi = 0;
+		if (ps.shfl)
+		{
+			s.lo = (u32)__shfl((int)s.w[3], ps.src_lo) & ps.lo_mask;
+			s.hi = (u32)__shfl((int)s.w[0], ps.src_hi);
+		}
+		else
+		{
+			s.lo = plane[ps.row0[r] + ps.lo_rel] & m & ps.lo_mask;
+			s.hi = plane[ps.row0[r] + ps.hi_rel] & m;
+		}
 	}
 	return s;
 }
 
-__device__ __forceinline__ u32 seg_l(const Seg &s, int i) { return from_left(s.w[i], i ? s.w[i - 1] : s.lo); }
-__device__ __forceinline__ u32 seg_r(const Seg &s, int i) { return from_right(i < 3 ? s.w[i + 1] : s.hi, s.w[i]); }
+struct PlaneRows
+{
+	Seg ym, c, yp;
+};
 
 template <int MAIN>
 struct MainPlanes
@@ -202,116 +263,149 @@ struct MainPlanes
 	static constexpr int value = (MAIN == MAIN_VN || MAIN == MAIN_VN2D) ? 3 : (MAIN == MAIN_MOORE ? 5 : 4);
 };
 
-// ---------------------------------------------------------------------------------------------- class kernel
-template <int MAIN, bool E, bool C_>
+// Each thread owns one dwordx4 column position (y, cx0..cx0+3) and walks ZR consecutive z-planes with the three
+// planes it needs held in registers, so a plane's rows are fetched once per ZR outputs instead of three times.
+template <int MAIN, bool E, bool C_, int ZR>
 __global__ __launch_bounds__(256) void ca_packed_class(const u32 *__restrict__ in, u32 *__restrict__ out,
-                                                       PlaneRange pr, u32 CV, int cv_shift, u32 blocks_per_plane,
-                                                       PackedRuleArgs rules)
+                                                       PlaneRange pr, TileGeom g, PackedRuleArgs rules)
 {
-	// XCD-aware block order: hardware deals blocks round-robin over the 8 XCDs, so give XCD k the k-th
-	// contiguous eighth of the (plane, tile) space: z-neighbour planes then meet in one XCD's L2.
-	const u32 b = blockIdx.x, nb = gridDim.x;
-	const u32 v = (nb & 7u) == 0 ? (b & 7u) * (nb >> 3) + (b >> 3) : b;
-	const u32 pj = v / blocks_per_plane;
-	const u32 t = (v - pj * blocks_per_plane) * 256u + threadIdx.x;
-	if (t >= pr.G * CV) return;
-	u32 y, cxv;
-	if (cv_shift >= 0) { y = t >> cv_shift; cxv = t & (CV - 1u); }
-	else { y = t / CV; cxv = t - y * CV; }
-	const u32 j = pr.lo + pj;
-	const u32 C = CV * 4u, cx0 = cxv * 4u;
-
-	const Nbr n = neighbours(in, pr, C, j, y);
-
 	constexpr bool kMainVN = MAIN == MAIN_VN || MAIN == MAIN_MOORE;
 	constexpr bool kNeedEdges = E || MAIN == MAIN_MOORE || MAIN == MAIN_EDGES;
 	constexpr bool kNeedCorners = C_ || MAIN == MAIN_MOORE || MAIN == MAIN_CORNERS;
-	constexpr bool kNeedCenterLR = kMainVN || MAIN == MAIN_VN2D || MAIN == MAIN_MOORE2D;
-	constexpr bool kNeedYM = kMainVN || MAIN == MAIN_VN2D || MAIN == MAIN_MOORE2D; // M of (y+-1, z)
-	constexpr bool kNeedYLR = kNeedEdges || MAIN == MAIN_MOORE2D;                 // L,R of (y+-1, z)
-	constexpr bool kNeedZM = kMainVN;                                              // M of (y, z+-1)
-	constexpr bool kNeedZLR = kNeedEdges;                                          // L,R of (y, z+-1)
-	constexpr bool kNeedDM = kNeedEdges;                                           // M of the 4 diagonals
-	constexpr bool kNeedDLR = kNeedCorners;                                        // L,R of the 4 diagonals
+	constexpr bool kCenterLR = kMainVN || MAIN == MAIN_VN2D || MAIN == MAIN_MOORE2D || kNeedEdges; // own plane or z+-1 planes
+	constexpr bool kYRows = kMainVN || MAIN == MAIN_VN2D || MAIN == MAIN_MOORE2D || kNeedEdges || kNeedCorners;
+	constexpr bool kYLR = kNeedEdges || kNeedCorners || MAIN == MAIN_MOORE2D;
+	constexpr bool kZNbr = kMainVN || kNeedEdges || kNeedCorners;  // z+-1 planes needed at all
+	constexpr bool kZYRows = kNeedEdges || kNeedCorners;           // y+-1 rows of the z+-1 planes (diagonals)
 
-	const Seg c = load_seg<kNeedCenterLR>(n, 0, 0, C, cx0);
-	Seg yp{}, ym{}, zp{}, zm{}, pp{}, pm{}, mp{}, mm{};
-	if (kNeedYM || kNeedYLR) { yp = load_seg<kNeedYLR>(n, 1, 0, C, cx0); ym = load_seg<kNeedYLR>(n, -1, 0, C, cx0); }
-	if (kNeedZM || kNeedZLR) { zp = load_seg<kNeedZLR>(n, 0, 1, C, cx0); zm = load_seg<kNeedZLR>(n, 0, -1, C, cx0); }
-	if (kNeedDM || kNeedDLR)
+	// XCD-aware block order: hardware deals blocks round-robin over the 8 XCDs; give XCD k the k-th contiguous
+	// eighth of the (z-run, tile) space so z-neighbour planes meet in one XCD's L2.
+	const u32 b = blockIdx.x, nb = gridDim.x;
+	const u32 v = (nb & 7u) == 0 ? (b & 7u) * (nb >> 3) + (b >> 3) : b;
+	u32 zr, tile;
+	if (g.tpp_shift >= 0) { zr = v >> g.tpp_shift; tile = v & (g.tiles_per_plane - 1u); }
+	else { zr = v / g.tiles_per_plane; tile = v - zr * g.tiles_per_plane; }
+	const u32 t = tile * 256u + threadIdx.x;
+	if (t >= pr.G * g.CV) return;
+	u32 y, cxv;
+	if (g.cv_shift >= 0) { y = t >> g.cv_shift; cxv = t & (g.CV - 1u); }
+	else { y = t / g.CV; cxv = t - y * g.CV; }
+	const u32 C = g.CV * 4u, cx0 = cxv * 4u;
+	const u32 plane_words = C * pr.G;
+
+	Pos ps;
 	{
-		pp = load_seg<kNeedDLR>(n, 1, 1, C, cx0);
-		pm = load_seg<kNeedDLR>(n, 1, -1, C, cx0);
-		mp = load_seg<kNeedDLR>(n, -1, 1, C, cx0);
-		mm = load_seg<kNeedDLR>(n, -1, -1, C, cx0);
+		const u32 yr[3] = {y == 0 ? 0u : y - 1, y, (y + 1 == pr.G) ? 0u : y + 1};
+		for (int r = 0; r < 3; r++) { ps.row0[r] = yr[r] * C; ps.off[r] = ps.row0[r] + cx0; ps.ymask[r] = 0xFFFFFFFFu; }
+		ps.ymask[0] = y == 0 ? 0u : 0xFFFFFFFFu;
+		ps.lo_rel = cx0 == 0 ? 0u : cx0 - 1;
+		ps.hi_rel = cx0 + 4 == C ? 0u : cx0 + 4;
+		ps.lo_mask = cx0 == 0 ? 0u : 0xFFFFFFFFu;
+		const int lane = (int)(threadIdx.x & 63u);
+		ps.src_lo = lane - 1;
+		ps.src_hi = cxv + 1 == g.CV ? lane - (int)(g.CV - 1u) : lane + 1;
+		ps.shfl = g.use_shfl != 0;
 	}
 
-	u32 o[4];
+	const u32 j0 = pr.lo + zr * ZR;
+	// window plane q holds array plane j0 + q - 1 (q = 0 .. ZR+1); out-of-range ends are clamped / wrapped
+	PlaneRows win[ZR + 2];
 #pragma unroll
-	for (int i = 0; i < 4; i++)
+	for (int q = 0; q < ZR + 2; q++)
 	{
-		u32 ed[4] = {0, 0, 0, 0}, co[4] = {0, 0, 0, 0};
-		if (kNeedEdges)
+		const bool is_out = q >= 1 && q <= ZR; // planes that are themselves outputs of this thread
+		if (!kZNbr && !is_out) continue;
+		u32 jq = j0 + (u32)q - 1u;
+		if (q == 0 && j0 == 0) jq = 0;                                     // only ever used masked (global z == 0)
+		if (jq >= pr.nplanes) jq = (jq == pr.nplanes && pr.wrap_full) ? 0u : pr.nplanes - 1u;
+		const u32 *plane = in + (size_t)jq * plane_words;
+		win[q].c = load_seg<kCenterLR>(plane, ps, 1, 0xFFFFFFFFu);
+		if (kYRows && (is_out || kZYRows))
 		{
-			const u32 x[12] = {seg_l(yp, i), seg_r(yp, i), seg_l(ym, i), seg_r(ym, i),
-			                   seg_l(zp, i), seg_r(zp, i), seg_l(zm, i), seg_r(zm, i),
-			                   pp.w[i], pm.w[i], mp.w[i], mm.w[i]};
-			sum12(x, ed);
+			win[q].ym = load_seg<kYLR>(plane, ps, 0, 0xFFFFFFFFu);
+			win[q].yp = load_seg<kYLR>(plane, ps, 2, 0xFFFFFFFFu);
 		}
-		if (kNeedCorners)
-		{
-			const u32 x[8] = {seg_l(pp, i), seg_r(pp, i), seg_l(pm, i), seg_r(pm, i),
-			                  seg_l(mp, i), seg_r(mp, i), seg_l(mm, i), seg_r(mm, i)};
-			sum8(x, co);
-		}
-		constexpr int NP = MainPlanes<MAIN>::value;
-		u32 mn[NP];
-		if (MAIN == MAIN_VN)
-		{
-			u32 p[3];
-			sum6(seg_l(c, i), seg_r(c, i), yp.w[i], ym.w[i], zp.w[i], zm.w[i], p);
-			mn[0] = p[0]; mn[1] = p[1]; mn[2] = p[2];
-		}
-		else if (MAIN == MAIN_VN2D)
-		{
-			u32 p[3];
-			sum4(seg_l(c, i), seg_r(c, i), yp.w[i], ym.w[i], p);
-			mn[0] = p[0]; mn[1] = p[1]; mn[2] = p[2];
-		}
-		else if (MAIN == MAIN_MOORE)
-		{
-			u32 vn[3], p[5];
-			sum6(seg_l(c, i), seg_r(c, i), yp.w[i], ym.w[i], zp.w[i], zm.w[i], vn);
-			sum_moore(vn, ed, co, p);
-			for (int q = 0; q < NP; q++) mn[q] = p[q];
-		}
-		else if (MAIN == MAIN_MOORE2D)
-		{
-			const u32 x[8] = {seg_l(c, i), seg_r(c, i), yp.w[i], seg_l(yp, i), seg_r(yp, i),
-			                  ym.w[i], seg_l(ym, i), seg_r(ym, i)};
-			u32 p[4];
-			sum8(x, p);
-			for (int q = 0; q < NP; q++) mn[q] = p[q];
-		}
-		else if (MAIN == MAIN_EDGES)
-		{
-			for (int q = 0; q < NP; q++) mn[q] = ed[q];
-		}
-		else
-		{
-			for (int q = 0; q < NP; q++) mn[q] = co[q];
-		}
-		u32 S = eval_prog<NP>(rules.set[0].survive, mn);
-		u32 B = eval_prog<NP>(rules.set[0].born, mn);
-		S |= eval_prog<(E ? 4 : 0)>(rules.set[1].survive, ed);
-		B |= eval_prog<(E ? 4 : 0)>(rules.set[1].born, ed);
-		S |= eval_prog<(C_ ? 4 : 0)>(rules.set[2].survive, co);
-		B |= eval_prog<(C_ ? 4 : 0)>(rules.set[2].born, co);
-		o[i] = next_state(c.w[i], S, B);
 	}
-	uint4 r;
-	r.x = o[0]; r.y = o[1]; r.z = o[2]; r.w = o[3];
-	*reinterpret_cast<uint4 *>(out + ((size_t)j * pr.G + y) * C + cx0) = r;
+
+	int zg = global_z(pr, j0);
+#pragma unroll
+	for (int q = 1; q <= ZR; q++)
+	{
+		const u32 j = j0 + (u32)q - 1u;
+		if (j >= pr.hi) break;
+		const u32 zmask = zg == 0 ? 0u : 0xFFFFFFFFu; // z-1 == -1 is dropped (compute_clustered.wgsl:104)
+		zg = zg + 1 == (int)pr.G ? 0 : zg + 1;
+		const PlaneRows &P0 = win[q - 1], &P1 = win[q], &P2 = win[q + 1];
+
+		constexpr int NP = MainPlanes<MAIN>::value;
+		u32 mn[4][NP], ed[4][4], co[4][4];
+#pragma unroll
+		for (int i = 0; i < 4; i++)
+		{
+			for (int k = 0; k < 4; k++) { ed[i][k] = 0; co[i][k] = 0; }
+			if (kNeedEdges)
+			{
+				const u32 x[12] = {seg_l(P1.yp, i), seg_r(P1.yp, i), seg_l(P1.ym, i), seg_r(P1.ym, i),
+				                   seg_l(P2.c, i), seg_r(P2.c, i), seg_l(P0.c, i) & zmask, seg_r(P0.c, i) & zmask,
+				                   P2.yp.w[i], P0.yp.w[i] & zmask, P2.ym.w[i], P0.ym.w[i] & zmask};
+				sum12(x, ed[i]);
+			}
+			if (kNeedCorners)
+			{
+				const u32 x[8] = {seg_l(P2.yp, i), seg_r(P2.yp, i), seg_l(P0.yp, i) & zmask, seg_r(P0.yp, i) & zmask,
+				                  seg_l(P2.ym, i), seg_r(P2.ym, i), seg_l(P0.ym, i) & zmask, seg_r(P0.ym, i) & zmask};
+				sum8(x, co[i]);
+			}
+			if (MAIN == MAIN_VN)
+			{
+				u32 p[3];
+				sum6(seg_l(P1.c, i), seg_r(P1.c, i), P1.yp.w[i], P1.ym.w[i], P2.c.w[i], P0.c.w[i] & zmask, p);
+				for (int k = 0; k < 3; k++) mn[i][k] = p[k];
+			}
+			else if (MAIN == MAIN_VN2D)
+			{
+				u32 p[3];
+				sum4(seg_l(P1.c, i), seg_r(P1.c, i), P1.yp.w[i], P1.ym.w[i], p);
+				for (int k = 0; k < 3; k++) mn[i][k] = p[k];
+			}
+			else if (MAIN == MAIN_MOORE)
+			{
+				u32 vn[3], p[5];
+				sum6(seg_l(P1.c, i), seg_r(P1.c, i), P1.yp.w[i], P1.ym.w[i], P2.c.w[i], P0.c.w[i] & zmask, vn);
+				sum_moore(vn, ed[i], co[i], p);
+				for (int k = 0; k < NP; k++) mn[i][k] = p[k];
+			}
+			else if (MAIN == MAIN_MOORE2D)
+			{
+				const u32 x[8] = {seg_l(P1.c, i), seg_r(P1.c, i), P1.yp.w[i], seg_l(P1.yp, i), seg_r(P1.yp, i),
+				                  P1.ym.w[i], seg_l(P1.ym, i), seg_r(P1.ym, i)};
+				u32 p[4];
+				sum8(x, p);
+				for (int k = 0; k < NP; k++) mn[i][k] = p[k];
+			}
+			else if (MAIN == MAIN_EDGES)
+			{
+				for (int k = 0; k < NP; k++) mn[i][k] = ed[i][k];
+			}
+			else
+			{
+				for (int k = 0; k < NP; k++) mn[i][k] = co[i][k];
+			}
+		}
+		u32 S[4] = {0, 0, 0, 0}, B[4] = {0, 0, 0, 0};
+		eval_prog4<NP>(rules.set[0].survive, mn, S);
+		eval_prog4<NP>(rules.set[0].born, mn, B);
+		eval_prog4<(E ? 4 : 0)>(rules.set[1].survive, ed, S);
+		eval_prog4<(E ? 4 : 0)>(rules.set[1].born, ed, B);
+		eval_prog4<(C_ ? 4 : 0)>(rules.set[2].survive, co, S);
+		eval_prog4<(C_ ? 4 : 0)>(rules.set[2].born, co, B);
+		uint4 r;
+		r.x = next_state(P1.c.w[0], S[0], B[0]);
+		r.y = next_state(P1.c.w[1], S[1], B[1]);
+		r.z = next_state(P1.c.w[2], S[2], B[2]);
+		r.w = next_state(P1.c.w[3], S[3], B[3]);
+		*reinterpret_cast<uint4 *>(out + (size_t)j * plane_words + ps.off[1]) = r;
+	}
 }
 
 // -------------------------------------------------------------------------------------------- generic kernel
@@ -359,14 +453,25 @@ __global__ __launch_bounds__(256) void ca_packed_generic(const u32 *__restrict__
 template <int MAIN, bool E, bool C_>
 hipError_t launch_class(const PackedLaunch &l, hipStream_t stream)
 {
-	const u32 C = l.pr.G / 32u, CV = C / 4u;
-	const u32 items = l.pr.G * CV;
-	const u32 bpp = (items + 255u) / 256u;
+	const u32 C = l.pr.G / 32u;
+	TileGeom g;
+	g.CV = C / 4u;
+	const u32 items = l.pr.G * g.CV;
+	g.tiles_per_plane = (items + 255u) / 256u;
+	auto log2_exact = [](u32 x) { int s = -1; if (x && (x & (x - 1u)) == 0) { s = 0; while ((1u << s) < x) s++; } return s; };
+	g.cv_shift = log2_exact(g.CV);
+	g.tpp_shift = log2_exact(g.tiles_per_plane);
+	g.use_shfl = (g.cv_shift >= 0 && g.CV <= 64u) ? 1u : 0u;
 	const u32 planes = l.pr.hi - l.pr.lo;
-	int shift = -1;
-	if ((CV & (CV - 1u)) == 0) { shift = 0; while ((1u << shift) < CV) shift++; }
-	hipLaunchKernelGGL((ca_packed_class<MAIN, E, C_>), dim3(bpp * planes), dim3(256), 0, stream, l.in, l.out, l.pr, CV,
-	                   shift, bpp, l.rules->prog);
+	// z-run of 4 planes per thread once that still leaves >= 4 workgroups per CU; small grids keep 1 plane per
+	// thread so all 256 CUs get work.
+	const bool deep = (size_t)g.tiles_per_plane * ((planes + 3u) / 4u) >= 1024u;
+	if (deep)
+		hipLaunchKernelGGL((ca_packed_class<MAIN, E, C_, 4>), dim3(g.tiles_per_plane * ((planes + 3u) / 4u)), dim3(256), 0,
+		                   stream, l.in, l.out, l.pr, g, l.rules->prog);
+	else
+		hipLaunchKernelGGL((ca_packed_class<MAIN, E, C_, 1>), dim3(g.tiles_per_plane * planes), dim3(256), 0, stream, l.in,
+		                   l.out, l.pr, g, l.rules->prog);
 	return hipGetLastError();
 }
 

@@ -1,0 +1,337 @@
+// Per-pixel volume renderer over the bit-packed state for gfx950 — the frame the reference's fragment shader
+// (shaders/pathtraced_fragment_clustered.wgsl) converges to under a static camera (SURVEY 8(a) rows R1-R12,
+// R-par): an exact DDA cell walk replaces the jittered fixed-step march (682-741) and the jittered shadow march
+// (635-680); visible-cube slab tests, shading gate, Cook-Torrance BRDF, clamp of the temporal blend, light
+// gizmo, depth overlay and gamma follow the shader line by line. One thread per pixel, spp sub-samples in a
+// loop, three outputs: presentation RGBA8, light RGBA16F, depth RG16F (885-887).
+//
+// Built with -ffp-contract=off: the parity target is a plain-float CPU restatement (oracle/render_oracle.c).
+#include <hip/hip_fp16.h>
+
+#include "ca3d_internal.h"
+
+namespace ca3d
+{
+namespace
+{
+
+using u32 = uint32_t;
+
+struct v3
+{
+	float x, y, z;
+};
+__device__ __forceinline__ v3 V(float x, float y, float z) { return v3{x, y, z}; }
+__device__ __forceinline__ v3 operator+(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ v3 operator-(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ v3 operator*(v3 a, v3 b) { return V(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ v3 operator*(v3 a, float s) { return V(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ float dot3(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ float len3(v3 a) { return sqrtf(dot3(a, a)); }
+__device__ __forceinline__ v3 norm3(v3 a) { const float l = len3(a); return V(a.x / l, a.y / l, a.z / l); }
+
+// float indices of the 128-float uniform block (MemoryManager allocation order, main_pathtraced.js:166,
+// 467-478 == struct CommonBufferLayout, pathtraced_fragment_clustered.wgsl:17-34)
+enum
+{
+	U_LIGHT = 0, U_VIEW = 4, U_PROJVIEWINV = 20, U_PREVVIEW = 36, U_PREVPROJVIEWINV = 52, U_WINDOW = 68, U_TIME = 70,
+	U_DEPTHSAMPLES = 71, U_SHADOWSAMPLES = 72, U_CELLSIZE = 73, U_SHOWDEPTH = 74, U_TEMPORALALPHA = 75,
+	U_REFLECTIVITY = 76, U_ROUGHNESS = 79, U_MATERIALCOLOR = 80, U_GAMMA = 83, U_LIVE = 84
+};
+
+struct RenderParams
+{
+	const u32 *cells;
+	u32 G, cols; // cols = G / 32
+	u32 W, H, spp;
+	float cot_half_fov;
+	float u[U_LIVE];
+	u32 *presentation;         // RGBA8
+	uint2 *light;              // RGBA16F
+	u32 *depth;                // RG16F
+	unsigned long long *counters; // [0] shadow rays, [1] primary cell visits, [2] shadow cell visits
+};
+
+constexpr float kPi = 3.14159265359f;
+constexpr float kHalf = 0.5f;
+constexpr float kOcclusion = 0.0095f;
+
+__device__ __forceinline__ u32 cell_state(const RenderParams &P, u32 x, u32 y, u32 z)
+{
+	// :268-290 — every coordinate wraps modulo the grid
+	const u32 idx = ((x >> 5) % P.cols) + (y % P.G) * P.cols + (z % P.G) * P.cols * P.G;
+	return (P.cells[idx] >> (x & 31u)) & 1u;
+}
+
+__device__ __forceinline__ void ray_cube(v3 o, v3 d, v3 center, v3 half, float &tnear, float &tfar)
+{
+	// :212-225
+	const v3 inv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+	const v3 tmin = ((center - half) - o) * inv;
+	const v3 tmax = ((center + half) - o) * inv;
+	const v3 t1 = V(fminf(tmin.x, tmax.x), fminf(tmin.y, tmax.y), fminf(tmin.z, tmax.z));
+	const v3 t2 = V(fmaxf(tmin.x, tmax.x), fmaxf(tmin.y, tmax.y), fmaxf(tmin.z, tmax.z));
+	tnear = fmaxf(fmaxf(t1.x, t1.y), t1.z);
+	tfar = fminf(fminf(t2.x, t2.y), t2.z);
+}
+
+__device__ __forceinline__ float sd_box(v3 p, v3 b)
+{
+	// :182-186
+	const v3 q = V(fabsf(p.x) - b.x, fabsf(p.y) - b.y, fabsf(p.z) - b.z);
+	const v3 m = V(fmaxf(q.x, 0.0f), fmaxf(q.y, 0.0f), fmaxf(q.z, 0.0f));
+	return len3(m) + fminf(fmaxf(q.x, fmaxf(q.y, q.z)), 0.0f);
+}
+
+__device__ __forceinline__ v3 face_normal(v3 p, v3 origin)
+{
+	// :227-254
+	const v3 d = p - origin;
+	const v3 a = V(fabsf(d.x), fabsf(d.y), fabsf(d.z));
+	const float m = fmaxf(fmaxf(a.x, a.y), a.z);
+	v3 n;
+	if (a.x == m) n = V(d.x, 0.0f, 0.0f);
+	else if (a.y == m) n = V(0.0f, d.y, 0.0f);
+	else n = V(0.0f, 0.0f, d.z);
+	return norm3(n);
+}
+
+__device__ __forceinline__ v3 cell_origin(float cs, int x, int y, int z)
+{
+	return V((float)x * cs + cs * 0.5f - kHalf, (float)y * cs + cs * 0.5f - kHalf, (float)z * cs + cs * 0.5f - kHalf);
+}
+
+__device__ v3 surface_brdf(v3 L, v3 Vd, v3 N, float roughness, v3 albedo, v3 F0)
+{
+	// :537-592
+	const v3 Hh = norm3(L + Vd);
+	const v3 fL = V(albedo.x / kPi, albedo.y / kPi, albedo.z / kPi);
+	const float a2 = roughness * roughness;
+	const float NoH = dot3(N, Hh);
+	const float NoH2 = NoH * NoH;
+	const float f = NoH2 * (a2 - 1.0f) + 1.0f;
+	const float D = a2 / (kPi * f * f);
+	const float n = roughness + 1.0f;
+	const float k = (n * n) / 8.0f;
+	const float NoV = fmaxf(0.0f, dot3(N, Vd));
+	const float gv = NoV / (NoV * (1.0f - k) + k);
+	const float NoL = fmaxf(0.0f, dot3(N, L));
+	const float gl = NoL / (NoL * (1.0f - k) + k);
+	const float Gm = gv * gl;
+	const float p = powf(1.0f - dot3(Hh, Vd), 5.0f);
+	const v3 F = V(F0.x + (1.0f - F0.x) * p, F0.y + (1.0f - F0.y) * p, F0.z + (1.0f - F0.z) * p);
+	const float denom = 4.0f * dot3(Vd, N) * dot3(L, N);
+	return V(fL.x + (D * Gm * F.x) / denom, fL.y + (D * Gm * F.y) / denom, fL.z + (D * Gm * F.z) / denom);
+}
+
+// Exact cell walk (Amanatides-Woo) from `start` along unit `dir` over (t0, tmax). SHADOW selects the visit test.
+// Returns true on a hit; `tnear_out` is the slab entry of the hit cube (primary only).
+template <bool SHADOW>
+__device__ bool walk(const RenderParams &P, v3 start, v3 dir, float t0, float tmax, v3 half, int sx0, int sy0, int sz0,
+                     float &tnear_out, u32 &visits)
+{
+	const int G = (int)P.G;
+	const float cs = 1.0f / (float)P.G;
+	const v3 p = start + dir * t0;
+	int ix = (int)floorf((p.x + kHalf) / cs), iy = (int)floorf((p.y + kHalf) / cs), iz = (int)floorf((p.z + kHalf) / cs);
+	ix = min(max(ix, 0), G - 1);
+	iy = min(max(iy, 0), G - 1);
+	iz = min(max(iz, 0), G - 1);
+	const int sx = dir.x > 0.0f ? 1 : -1, sy = dir.y > 0.0f ? 1 : -1, sz = dir.z > 0.0f ? 1 : -1;
+	const float big = 3.0e38f;
+	float tx = dir.x != 0.0f ? (((float)(ix + (sx > 0 ? 1 : 0)) * cs - kHalf) - start.x) / dir.x : big;
+	float ty = dir.y != 0.0f ? (((float)(iy + (sy > 0 ? 1 : 0)) * cs - kHalf) - start.y) / dir.y : big;
+	float tz = dir.z != 0.0f ? (((float)(iz + (sz > 0 ? 1 : 0)) * cs - kHalf) - start.z) / dir.z : big;
+	const float dx = dir.x != 0.0f ? cs / fabsf(dir.x) : big, dy = dir.y != 0.0f ? cs / fabsf(dir.y) : big,
+	            dz = dir.z != 0.0f ? cs / fabsf(dir.z) : big;
+	float t = t0;
+	// one packed word covers 32 x-cells of a row: keep it in a register while the walk stays inside it
+	u32 word = 0;
+	int wkey = -1;
+	for (int guard = 0; guard < 3 * G + 3; guard++)
+	{
+		if (t >= tmax) return false;
+		visits++;
+		const int key = (ix >> 5) + (iy + iz * G) * (int)P.cols;
+		if (key != wkey) { word = P.cells[key]; wkey = key; }
+		if ((word >> (ix & 31)) & 1u)
+		{
+			if (!(SHADOW && ix == sx0 && iy == sy0 && iz == sz0)) // any(cell != startCell) :664
+			{
+				float tn, tf;
+				ray_cube(start, dir, cell_origin(cs, ix, iy, iz), half, tn, tf);
+				if (SHADOW ? (tn <= tf && tn >= 0.0f) /* :668 */ : (tf >= 0.0f && tn <= tf) /* :722-729 */)
+				{
+					tnear_out = tn;
+					return true;
+				}
+			}
+		}
+		if (tx <= ty && tx <= tz) { t = tx; tx += dx; ix += sx; if (ix < 0 || ix >= G) return false; }
+		else if (ty <= tz) { t = ty; ty += dy; iy += sy; if (iy < 0 || iy >= G) return false; }
+		else { t = tz; tz += dz; iz += sz; if (iz < 0 || iz >= G) return false; }
+	}
+	return false;
+}
+
+struct Sample
+{
+	float r, g, b, a, depth;
+	u32 shadow_ray;
+};
+
+__device__ Sample shade_sample(const RenderParams &P, float vu, float vv, u32 &pvis, u32 &svis)
+{
+	const float *u = P.u;
+	const float *view = u + U_VIEW;
+	Sample s{0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0u};
+	const v3 cam = V(view[12], view[13], view[14]);
+	// getRay :188-197, then viewMat * vec4(ray, 0)
+	const float r = u[U_WINDOW] / u[U_WINDOW + 1];
+	const v3 rl = norm3(V((vu - 0.5f) * r, vv - 0.5f, -(0.5f * P.cot_half_fov)));
+	const v3 ray = V(view[0] * rl.x + view[4] * rl.y + view[8] * rl.z, view[1] * rl.x + view[5] * rl.y + view[9] * rl.z,
+	                 view[2] * rl.x + view[6] * rl.y + view[10] * rl.z);
+	const v3 half = V(kHalf, kHalf, kHalf);
+	float tn, tf;
+	ray_cube(cam, ray, V(0.0f, 0.0f, 0.0f), half, tn, tf);
+	const float cam_dist = sd_box(cam, half);
+	if (tn <= tf && tf >= 0.0f) // :822
+	{
+		v3 enter = cam;
+		const v3 exitp = cam + ray * tf;
+		if (cam_dist >= 0.0f) enter = cam + ray * tn;
+		const v3 seg = exitp - enter;
+		const v3 dir = norm3(seg);
+		const float depth_len = len3(seg);
+		const float cs = 1.0f / (float)P.G;
+		const float vis = cs * u[U_CELLSIZE] * 0.5f;
+		const v3 vhalf = V(vis, vis, vis);
+		float tnear = 0.0f;
+		const bool hit = walk<false>(P, enter, dir, 0.0f, depth_len, vhalf, 0, 0, 0, tnear, pvis);
+		const v3 final_point = hit ? enter + dir * tnear : exitp;
+		s.depth = len3(final_point - cam);  // :762, 774
+		const v3 p = cam + ray * s.depth;   // moreAccurateSamplePoint :840
+		// calculateLightingAndOcclusionAt :379-427
+		const v3 f = V(floorf((p.x + kHalf) / cs), floorf((p.y + kHalf) / cs), floorf((p.z + kHalf) / cs));
+		const v3 origin = V(f.x * cs + cs * 0.5f - kHalf, f.y * cs + cs * 0.5f - kHalf, f.z * cs + cs * 0.5f - kHalf);
+		const int cx = (int)f.x, cy = (int)f.y, cz = (int)f.z;
+		const u32 st = cell_state(P, (u32)cx, (u32)cy, (u32)cz);
+		const float dist = sd_box(p - origin, vhalf);
+		if (st == 1u && !(dist > 0.001f))
+		{
+			const v3 light_pos = V(u[U_LIGHT], u[U_LIGHT + 1], u[U_LIGHT + 2]);
+			const v3 ldir = norm3(light_pos - p);
+			float vn, vf;
+			ray_cube(p, ldir, V(0.0f, 0.0f, 0.0f), half, vn, vf);
+			const v3 vexit = p + ldir * vf;
+			const v3 sseg = vexit - p;
+			const v3 sdir = norm3(sseg);
+			const float slen = len3(sseg);
+			float dummy = 0.0f;
+			const bool occluded = walk<true>(P, p, sdir, 0.0025f, slen, vhalf, cx, cy, cz, dummy, svis);
+			const float occ = occluded ? kOcclusion : 1.0f;
+			// calculateLightingAt :594-633
+			const v3 N = face_normal(p, origin);
+			const float Gf = (float)P.G;
+			const float cxn = (float)(u32)cx / Gf, cyn = (float)(u32)cy / Gf;
+			v3 albedo = V(cxn, cyn, 1.0f - cxn);
+			if (u[U_MATERIALCOLOR] != 0.0f || u[U_MATERIALCOLOR + 1] != 0.0f || u[U_MATERIALCOLOR + 2] != 0.0f)
+				albedo = V(u[U_MATERIALCOLOR], u[U_MATERIALCOLOR + 1], u[U_MATERIALCOLOR + 2]);
+			const v3 Vd = norm3(cam - p);
+			const v3 L = norm3(light_pos - p);
+			const v3 F0 = V(u[U_REFLECTIVITY], u[U_REFLECTIVITY + 1], u[U_REFLECTIVITY + 2]);
+			const v3 brdf = surface_brdf(L, Vd, N, u[U_ROUGHNESS], albedo, F0);
+			const float mag = u[U_LIGHT + 3];
+			const float LoN = dot3(L, N);
+			s.r = occ * fmaxf(0.0f, brdf.x * mag * LoN);
+			s.g = occ * fmaxf(0.0f, brdf.y * mag * LoN);
+			s.b = occ * fmaxf(0.0f, brdf.z * mag * LoN);
+			s.shadow_ray = 1u;
+		}
+		// fixed point of clamp(mix(prev, cur, alpha), 0, 1) under a static camera :468
+		s.r = fminf(fmaxf(s.r, 0.0f), 1.0f);
+		s.g = fminf(fmaxf(s.g, 0.0f), 1.0f);
+		s.b = fminf(fmaxf(s.b, 0.0f), 1.0f);
+	}
+	{
+		// light gizmo :866-874
+		const v3 light_pos = V(u[U_LIGHT], u[U_LIGHT + 1], u[U_LIGHT + 2]);
+		float ln, lf;
+		ray_cube(cam, ray, light_pos, V(0.005f, 0.005f, 0.005f), ln, lf);
+		if (ln <= lf && lf >= 0.0f && s.r == 0.0f && s.g == 0.0f && s.b == 0.0f) { s.r = s.g = s.b = 1.0f; s.a = 1.0f; }
+	}
+	if (u[U_SHOWDEPTH] == 1.0f && vu < 0.5f) { s.r = s.depth; s.g = 0.0f; s.b = 0.0f; s.a = 1.0f; } // :880-883
+	return s;
+}
+
+__device__ __forceinline__ u32 unorm8(float x) { return (u32)__float2int_rn(fminf(fmaxf(x, 0.0f), 1.0f) * 255.0f); }
+
+__global__ __launch_bounds__(256) void ca_render_packed(RenderParams P)
+{
+	const u32 px = blockIdx.x * 16u + (threadIdx.x & 15u);
+	const u32 py = blockIdx.y * 16u + (threadIdx.x >> 4);
+	if (px >= P.W || py >= P.H) return;
+	float r = 0.0f, g = 0.0f, b = 0.0f, a = 0.0f, d0 = 0.0f;
+	u32 shadow = 0, pvis = 0, svis = 0;
+	for (u32 k = 0; k < P.spp; k++)
+	{
+		const float ox = P.spp == 1u ? 0.5f : ((k & 1u) ? 0.75f : 0.25f);
+		const float oy = P.spp == 1u ? 0.5f : ((k & 2u) ? 0.75f : 0.25f);
+		const float vu = ((float)px + ox) / (float)P.W, vv = 1.0f - ((float)py + oy) / (float)P.H;
+		const Sample s = shade_sample(P, vu, vv, pvis, svis);
+		r += s.r; g += s.g; b += s.b; a += s.a;
+		if (k == 0) d0 = s.depth;
+		shadow += s.shadow_ray;
+	}
+	const float inv = 1.0f / (float)P.spp;
+	r *= inv; g *= inv; b *= inv; a *= inv;
+	const size_t i = (size_t)py * P.W + px;
+	if (P.light)
+	{
+		const __half2 rg = __floats2half2_rn(r, g), ba = __floats2half2_rn(b, 1.0f);
+		uint2 v;
+		v.x = *reinterpret_cast<const u32 *>(&rg);
+		v.y = *reinterpret_cast<const u32 *>(&ba);
+		P.light[i] = v;
+	}
+	if (P.depth)
+	{
+		const __half2 d = __floats2half2_rn(d0, 1.0f);
+		P.depth[i] = *reinterpret_cast<const u32 *>(&d);
+	}
+	if (P.presentation)
+	{
+		const float ig = 1.0f / P.u[U_GAMMA];
+		P.presentation[i] = unorm8(powf(r, ig)) | (unorm8(powf(g, ig)) << 8) | (unorm8(powf(b, ig)) << 16) | (unorm8(a) << 24);
+	}
+	if (P.counters)
+	{
+		atomicAdd(&P.counters[0], (unsigned long long)shadow);
+		atomicAdd(&P.counters[1], (unsigned long long)pvis);
+		atomicAdd(&P.counters[2], (unsigned long long)svis);
+	}
+}
+
+} // namespace
+
+hipError_t launch_render(const RenderLaunch &l, hipStream_t stream)
+{
+	RenderParams P;
+	P.cells = l.cells;
+	P.G = l.G;
+	P.cols = l.G / 32u;
+	P.W = l.W;
+	P.H = l.H;
+	P.spp = l.spp;
+	P.cot_half_fov = (float)(1.0 / tan(37.5 * 3.14159265359 / 180.0)); // COT_HALF_FOV :70
+	for (int i = 0; i < U_LIVE; i++) P.u[i] = l.uniforms[i];
+	P.presentation = l.presentation;
+	P.light = reinterpret_cast<uint2 *>(l.light);
+	P.depth = l.depth;
+	P.counters = l.counters;
+	const dim3 grid((l.W + 15u) / 16u, (l.H + 15u) / 16u);
+	hipLaunchKernelGGL(ca_render_packed, grid, dim3(256), 0, stream, P);
+	return hipGetLastError();
+}
+
+} // namespace ca3d

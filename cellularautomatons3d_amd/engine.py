@@ -11,7 +11,7 @@ from typing import Optional, Sequence
 import numpy as np
 
 from . import _capi, host
-from ._capi import Ca3dError, Info, Stats  # noqa: F401
+from ._capi import Ca3dError, Info, RenderStats, Stats  # noqa: F401
 
 _u32p = C.POINTER(C.c_uint32)
 _i32p = C.POINTER(C.c_int32)
@@ -130,6 +130,28 @@ class Engine:
 
     def set_option(self, name: str, value: int) -> None:
         _capi.check(self._lib.ca3d_set_option(self._h, name.encode(), int(value)))
+
+    # -- rendering ------------------------------------------------------------------------------------------
+    def render(self, uniforms, width: int, height: int, spp: int = 1, readback: bool = True):
+        """`_renderPass` on the current state. Returns (presentation u8[H,W,4], light f16[H,W,4], depth f16[H,W,2])
+        when `readback`, else None (targets stay on the device)."""
+        u = np.ascontiguousarray(uniforms, dtype=np.float32)
+        if u.size != 128:
+            raise ValueError("the common uniform block holds 128 floats")
+        up = u.ctypes.data_as(C.POINTER(C.c_float))
+        if not readback:
+            _capi.check(self._lib.ca3d_render(self._h, up, width, height, spp, None, None, None))
+            return None
+        pres = np.empty((height, width, 4), dtype=np.uint8)
+        light = np.empty((height, width, 4), dtype=np.float16)
+        depth = np.empty((height, width, 2), dtype=np.float16)
+        _capi.check(self._lib.ca3d_render(self._h, up, width, height, spp, pres.ctypes.data, light.ctypes.data, depth.ctypes.data))
+        return pres, light, depth
+
+    def render_stats(self) -> RenderStats:
+        s = RenderStats()
+        _capi.check(self._lib.ca3d_get_render_stats(self._h, C.byref(s)))
+        return s
 
     def info(self) -> Info:
         i = Info()

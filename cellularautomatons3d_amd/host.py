@@ -212,3 +212,100 @@ def cells_to_words(grid_size: int, cells: Iterable[Sequence[int]]) -> np.ndarray
 
 def get_cell(grid_size: int, words: np.ndarray, x: int, y: int, z: int) -> int:
     return int((int(words[get_cluster_idx_from_grid_coordinates(grid_size, x, y, z)]) >> (x % 32)) & 1)
+
+
+# ------------------------------------------------------------------------------------------------ renderer
+# The 128-float common uniform block (MemoryManager.js; allocation order main_pathtraced.js:166, 467-478 ==
+# struct CommonBufferLayout, pathtraced_fragment_clustered.wgsl:17-34). Matrices are column-major f32.
+
+UNIFORM_INDEX = {
+    "light": 0, "viewMat": 4, "projViewMatInv": 20, "prevViewMat": 36, "prevProjViewMatInv": 52, "windowSize": 68,
+    "elapsedTime": 70, "depthSamples": 71, "shadowSamples": 72, "cellSize": 73, "showDepthOverlay": 74,
+    "temporalAlpha": 75, "baseReflectivity": 76, "roughness": 79, "materialColor": 80, "gamma": 83,
+}
+
+RENDER_DEFAULTS = {  # main_pathtraced.js:116-121, 135-152, 164-165
+    "light": (0.721, 1.0, 1.0, 5.0), "depthSamples": 35, "shadowSamples": 30, "cellSize": 0.85, "showDepthOverlay": 0,
+    "temporalAlpha": 0.1, "baseReflectivity": (0.17, 0.17, 0.17), "roughness": 0.29, "materialColor": (0.0, 0.0, 0.0),
+    "gamma": 2.0, "fov_deg": 75.0, "near": 0.01, "far": 1000.0,
+}
+
+
+def mat4_perspective(fov_rad: float, aspect: float, near: float, far: float) -> np.ndarray:
+    """wgpu-matrix mat4.perspective (libs/wgpu-matrix.module.js:3140): depth 0..1, column-major."""
+    f = np.float32(math.tan(math.pi * 0.5 - 0.5 * fov_rad))
+    m = np.zeros(16, dtype=np.float32)
+    m[0] = f / np.float32(aspect)
+    m[5] = f
+    m[11] = -1.0
+    range_inv = np.float32(1.0 / (near - far))
+    m[10] = np.float32(far) * range_inv
+    m[14] = np.float32(far) * np.float32(near) * range_inv
+    return m
+
+
+def mat4_multiply(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """mat4.multiply(a, b) = a * b on column-major arrays."""
+    A = np.asarray(a, dtype=np.float32).reshape(4, 4).T
+    B = np.asarray(b, dtype=np.float32).reshape(4, 4).T
+    return (A @ B).T.reshape(16).astype(np.float32)
+
+
+def mat4_inverse(m: np.ndarray) -> np.ndarray:
+    M = np.asarray(m, dtype=np.float64).reshape(4, 4).T
+    return np.linalg.inv(M).T.reshape(16).astype(np.float32)
+
+
+def camera_matrix(position=(0.0, 0.0, 0.75), axis=(0.0, 1.0, 0.0), angle_rad: float = 0.0) -> np.ndarray:
+    """Camera-to-world `viewMat` (the shader reads cameraPos = viewMat[3].xyz, :812): rotation about `axis`
+    followed by translation to `position`. Default = the reference's start pose (main_pathtraced.js:207-213)."""
+    ax = np.asarray(axis, dtype=np.float64)
+    ax = ax / np.linalg.norm(ax)
+    c, s = math.cos(angle_rad), math.sin(angle_rad)
+    x, y, z = ax
+    R = np.array([[c + x * x * (1 - c), x * y * (1 - c) - z * s, x * z * (1 - c) + y * s],
+                  [y * x * (1 - c) + z * s, c + y * y * (1 - c), y * z * (1 - c) - x * s],
+                  [z * x * (1 - c) - y * s, z * y * (1 - c) + x * s, c + z * z * (1 - c)]])
+    M = np.eye(4)
+    M[:3, :3] = R
+    M[:3, 3] = position
+    return M.T.reshape(16).astype(np.float32)
+
+
+def orbit_camera(distance: float = 1.4, axis=(1.0, 1.0, 0.0), angle_rad: float = 0.6) -> np.ndarray:
+    """The oblique bench pose: rotate about `axis`, camera at `distance` looking at the origin."""
+    m = camera_matrix((0.0, 0.0, 0.0), axis, angle_rad).reshape(4, 4).T.astype(np.float64)
+    pos = m[:3, :3] @ np.array([0.0, 0.0, distance])
+    return camera_matrix(tuple(pos), axis, angle_rad)
+
+
+def uniform_block(width: int, height: int, view_mat: Optional[np.ndarray] = None, elapsed_time: float = 0.5,
+                  prev_view_mat: Optional[np.ndarray] = None, **overrides) -> np.ndarray:
+    """Fill the common block the way `_setupUniformsMemoryCPU` / `_updateMatrices` / `_updateUIValues` do
+    (main_pathtraced.js:464-518, 1762-1773). `overrides` may set any key of RENDER_DEFAULTS."""
+    p = dict(RENDER_DEFAULTS)
+    for k, v in overrides.items():
+        if k not in p:
+            raise KeyError(k)
+        p[k] = v
+    u = np.zeros(128, dtype=np.float32)
+    if view_mat is None:
+        view_mat = camera_matrix()
+    view_mat = np.asarray(view_mat, dtype=np.float32)
+    proj = mat4_perspective(p["fov_deg"] * math.pi / 180.0, width / height, p["near"], p["far"])
+    pvi = mat4_multiply(proj, mat4_inverse(view_mat))
+    I = UNIFORM_INDEX
+    u[I["light"]:I["light"] + 4] = p["light"]
+    u[I["viewMat"]:I["viewMat"] + 16] = view_mat
+    u[I["projViewMatInv"]:I["projViewMatInv"] + 16] = pvi
+    if prev_view_mat is not None:
+        prev_view_mat = np.asarray(prev_view_mat, dtype=np.float32)
+        u[I["prevViewMat"]:I["prevViewMat"] + 16] = prev_view_mat
+        u[I["prevProjViewMatInv"]:I["prevProjViewMatInv"] + 16] = mat4_multiply(proj, mat4_inverse(prev_view_mat))
+    u[I["windowSize"]:I["windowSize"] + 2] = (width, height)
+    u[I["elapsedTime"]] = elapsed_time
+    for k in ("depthSamples", "shadowSamples", "cellSize", "showDepthOverlay", "temporalAlpha", "roughness", "gamma"):
+        u[I[k]] = p[k]
+    u[I["baseReflectivity"]:I["baseReflectivity"] + 3] = p["baseReflectivity"]
+    u[I["materialColor"]:I["materialColor"] + 3] = p["materialColor"]
+    return u

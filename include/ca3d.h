@@ -144,6 +144,31 @@ typedef struct ca3d_stats
 } ca3d_stats;
 int ca3d_get_stats(ca3d_t *h, ca3d_stats *out);
 
+/*
+ * _updateUniforms + _renderPass (main_pathtraced.js:1747-1750, 1775-1794) and the history textures (729-779):
+ * renders the CURRENT state (buffer step % 2, as bind group 2 of the render pass, 1788) through the volume
+ * renderer. `uniforms` is the reference's 128-float common block verbatim (MemoryManager.bufferf32; layout
+ * pathtraced_fragment_clustered.wgsl:17-34); width/height give the pixel grid (the shader's windowSize
+ * uniform supplies the aspect ratio, as in the reference). spp is 1 (pixel centre) or 4 (2x2 stratified
+ * sub-samples averaged in linear light before gamma). Outputs, each nullable, row-major, top row first:
+ *   presentation_rgba8  width*height*4 bytes   pow(rgb, 1/gamma), alpha  -> the canvas attachment
+ *   light_rgba16f       width*height*4 halfs   linear rgb, 1              -> light history attachment
+ *   depth_rg16f         width*height*2 halfs   distance from camera, 1    -> depth history attachment
+ * The engine keeps the device-side targets and swaps its two history surfaces per call (1793). Packed layout,
+ * full grid only. Synchronous only when an output pointer is given.
+ */
+int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t height, uint32_t spp,
+                uint8_t *presentation_rgba8, uint16_t *light_rgba16f, uint16_t *depth_rg16f);
+
+typedef struct ca3d_render_stats
+{
+	double gpu_ms;          /* hipEvent time of the last ca3d_render kernel */
+	uint64_t primary_rays;  /* width * height * spp */
+	uint64_t shadow_rays;   /* samples that reached the shading gate and traced a shadow ray */
+	uint64_t primary_cell_visits, shadow_cell_visits; /* cells the two walks stepped through */
+} ca3d_render_stats;
+int ca3d_get_render_stats(ca3d_t *h, ca3d_render_stats *out);
+
 /* Tuning knobs (not part of the reference surface): "graph" 0/1 hipGraph batching, "variant" kernel override. */
 int ca3d_set_option(ca3d_t *h, const char *name, int64_t value);
 

@@ -146,3 +146,31 @@ def fill(n_words, seed=0xCA3D0001, and_rounds=0):
     out = np.empty(n_words, dtype=np.uint32)
     lib().ca3d_oracle_fill(out.ctypes.data, n_words, seed, and_rounds)
     return out
+
+
+def render(cells, G, uniforms, W, H, spp=1, rows=None):
+    """Oracle frame: (light f32[H,W,4], depth f32[H,W,2], presentation f32[H,W,4], shadow_rays)."""
+    c, cp = _u32(cells)
+    u = np.ascontiguousarray(uniforms, dtype=np.float32)
+    light = np.zeros((H, W, 4), dtype=np.float32)
+    depth = np.zeros((H, W, 2), dtype=np.float32)
+    pres = np.zeros((H, W, 4), dtype=np.float32)
+    y0, y1 = rows if rows else (0, H)
+    fn = lib().ca3d_oracle_render
+    fn.restype = C.c_int64
+    n = fn(cp, C.c_uint32(G), u.ctypes.data_as(C.POINTER(C.c_float)), C.c_uint32(W), C.c_uint32(H), C.c_uint32(spp),
+           light.ctypes.data_as(C.POINTER(C.c_float)), depth.ctypes.data_as(C.POINTER(C.c_float)),
+           pres.ctypes.data_as(C.POINTER(C.c_float)), C.c_uint32(y0), C.c_uint32(y1))
+    assert n >= 0, n
+    return light, depth, pres, int(n)
+
+
+def primary_bruteforce(cells, G, uniforms, W, H, px, py):
+    c, cp = _u32(cells)
+    u = np.ascontiguousarray(uniforms, dtype=np.float32)
+    cell = C.c_int64(-1)
+    fn = lib().ca3d_oracle_primary_bruteforce
+    fn.restype = C.c_float
+    d = fn(cp, C.c_uint32(G), u.ctypes.data_as(C.POINTER(C.c_float)), C.c_uint32(W), C.c_uint32(H), C.c_uint32(px),
+           C.c_uint32(py), C.byref(cell))
+    return float(d), int(cell.value)

@@ -1,0 +1,104 @@
+"""CPU checks of the renderer's host surface and oracle: the uniform block against the values captured from the
+reference host, the exact cell walk against a brute-force visibility search, analytic known answers."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from cellularautomatons3d_amd import host
+
+
+def test_uniform_block_matches_reference_host(golden):
+    ub = golden["uniform_block"]
+    W, H = golden["window"]
+    got = host.uniform_block(W, H, elapsed_time=0.0)
+    want = np.array(ub["f32"], dtype=np.float32)
+    np.testing.assert_array_equal(got[:4], want[:4])
+    np.testing.assert_array_equal(got[4:20], want[4:20])  # viewMat: identity + (0, 0, 0.75)
+    np.testing.assert_allclose(got[20:36], want[20:36], rtol=0, atol=3e-7)  # proj * inverse(view)
+    np.testing.assert_array_equal(got[36:68], want[36:68])  # previous-frame matrices are zero on frame 1
+    np.testing.assert_array_equal(got[68:84], want[68:84])
+    assert ub["indices"] == {"light": 0, "viewMatrices": 4, "windowSize": 68, "elapsedTime": 70, "depthSamples": 71,
+                             "shadowSamples": 72, "cellSize": 73, "showDepthOverlay": 74, "temporalAlpha": 75,
+                             "baseReflectivity": 76, "roughness": 79, "materialColor": 80, "gamma": 83}
+    np.testing.assert_allclose(host.mat4_perspective(ub["fov"], W / H, 0.01, 1000.0), ub["projectionMat"], rtol=0, atol=3e-7)
+    # second frame: prev matrices = current ones
+    got2 = host.uniform_block(W, H, elapsed_time=0.0, prev_view_mat=host.camera_matrix())
+    np.testing.assert_allclose(got2[:84], np.array(ub["f32_second_frame"], dtype=np.float32)[:84], rtol=0, atol=3e-7)
+
+
+def _scene(G, seed=3, rounds=4):
+    cells = host.random_fill(host.words_per_buffer(G), seed=seed, and_rounds=rounds)
+    return cells
+
+
+@pytest.mark.parametrize("pose", ["default", "oblique"])
+def test_walk_equals_bruteforce_visibility(pose):
+    G, W, H = 32, 48, 27
+    cells = _scene(G)
+    vm = host.camera_matrix() if pose == "default" else host.orbit_camera()
+    u = host.uniform_block(W, H, vm)
+    _, depth, _, _ = ol.render(cells, G, u, W, H)
+    bad = 0
+    for py in range(0, H, 2):
+        for px in range(0, W, 2):
+            d, cell = ol.primary_bruteforce(cells, G, u, W, H, px, py)
+            got = depth[py, px, 0]
+            if d < 0:
+                assert got == 0.0
+            elif abs(got - d) > 1e-5:
+                bad += 1
+    assert bad == 0
+
+
+def test_single_cell_known_answer():
+    # One alive cell at the volume centre, default pose: the centre pixel hits its +z face at
+    # z = origin + visible half = (c + .5)/G - .5 + .85/(2G); depth = 0.75 - z; shaded, unoccluded.
+    G, W, H = 32, 65, 65
+    c = 16
+    cells = host.cells_to_words(G, [(c, c, c)])
+    u = host.uniform_block(W, H)
+    light, depth, pres, shadow = ol.render(cells, G, u, W, H)
+    z_face = (c + 0.5) / G - 0.5 + 0.85 / (2 * G)
+    # the centre ray passes through (0,0): cell (16,16,16) spans [0, 1/32] in x and y; its visible cube [0.0023, 0.029]
+    # so shoot at the pixel over the cube centre instead
+    x_c = (c + 0.5) / G - 0.5
+    # u - .5 = x / ((0.75 - z) * 2 tan(37.5deg)) (aspect 1)
+    t = np.tan(np.radians(37.5))
+    px = int((x_c / ((0.75 - z_face) * 2 * t) + 0.5) * W)
+    py = int((0.5 - x_c / ((0.75 - z_face) * 2 * t)) * H)
+    assert light[py, px, :3].max() > 0.05
+    ray_len = depth[py, px, 0]
+    assert abs(ray_len - np.hypot(np.hypot(0.75 - z_face, 0), 0)) < 2e-2  # oblique by less than one pixel
+    assert shadow >= 1
+    # pixels that miss the volume entirely are black with depth 0; volume misses keep the exit depth
+    assert depth[0, 0, 0] == 0.0 or depth[0, 0, 0] > 0.5
+    assert (pres[..., 3] == 1.0).all()
+
+
+def test_shadow_known_answer():
+    # A cell on the light ray (but off the view ray) of a lit face scales its colour by OCCLUSION_FACTOR = 0.0095.
+    G, W, H = 32, 257, 257
+    u = host.uniform_block(W, H, light=(0.3, 0.0156, 0.75, 0.5))  # dim light: stay below the clamp
+    far = host.cells_to_words(G, [(16, 16, 10)])
+    occ = host.cells_to_words(G, [(16, 16, 10), (19, 16, 20)])
+    l1, d1, _, _ = ol.render(far, G, u, W, H)
+    l2, d2, _, _ = ol.render(occ, G, u, W, H)
+    same = (d1[..., 0] == d2[..., 0]) & (l1[..., :3].sum(-1) > 0.02)  # pixels still showing the far cell's face
+    assert same.sum() >= 12
+    ratio = l2[same][:, :3].sum(-1) / l1[same][:, :3].sum(-1)
+    shadowed = np.abs(ratio - 0.0095) < 1e-4
+    assert shadowed.sum() >= 0.6 * same.sum()
+    assert (shadowed | (np.abs(ratio - 1.0) < 1e-6)).all()  # binary: fully lit or occluded
+
+
+def test_spp4_is_mean_of_subsamples_and_gamma():
+    G, W, H = 32, 24, 16
+    cells = _scene(G, seed=8, rounds=3)
+    u = host.uniform_block(W, H, host.orbit_camera())
+    light4, _, pres4, _ = ol.render(cells, G, u, W, H, spp=4)
+    # a 2x supersampled spp=1 frame has its pixel centres exactly at the 2x2 stratified offsets
+    u2 = host.uniform_block(W, H, host.orbit_camera())
+    light1, _, _, _ = ol.render(cells, G, u2, 2 * W, 2 * H, spp=1)
+    mean = light1[..., :3].reshape(H, 2, W, 2, 3).mean(axis=(1, 3))
+    np.testing.assert_allclose(light4[..., :3], mean, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(pres4[..., :3], np.power(light4[..., :3], 0.5), rtol=0, atol=1e-6)

@@ -42,6 +42,10 @@ def parse():
     ap.add_argument("--ghost", type=int, default=8, help="ghost planes per side = steps between halo exchanges (N>1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-render", action="store_true", help="skip the renderer leg (N=1 only)")
+    ap.add_argument("--render-size", default="1920x1080")
+    ap.add_argument("--render-spp", type=int, default=4)
+    ap.add_argument("--render-frames", type=int, default=10)
     ap.add_argument("--check", action="store_true", help="verify the final state against the oracle (small grids)")
     return ap.parse_args()
 
@@ -66,6 +70,57 @@ def cpu_baseline(G, rule_kw, seconds):
             break
     return {"value": round(G ** 3 * n / dt / 1e9, 4), "unit": "Gcells/s", "cores": threads, "kind": "port",
             "sample": f"{n} steps of the {G}^3 packed grid, rule '{rule_kw.get('neighbourhood')}', oracle/ca_oracle.c word-parallel form, {dt:.1f} s"}
+
+
+def cpu_baseline_js(seconds=4.0, G=256):
+    """the JavaScript CPU stepper (oracle/js_stepper.js), single thread, on this host."""
+    import shutil
+    import subprocess
+
+    node = shutil.which("node")
+    if not node:
+        return None
+    try:
+        r = subprocess.run([node, os.path.join(ROOT, "oracle", "js_stepper.js"), "bench", str(G), str(seconds)],
+                           capture_output=True, text=True, timeout=120)
+        d = json.loads(r.stdout)
+        return {"value": round(d["gcells_s"], 4), "unit": "Gcells/s", "cores": 1, "kind": "port",
+                "sample": f"{d['steps']} steps of the {G}^3 packed grid, default rule, oracle/js_stepper.js on node {d['node']}, "
+                          f"{d['seconds']:.1f} s; host has {d['cpus']} x {d['cpu_model']}"}
+    except Exception as e:  # baseline only: never fail the bench for it
+        return {"error": str(e)}
+
+
+def render_leg(eng, G, a):
+    """Second half of BASELINE's metric: Mray/s of the volume renderer at 1080p, 4 spp, on the same grid size.
+    Volume = hashed fill of density 2^-5 (dense silhouette), oblique bench pose; rays = primary +
+    shadow rays traced; frames stay on the device (no read-back in the timed region)."""
+    import torch
+
+    from cellularautomatons3d_amd import host
+
+    W, H = (int(v) for v in a.render_size.lower().split("x"))
+    cells = host.random_fill(host.words_per_buffer(G), seed=0xCA3D0001, and_rounds=4)
+    eng.upload_state(cells)
+    u = host.uniform_block(W, H, host.orbit_camera())
+    for _ in range(2):
+        eng.render(u, W, H, a.render_spp, readback=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    gpu_ms = 0.0
+    for _ in range(a.render_frames):
+        eng.render(u, W, H, a.render_spp, readback=False)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st = eng.render_stats()
+    rays = st.primary_rays + st.shadow_rays
+    return {"metric": "Mray/s path-trace 1080p", "value": round(rays * a.render_frames / dt / 1e6, 2), "unit": "Mray/s",
+            "ms_per_frame": round(dt * 1e3 / a.render_frames, 4), "kernel_ms": round(st.gpu_ms, 4),
+            "primary_rays": int(st.primary_rays), "shadow_rays": int(st.shadow_rays),
+            "cell_visits_per_primary_ray": round(st.primary_cell_visits / max(1, st.primary_rays), 2),
+            "cell_visits_per_shadow_ray": round(st.shadow_cell_visits / max(1, st.shadow_rays), 2),
+            "config": {"workload": f"{G}^3 packed volume, hashed fill density 2^-5, {W}x{H} @ {a.render_spp} spp, oblique pose "
+                                   "(0.6 rad about (1,1,0), distance 1.4), exact DDA walk + shadow ray + Cook-Torrance"}}
 
 
 def pmc_traffic(kernel, G):
@@ -177,8 +232,11 @@ def main():
         }
         if ok is not None:
             out["oracle_match"] = ok
+        if world == 1 and not a.no_render:
+            out["render"] = render_leg(eng, G, a)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(G, rule_kw, a.cpu_seconds)
+            out["cpu_baseline_js"] = cpu_baseline_js()
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

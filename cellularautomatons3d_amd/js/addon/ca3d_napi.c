@@ -1,0 +1,381 @@
+/*
+ * N-API addon: the JavaScript face of include/ca3d.h, 1:1, typed arrays in and out. This is the binding a
+ * maintainer of main_pathtraced.js adds in place of the navigator.gpu calls. No logic lives
+ * here: every function forwards to libca3d.so and throws a JS Error carrying ca3d_last_error() on failure.
+ *
+ * Built with plain gcc against /usr/include/node (N-API 8 headers; Node >= 12).
+ */
+#include <node_api.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "ca3d.h"
+
+#define NAPI_OK_OR_NULL(call)                                  \
+	do {                                                       \
+		if ((call) != napi_ok) {                               \
+			napi_throw_error(env, NULL, "N-API call failed: " #call); \
+			return NULL;                                       \
+		}                                                      \
+	} while (0)
+
+static napi_value throw_ca3d(napi_env env, int rc)
+{
+	char msg[600];
+	snprintf(msg, sizeof msg, "ca3d error %d: %s", rc, ca3d_last_error());
+	napi_throw_error(env, NULL, msg);
+	return NULL;
+}
+
+static napi_value undefined(napi_env env)
+{
+	napi_value u;
+	napi_get_undefined(env, &u);
+	return u;
+}
+
+static int get_args(napi_env env, napi_callback_info info, size_t want, napi_value *argv)
+{
+	size_t argc = want;
+	if (napi_get_cb_info(env, info, &argc, argv, NULL, NULL) != napi_ok || argc < want)
+	{
+		napi_throw_type_error(env, NULL, "wrong number of arguments");
+		return 0;
+	}
+	return 1;
+}
+
+static ca3d_t *get_handle(napi_env env, napi_value v)
+{
+	void *p = NULL;
+	if (napi_get_value_external(env, v, &p) != napi_ok || !p)
+	{
+		napi_throw_type_error(env, NULL, "expected an engine handle");
+		return NULL;
+	}
+	return *(ca3d_t **)p;
+}
+
+static int get_u32(napi_env env, napi_value v, uint32_t *out)
+{
+	if (napi_get_value_uint32(env, v, out) != napi_ok)
+	{
+		napi_throw_type_error(env, NULL, "expected an unsigned integer");
+		return 0;
+	}
+	return 1;
+}
+
+/* typed array of the given element type, or null/undefined when `nullable` */
+static int get_typed(napi_env env, napi_value v, napi_typedarray_type want, int nullable, void **data, size_t *len)
+{
+	napi_valuetype t;
+	napi_typeof(env, v, &t);
+	if (nullable && (t == napi_null || t == napi_undefined))
+	{
+		*data = NULL;
+		*len = 0;
+		return 1;
+	}
+	bool is = false;
+	napi_is_typedarray(env, v, &is);
+	napi_typedarray_type type;
+	napi_value ab;
+	size_t off;
+	if (!is || napi_get_typedarray_info(env, v, &type, len, data, &ab, &off) != napi_ok || type != want)
+	{
+		napi_throw_type_error(env, NULL, "expected a typed array of the documented element type");
+		return 0;
+	}
+	return 1;
+}
+
+static void finalize_handle(napi_env env, void *data, void *hint)
+{
+	(void)env;
+	(void)hint;
+	ca3d_t **slot = (ca3d_t **)data;
+	if (*slot) ca3d_destroy(*slot);
+	*slot = NULL;
+	free(slot);
+}
+
+static napi_value js_create(napi_env env, napi_callback_info info)
+{
+	napi_value argv[1];
+	if (!get_args(env, info, 1, argv)) return NULL;
+	int32_t device = 0;
+	napi_get_value_int32(env, argv[0], &device);
+	ca3d_t *h = NULL;
+	int rc = ca3d_create(device, &h);
+	if (rc) return throw_ca3d(env, rc);
+	ca3d_t **slot = (ca3d_t **)malloc(sizeof *slot);
+	*slot = h;
+	napi_value ext;
+	NAPI_OK_OR_NULL(napi_create_external(env, slot, finalize_handle, NULL, &ext));
+	return ext;
+}
+
+static napi_value js_destroy(napi_env env, napi_callback_info info)
+{
+	napi_value argv[1];
+	if (!get_args(env, info, 1, argv)) return NULL;
+	void *p = NULL;
+	if (napi_get_value_external(env, argv[0], &p) == napi_ok && p)
+	{
+		ca3d_t **slot = (ca3d_t **)p;
+		if (*slot) ca3d_destroy(*slot);
+		*slot = NULL;
+	}
+	return undefined(env);
+}
+
+static napi_value js_device_count(napi_env env, napi_callback_info info)
+{
+	(void)info;
+	int n = 0;
+	int rc = ca3d_device_count(&n);
+	if (rc) return throw_ca3d(env, rc);
+	napi_value v;
+	napi_create_int32(env, n, &v);
+	return v;
+}
+
+static napi_value js_configure(napi_env env, napi_callback_info info)
+{
+	napi_value argv[3];
+	if (!get_args(env, info, 3, argv)) return NULL;
+	ca3d_t *h = get_handle(env, argv[0]);
+	uint32_t g, layout;
+	if (!h || !get_u32(env, argv[1], &g) || !get_u32(env, argv[2], &layout)) return NULL;
+	int rc = ca3d_configure(h, g, g, g, (int)layout);
+	return rc ? throw_ca3d(env, rc) : undefined(env);
+}
+
+static napi_value js_configure_slab(napi_env env, napi_callback_info info)
+{
+	napi_value argv[6];
+	if (!get_args(env, info, 6, argv)) return NULL;
+	ca3d_t *h = get_handle(env, argv[0]);
+	uint32_t g, layout, z0, nz, ghost;
+	if (!h || !get_u32(env, argv[1], &g) || !get_u32(env, argv[2], &layout) || !get_u32(env, argv[3], &z0) ||
+	    !get_u32(env, argv[4], &nz) || !get_u32(env, argv[5], &ghost))
+		return NULL;
+	int rc = ca3d_configure_slab(h, g, (int)layout, z0, nz, ghost);
+	return rc ? throw_ca3d(env, rc) : undefined(env);
+}
+
+static napi_value js_set_rules(napi_env env, napi_callback_info info)
+{
+	napi_value argv[6];
+	if (!get_args(env, info, 6, argv)) return NULL;
+	ca3d_t *h = get_handle(env, argv[0]);
+	if (!h) return NULL;
+	void *m, *e, *c, *s, *b;
+	size_t nm, ne, nc, ns, nb;
+	if (!get_typed(env, argv[1], napi_int32_array, 0, &m, &nm) || !get_typed(env, argv[2], napi_int32_array, 0, &e, &ne) ||
+	    !get_typed(env, argv[3], napi_int32_array, 0, &c, &nc) || !get_typed(env, argv[4], napi_uint32_array, 0, &s, &ns) ||
+	    !get_typed(env, argv[5], napi_uint32_array, 0, &b, &nb))
+		return NULL;
+	if (ns != CA3D_LUT_LEN || nb != CA3D_LUT_LEN)
+	{
+		napi_throw_range_error(env, NULL, "survive/born must be Uint32Array(81)");
+		return NULL;
+	}
+	int rc = ca3d_set_rules(h, (const int32_t *)m, (uint32_t)nm, (const int32_t *)e, (uint32_t)ne, (const int32_t *)c,
+	                        (uint32_t)nc, (const uint32_t *)s, (const uint32_t *)b);
+	return rc ? throw_ca3d(env, rc) : undefined(env);
+}
+
+static napi_value js_upload_state(napi_env env, napi_callback_info info)
+{
+	napi_value argv[2];
+	if (!get_args(env, info, 2, argv)) return NULL;
+	ca3d_t *h = get_handle(env, argv[0]);
+	void *w;
+	size_t n;
+	if (!h || !get_typed(env, argv[1], napi_uint32_array, 0, &w, &n)) return NULL;
+	int rc = ca3d_upload_state(h, (const uint32_t *)w, n);
+	return rc ? throw_ca3d(env, rc) : undefined(env);
+}
+
+static napi_value js_read_state(napi_env env, napi_callback_info info)
+{
+	napi_value argv[2];
+	if (!get_args(env, info, 2, argv)) return NULL;
+	ca3d_t *h = get_handle(env, argv[0]);
+	void *w;
+	size_t n;
+	if (!h || !get_typed(env, argv[1], napi_uint32_array, 0, &w, &n)) return NULL;
+	int rc = ca3d_read_state(h, (uint32_t *)w, n);
+	return rc ? throw_ca3d(env, rc) : undefined(env);
+}
+
+static napi_value js_step(napi_env env, napi_callback_info info)
+{
+	napi_value argv[2];
+	if (!get_args(env, info, 2, argv)) return NULL;
+	ca3d_t *h = get_handle(env, argv[0]);
+	uint32_t n;
+	if (!h || !get_u32(env, argv[1], &n)) return NULL;
+	int rc = ca3d_step(h, n);
+	return rc ? throw_ca3d(env, rc) : undefined(env);
+}
+
+static napi_value js_slab_step(napi_env env, napi_callback_info info)
+{
+	napi_value argv[2];
+	if (!get_args(env, info, 2, argv)) return NULL;
+	ca3d_t *h = get_handle(env, argv[0]);
+	uint32_t n;
+	if (!h || !get_u32(env, argv[1], &n)) return NULL;
+	int rc = ca3d_slab_step(h, n);
+	return rc ? throw_ca3d(env, rc) : undefined(env);
+}
+
+static napi_value js_synchronize(napi_env env, napi_callback_info info)
+{
+	napi_value argv[1];
+	if (!get_args(env, info, 1, argv)) return NULL;
+	ca3d_t *h = get_handle(env, argv[0]);
+	if (!h) return NULL;
+	int rc = ca3d_synchronize(h);
+	return rc ? throw_ca3d(env, rc) : undefined(env);
+}
+
+static void set_num(napi_env env, napi_value obj, const char *k, double v)
+{
+	napi_value n;
+	napi_create_double(env, v, &n);
+	napi_set_named_property(env, obj, k, n);
+}
+
+static napi_value js_info(napi_env env, napi_callback_info info)
+{
+	napi_value argv[1];
+	if (!get_args(env, info, 1, argv)) return NULL;
+	ca3d_t *h = get_handle(env, argv[0]);
+	if (!h) return NULL;
+	ca3d_info i;
+	int rc = ca3d_get_info(h, &i);
+	if (rc) return throw_ca3d(env, rc);
+	napi_value o, s;
+	napi_create_object(env, &o);
+	set_num(env, o, "gridSize", i.grid_size);
+	set_num(env, o, "layout", i.layout);
+	set_num(env, o, "z0", i.z0);
+	set_num(env, o, "nz", i.nz);
+	set_num(env, o, "ghost", i.ghost);
+	set_num(env, o, "step", (double)i.step);
+	set_num(env, o, "stateWords", (double)i.state_words);
+	set_num(env, o, "currentBuffer", i.current_buffer);
+	set_num(env, o, "device", i.device);
+	napi_create_string_utf8(env, i.kernel_name, NAPI_AUTO_LENGTH, &s);
+	napi_set_named_property(env, o, "kernelName", s);
+	return o;
+}
+
+static napi_value js_stats(napi_env env, napi_callback_info info)
+{
+	napi_value argv[1];
+	if (!get_args(env, info, 1, argv)) return NULL;
+	ca3d_t *h = get_handle(env, argv[0]);
+	if (!h) return NULL;
+	ca3d_stats st;
+	int rc = ca3d_get_stats(h, &st);
+	if (rc) return throw_ca3d(env, rc);
+	napi_value o;
+	napi_create_object(env, &o);
+	set_num(env, o, "steps", (double)st.steps);
+	set_num(env, o, "kernelLaunches", (double)st.kernel_launches);
+	set_num(env, o, "gpuMs", st.gpu_ms);
+	set_num(env, o, "cellSteps", st.cell_steps);
+	set_num(env, o, "algorithmicBytes", st.algorithmic_bytes);
+	return o;
+}
+
+static napi_value js_render(napi_env env, napi_callback_info info)
+{
+	napi_value argv[8];
+	if (!get_args(env, info, 8, argv)) return NULL;
+	ca3d_t *h = get_handle(env, argv[0]);
+	if (!h) return NULL;
+	void *u, *pres, *light, *depth;
+	size_t nu, npres, nlight, ndepth;
+	uint32_t w, hh, spp;
+	if (!get_typed(env, argv[1], napi_float32_array, 0, &u, &nu) || !get_u32(env, argv[2], &w) || !get_u32(env, argv[3], &hh) ||
+	    !get_u32(env, argv[4], &spp) || !get_typed(env, argv[5], napi_uint8_array, 1, &pres, &npres) ||
+	    !get_typed(env, argv[6], napi_uint16_array, 1, &light, &nlight) || !get_typed(env, argv[7], napi_uint16_array, 1, &depth, &ndepth))
+		return NULL;
+	const size_t px = (size_t)w * hh;
+	if (nu != 128 || (pres && npres != px * 4) || (light && nlight != px * 4) || (depth && ndepth != px * 2))
+	{
+		napi_throw_range_error(env, NULL, "uniforms must be Float32Array(128); targets must match width*height");
+		return NULL;
+	}
+	int rc = ca3d_render(h, (const float *)u, w, hh, spp, (uint8_t *)pres, (uint16_t *)light, (uint16_t *)depth);
+	return rc ? throw_ca3d(env, rc) : undefined(env);
+}
+
+static napi_value js_render_stats(napi_env env, napi_callback_info info)
+{
+	napi_value argv[1];
+	if (!get_args(env, info, 1, argv)) return NULL;
+	ca3d_t *h = get_handle(env, argv[0]);
+	if (!h) return NULL;
+	ca3d_render_stats st;
+	int rc = ca3d_get_render_stats(h, &st);
+	if (rc) return throw_ca3d(env, rc);
+	napi_value o;
+	napi_create_object(env, &o);
+	set_num(env, o, "gpuMs", st.gpu_ms);
+	set_num(env, o, "primaryRays", (double)st.primary_rays);
+	set_num(env, o, "shadowRays", (double)st.shadow_rays);
+	set_num(env, o, "primaryCellVisits", (double)st.primary_cell_visits);
+	set_num(env, o, "shadowCellVisits", (double)st.shadow_cell_visits);
+	return o;
+}
+
+static napi_value js_set_option(napi_env env, napi_callback_info info)
+{
+	napi_value argv[3];
+	if (!get_args(env, info, 3, argv)) return NULL;
+	ca3d_t *h = get_handle(env, argv[0]);
+	if (!h) return NULL;
+	char name[64];
+	size_t len = 0;
+	int64_t v = 0;
+	napi_get_value_string_utf8(env, argv[1], name, sizeof name, &len);
+	napi_get_value_int64(env, argv[2], &v);
+	int rc = ca3d_set_option(h, name, v);
+	return rc ? throw_ca3d(env, rc) : undefined(env);
+}
+
+static napi_value js_abi_version(napi_env env, napi_callback_info info)
+{
+	(void)info;
+	napi_value v;
+	napi_create_int32(env, ca3d_abi_version(), &v);
+	return v;
+}
+
+static napi_value init(napi_env env, napi_value exports)
+{
+	static const struct { const char *name; napi_callback fn; } fns[] = {
+	    {"abiVersion", js_abi_version}, {"deviceCount", js_device_count}, {"create", js_create}, {"destroy", js_destroy},
+	    {"configure", js_configure}, {"configureSlab", js_configure_slab}, {"setRules", js_set_rules},
+	    {"uploadState", js_upload_state}, {"readState", js_read_state}, {"step", js_step}, {"slabStep", js_slab_step},
+	    {"synchronize", js_synchronize}, {"info", js_info}, {"stats", js_stats}, {"render", js_render},
+	    {"renderStats", js_render_stats}, {"setOption", js_set_option}};
+	for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++)
+	{
+		napi_value f;
+		if (napi_create_function(env, fns[i].name, NAPI_AUTO_LENGTH, fns[i].fn, NULL, &f) != napi_ok) return NULL;
+		napi_set_named_property(env, exports, fns[i].name, f);
+	}
+	return exports;
+}
+
+NAPI_MODULE(NODE_GYP_MODULE_NAME, init)

@@ -1,0 +1,210 @@
+/*
+ * JavaScript host of the MI355X engine: the rule / grid / step surface of the reference's MainModule
+ * (main_pathtraced.js) over the N-API addon (addon/ca3d_napi.c -> include/ca3d.h). CommonJS, Node >= 12.
+ *
+ * Host-side helpers mirror the reference's own (same names without the underscore, same quirks): they are the
+ * JS twin of cellularautomatons3d_amd/host.py and are checked against the same captured fixtures.
+ * There is no CPU stepping here: without the addon and a GPU, `new Engine()` throws.
+ */
+"use strict";
+const path = require("path");
+
+const NEIGHBOURS_STORAGE_LEN = 27; // main_pathtraced.js:10
+const WORK_GROUP_SIZE = 16; // main_pathtraced.js:5
+const LAYOUT_PACKED32 = 0;
+const LAYOUT_UNPACKED = 1;
+
+// main_pathtraced.js:13-94
+const vn = [1, 0, 0, -1, 0, 0, 0, 1, 0, 0, -1, 0, 0, 0, 1, 0, 0, -1];
+const vn2d = vn.slice(0, 12);
+const moore2d = vn2d.concat([1, 1, 0, -1, 1, 0, 1, -1, 0, -1, -1, 0]);
+const layer = (z) => [1, 0, z, -1, 0, z, 0, 1, z, 0, -1, z, 1, 1, z, -1, 1, z, 1, -1, z, -1, -1, z, 0, 0, z];
+const NEIGHBOURHOOD_MAP = {
+	"moore": new Int32Array(moore2d.concat(layer(1), layer(-1))),
+	"moore 2D": new Int32Array(moore2d),
+	"von neumann": new Int32Array(vn),
+	"von neumann 2D": new Int32Array(vn2d),
+	"edges": new Int32Array([1, 1, 0, -1, 1, 0, 0, 1, 1, 0, 1, -1, 1, -1, 0, -1, -1, 0, 0, -1, 1, 0, -1, -1, 1, 0, 1, -1, 0, 1, 1, 0, -1, -1, 0, -1]),
+	"corners": new Int32Array([1, 1, 1, -1, 1, 1, 1, 1, -1, -1, 1, -1, 1, -1, 1, -1, -1, 1, 1, -1, -1, -1, -1, -1])
+};
+
+// _rulesComponentsToValues (main_pathtraced.js:554-581); NaN components are dropped where the reference lets its
+// typed-array store ignore them.
+function rulesComponentsToValues(rulesComponents)
+{
+	const result = [];
+	const components = rulesComponents.split(" ").join("").split(",");
+	for (let i = 0; i < components.length; i++)
+	{
+		if (components[i].indexOf("-") > -1)
+		{
+			const range = components[i].split("-");
+			const start = parseInt(range[0], 10);
+			const end = parseInt(range[1], 10);
+			for (let j = start; j <= end; j++) { result.push(Math.min(j, 26)); }
+		}
+		else
+		{
+			const v = Math.min(parseInt(components[i], 10), 26);
+			if (!Number.isNaN(v)) { result.push(v); }
+		}
+	}
+	return result;
+}
+
+// _recalculateRulesValues (583-622) -> { born: Uint32Array(81), survive: Uint32Array(81) }
+function recalculateRulesValues(r)
+{
+	const rulesets = [r.born, r.survive, r.bornEdges, r.surviveEdges, r.bornCorners, r.surviveCorners].map(rulesComponentsToValues);
+	const born = new Uint32Array(NEIGHBOURS_STORAGE_LEN * 3);
+	const survive = new Uint32Array(NEIGHBOURS_STORAGE_LEN * 3);
+	let offset = 0;
+	for (let i = 0; i < rulesets.length; i += 2)
+	{
+		for (const v of rulesets[i]) { born[v + offset] = 1; }
+		for (const v of rulesets[i + 1]) { survive[v + offset] = 1; }
+		offset += NEIGHBOURS_STORAGE_LEN;
+	}
+	return { born, survive };
+}
+
+const DEFAULT_RULES = { neighbourhood: "von neumann", born: "1,3", survive: "0-6", bornEdges: "27", surviveEdges: "27", bornCorners: "27", surviveCorners: "27" };
+
+// _gridSizeUIFormatter (675-693)
+function gridSizeUIFormatter(v)
+{
+	let out = v;
+	const m = v % 32;
+	if (m > 0) { out = m <= 16 ? v - m : v - m + 32; }
+	return out;
+}
+
+// _getClusterIdxFromGridCoordinates (1170-1178)
+function getClusterIdxFromGridCoordinates(gridSize, c)
+{
+	const cols = gridSize / 32;
+	return (Math.floor(c.x / 32) % cols) + (c.y % gridSize) * cols + (c.z % gridSize) * cols * gridSize;
+}
+
+// initial state of _setupStorageBuffers (1241-1297); `random` replaces the unseeded Math.random
+function initialState(gridSize, randomInitialState, random)
+{
+	if (!(gridSize > 0) || gridSize % 32) { throw new RangeError("grid size must be a positive multiple of 32"); }
+	const data = new Uint32Array((gridSize / 32) * gridSize * gridSize);
+	const center = Math.floor(gridSize * 0.5) - 1;
+	if (randomInitialState)
+	{
+		const rnd = random || mulberry32(0xCA3D0001);
+		for (let i = -2; i < 3; i++) for (let j = -2; j < 3; j++) for (let k = -2; k < 3; k++)
+		{
+			const idx = getClusterIdxFromGridCoordinates(gridSize, { x: center + i, y: center + j, z: center + k });
+			if (rnd() > 0.5) { data[idx] = data[idx] | (1 << center + i); }
+			else { data[idx] = data[idx] & ~(1 << center + i); }
+		}
+	}
+	else
+	{
+		data[getClusterIdxFromGridCoordinates(gridSize, { x: center, y: center, z: center })] = 1 << (center % 32);
+	}
+	return data;
+}
+
+function mulberry32(a)
+{
+	return function () { a |= 0; a = a + 0x6D2B79F5 | 0; let t = Math.imul(a ^ a >>> 15, 1 | a); t = t + Math.imul(t ^ t >>> 7, 61 | t) ^ t; return ((t ^ t >>> 14) >>> 0) / 4294967296; };
+}
+
+function dispatchShape(gridSize)
+{
+	const wg = Math.ceil(gridSize / WORK_GROUP_SIZE);
+	return [gridSize / 32, wg, wg]; // main_pathtraced.js:1805-1806
+}
+
+// counter-based synthetic fill shared with host.py / the oracle (SURVEY 8(d))
+function randomFill(nWords, seed, andRounds)
+{
+	seed = seed === undefined ? 0xCA3D0001 : seed;
+	const mix = (i, r) => { let x = (Math.imul(i, 0x9E3779B9) + seed + Math.imul(r, 0x85EBCA6B)) >>> 0; x ^= x >>> 16; x = Math.imul(x, 0x7FEB352D) >>> 0; x ^= x >>> 15; x = Math.imul(x, 0x846CA68B) >>> 0; x ^= x >>> 16; return x >>> 0; };
+	const out = new Uint32Array(nWords);
+	for (let i = 0; i < nWords; i++)
+	{
+		let w = mix(i, 0);
+		for (let r = 1; r <= (andRounds || 0); r++) { w &= mix(i, r); }
+		out[i] = w;
+	}
+	return out;
+}
+
+let addon = null;
+function loadAddon()
+{
+	if (!addon)
+	{
+		try { addon = require(path.join(__dirname, "ca3d_napi.node")); }
+		catch (e) { throw new Error("ca3d_napi.node is missing or unloadable (build: make -C cellularautomatons3d_amd/js/addon): " + e.message + " — this engine has no CPU fallback"); }
+	}
+	return addon;
+}
+
+class Engine
+{
+	constructor(device)
+	{
+		this._a = loadAddon();
+		this._h = this._a.create(device || 0);
+		this.gridSize = 0;
+	}
+
+	close() { if (this._h) { this._a.destroy(this._h); this._h = null; } }
+
+	configure(gridSize, layout) { this._a.configure(this._h, gridSize, layout || LAYOUT_PACKED32); this.gridSize = gridSize; }
+
+	setRules(mainOffsets, edgesOffsets, cornersOffsets, survive, born) { this._a.setRules(this._h, mainOffsets, edgesOffsets, cornersOffsets, survive, born); }
+
+	setRuleStrings(rules)
+	{
+		const r = Object.assign({}, DEFAULT_RULES, rules || {});
+		const lut = recalculateRulesValues(r);
+		this.setRules(NEIGHBOURHOOD_MAP[r.neighbourhood], NEIGHBOURHOOD_MAP["edges"], NEIGHBOURHOOD_MAP["corners"], lut.survive, lut.born);
+	}
+
+	// _restartSim (624-637)
+	restartSim(gridSize, rules, randomInitialState, random)
+	{
+		this.configure(gridSize);
+		this.setRuleStrings(rules);
+		this.uploadState(initialState(gridSize, randomInitialState, random));
+	}
+
+	uploadState(words) { this._a.uploadState(this._h, words); }
+
+	readState()
+	{
+		const out = new Uint32Array(this.info().stateWords);
+		this._a.readState(this._h, out);
+		return out;
+	}
+
+	// _computePass (1796-1809), n times
+	step(n) { this._a.step(this._h, n === undefined ? 1 : n); }
+
+	synchronize() { this._a.synchronize(this._h); }
+
+	// _renderPass (1775-1794) with the reference's 128-float block (MemoryManager.bufferf32)
+	render(uniforms, width, height, spp, targets)
+	{
+		const t = targets || {};
+		this._a.render(this._h, uniforms, width, height, spp || 1, t.presentation || null, t.light || null, t.depth || null);
+	}
+
+	info() { return this._a.info(this._h); }
+	stats() { return this._a.stats(this._h); }
+	renderStats() { return this._a.renderStats(this._h); }
+	setOption(name, value) { this._a.setOption(this._h, name, value); }
+}
+
+module.exports = {
+	Engine, NEIGHBOURHOOD_MAP, DEFAULT_RULES, LAYOUT_PACKED32, LAYOUT_UNPACKED, NEIGHBOURS_STORAGE_LEN,
+	rulesComponentsToValues, recalculateRulesValues, gridSizeUIFormatter, getClusterIdxFromGridCoordinates,
+	initialState, dispatchShape, randomFill, loadAddon
+};

@@ -1,0 +1,57 @@
+"""The JavaScript host path (north_star: host code stays Node.js over N-API)."""
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NODE = shutil.which("node")
+
+pytestmark = pytest.mark.skipif(NODE is None, reason="node is not installed")
+
+
+def _node(*args, timeout=300):
+    return subprocess.run([NODE, *args], cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+
+
+def test_js_host_helpers_match_reference_fixtures():
+    r = _node("tests/js/check_host_fixtures.js")
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
+
+
+def test_js_cpu_stepper_hash_anchors():
+    import json
+
+    r = _node("oracle/js_stepper.js", "hash", "64", "8")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert json.loads(r.stdout)["hashes"] == "eaf84574 2a89e9f6 08947442 7e303b52 44d3c10e 3ca0f014 548cafef ae46dc87".split()
+
+
+def test_js_engine_refuses_without_gpu():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    r = _node("-e", "const c=require('./cellularautomatons3d_amd/js/ca3d.js'); try{new c.Engine(0);process.exit(1)}catch(e){console.log(e.message)}")
+    assert r.returncode == 0 and "no CPU fallback" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_js_engine_on_gpu(tmp_path):
+    import oracle_lib as ol
+    from cellularautomatons3d_amd import host
+
+    W, H = 160, 90
+    u = host.uniform_block(W, H, host.orbit_camera())
+    u.tofile(tmp_path / "uniforms.f32")
+    r = _node("tests/js/gpu_engine_check.js", str(tmp_path))
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout + r.stderr)[-3000:]
+    state = np.fromfile(tmp_path / "state.u32", dtype=np.uint32)
+    light = np.fromfile(tmp_path / "light.f16", dtype=np.float16).reshape(H, W, 4).astype(np.float32)
+    pres = np.fromfile(tmp_path / "presentation.u8", dtype=np.uint8).reshape(H, W, 4)
+    olight, _, opres, _ = ol.render(state, 128, u, W, H, 1)
+    ok = (np.abs(light[..., :3] - olight[..., :3]).max(-1) <= 2e-3) & \
+         (np.abs(pres.astype(np.float32) - np.rint(np.clip(opres, 0, 1) * 255)).max(-1) <= 1)
+    assert ok.mean() >= 0.999

@@ -55,14 +55,16 @@ struct ca3d_engine
 	uint32_t *buf[2] = {nullptr, nullptr};
 	bool has_state = false;
 	uint64_t step = 0;
+	uint32_t cur = 0; // physical buffer holding the current state (== step % 2 whenever control returns to the caller)
 
 	CanonRules rules;
 	int variant = 0;
 	int use_graph = 1;
+	int use_fused = 1;
 
 	// hipGraph of an even number of full-grid steps starting from buffer 0 (invalidated on any change)
 	hipGraphExec_t graph_exec = nullptr;
-	uint32_t graph_steps = 0;
+	uint32_t graph_steps = 0, graph_launches = 0;
 
 	ca3d_stats stats{};
 	const char *kernel_name = "";
@@ -122,6 +124,7 @@ void free_buffers(ca3d_engine *h)
 	h->configured = false;
 	h->has_state = false;
 	h->step = 0;
+	h->cur = 0;
 }
 
 int bind_device(ca3d_engine *h)
@@ -148,8 +151,8 @@ int allocate(ca3d_engine *h)
 	return CA3D_OK;
 }
 
-// One step reading buffer `src` over output planes [lo, hi).
-int enqueue_step(ca3d_engine *h, int src, uint32_t lo, uint32_t hi, hipStream_t s)
+// One launch reading buffer `src` over output planes [lo, hi): a single step, or a fused multi-step pass.
+int enqueue_step(ca3d_engine *h, int src, uint32_t lo, uint32_t hi, hipStream_t s, bool fused = false)
 {
 	PlaneRange pr;
 	pr.G = h->G;
@@ -162,7 +165,7 @@ int enqueue_step(ca3d_engine *h, int src, uint32_t lo, uint32_t hi, hipStream_t 
 	if (h->layout == CA3D_LAYOUT_PACKED32)
 	{
 		PackedLaunch l{h->buf[src], h->buf[src ^ 1], pr, &h->rules, h->variant};
-		e = launch_packed_step(l, s, &h->kernel_name);
+		e = fused ? launch_packed_fused(l, s, &h->kernel_name) : launch_packed_step(l, s, &h->kernel_name);
 	}
 	else
 	{
@@ -184,14 +187,49 @@ int check_ready(ca3d_engine *h)
 
 constexpr uint32_t kGraphSteps = 64;
 
+// Launch plan for n steps that keeps the reference's ping-pong invariant (main_pathtraced.js:1580-1609): the
+// state after n steps sits in buffer (start + n) % 2 and the other buffer holds the state one step earlier. A
+// fused pass advances T = 2 steps but flips the buffer once, so fused passes come in even numbers and the batch
+// always ends with single steps.
+void plan_steps(const ca3d_engine *h, uint32_t n, uint32_t *n_fused, uint32_t *n_single)
+{
+	uint32_t f = 0;
+	if (h->use_fused && h->layout == CA3D_LAYOUT_PACKED32 && !h->slab && packed_fused_steps(h->rules, h->G, h->variant) == 2 && n >= 3)
+	{
+		f = (n - 1u) / 2u;
+		f &= ~1u;
+	}
+	*n_fused = f;
+	*n_single = n - 2u * f;
+}
+
+int enqueue_batch(ca3d_engine *h, uint32_t n, uint32_t start_buf, hipStream_t s, uint64_t *launches)
+{
+	uint32_t f, single;
+	plan_steps(h, n, &f, &single);
+	uint32_t cur = start_buf;
+	for (uint32_t i = 0; i < f; i++, cur ^= 1u)
+	{
+		int rc = enqueue_step(h, (int)cur, 0, h->G, s, true);
+		if (rc) return rc;
+	}
+	for (uint32_t i = 0; i < single; i++, cur ^= 1u)
+	{
+		int rc = enqueue_step(h, (int)cur, 0, h->G, s, false);
+		if (rc) return rc;
+	}
+	if (launches) *launches += f + single;
+	return CA3D_OK;
+}
+
 int build_graph(ca3d_engine *h)
 {
-	// Capture kGraphSteps ping-pong steps starting at buffer 0. Launch boundaries stay (one kernel per step, as
-	// the reference dispatches) but the host cost per step drops from ~4 us to the graph's amortised cost.
+	// Capture kGraphSteps steps starting at buffer 0: launch boundaries stay, the host cost per launch drops
+	// from ~4 us to the graph's amortised cost.
 	hipGraph_t graph = nullptr;
 	HIP_TRY(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-	int rc = CA3D_OK;
-	for (uint32_t k = 0; k < kGraphSteps && rc == CA3D_OK; k++) rc = enqueue_step(h, (int)(k & 1u), 0, h->G, h->stream);
+	uint64_t launches = 0;
+	int rc = enqueue_batch(h, kGraphSteps, 0, h->stream, &launches);
 	hipError_t e = hipStreamEndCapture(h->stream, &graph);
 	if (rc != CA3D_OK) { if (graph) hipGraphDestroy(graph); return rc; }
 	if (e != hipSuccess) return fail(CA3D_ERR_DEVICE, "hipStreamEndCapture: %s", hipGetErrorString(e));
@@ -199,6 +237,7 @@ int build_graph(ca3d_engine *h)
 	hipGraphDestroy(graph);
 	if (e != hipSuccess) { h->graph_exec = nullptr; return fail(CA3D_ERR_DEVICE, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
 	h->graph_steps = kGraphSteps;
+	h->graph_launches = (uint32_t)launches;
 	return CA3D_OK;
 }
 
@@ -353,6 +392,7 @@ int ca3d_upload_state(ca3d_t *h, const uint32_t *words, size_t n_words)
 	HIP_TRY(hipMemcpyAsync(h->buf[1] + off, h->buf[0] + off, bytes, hipMemcpyDeviceToDevice, h->stream));
 	HIP_TRY(hipStreamSynchronize(h->stream));
 	h->step = 0;
+	h->cur = 0;
 	h->has_state = true;
 	return CA3D_OK;
 }
@@ -366,7 +406,7 @@ int ca3d_read_state(ca3d_t *h, uint32_t *words, size_t n_words)
 	int rc = bind_device(h);
 	if (rc) return rc;
 	const size_t off = h->slab ? (size_t)h->ghost * h->plane_words : 0;
-	HIP_TRY(hipMemcpyAsync(words, h->buf[h->step & 1u] + off, n_words * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+	HIP_TRY(hipMemcpyAsync(words, h->buf[h->cur] + off, n_words * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
 	HIP_TRY(hipStreamSynchronize(h->stream));
 	return CA3D_OK;
 }
@@ -382,10 +422,10 @@ int ca3d_step(ca3d_t *h, uint32_t n_steps)
 	HIP_TRY(hipEventRecord(h->ev_start, h->stream));
 	uint32_t left = n_steps;
 	uint64_t launches = 0;
-	// Graph replays need the batch to start at buffer 0; take single steps until parity and count allow it.
+	// Graph replays are captured from buffer 0; take one single step first if the state sits in buffer 1.
 	while (left)
 	{
-		if (h->use_graph && h->stream != nullptr && (h->step & 1u) == 0 && left >= kGraphSteps)
+		if (h->use_graph && h->stream != nullptr && h->cur == 0 && left >= kGraphSteps)
 		{
 			if (!h->graph_exec)
 			{
@@ -393,16 +433,18 @@ int ca3d_step(ca3d_t *h, uint32_t n_steps)
 				if (rc) return rc;
 			}
 			HIP_TRY(hipGraphLaunch(h->graph_exec, h->stream));
-			h->step += h->graph_steps;
+			h->step += h->graph_steps; // even: the buffer index is unchanged
 			left -= h->graph_steps;
-			launches += h->graph_steps;
+			launches += h->graph_launches;
 			continue;
 		}
-		rc = enqueue_step(h, (int)(h->step & 1u), 0, h->G, h->stream);
+		uint32_t n = left;
+		if (h->use_graph && h->stream != nullptr && left >= kGraphSteps) n = 1; // h->cur == 1: re-align for the graph
+		rc = enqueue_batch(h, n, h->cur, h->stream, &launches);
 		if (rc) return rc;
-		h->step++;
-		left--;
-		launches++;
+		h->step += n;
+		h->cur = (h->cur + n) & 1u;
+		left -= n;
 	}
 	HIP_TRY(hipEventRecord(h->ev_stop, h->stream));
 	h->ev_valid = true;
@@ -431,9 +473,10 @@ int ca3d_slab_step(ca3d_t *h, uint32_t n_steps)
 		// (z == -1 is dropped), so the slab that owns global plane 0 never needs its low ghost.
 		uint32_t lo = s, hi = L - s;
 		if (h->layout == CA3D_LAYOUT_PACKED32 && h->z0 == 0) lo = K;
-		rc = enqueue_step(h, (int)(h->step & 1u), lo, hi, h->stream);
+		rc = enqueue_step(h, (int)h->cur, lo, hi, h->stream);
 		if (rc) return rc;
 		h->step++;
+		h->cur ^= 1u;
 		planes_done += hi - lo;
 	}
 	HIP_TRY(hipEventRecord(h->ev_stop, h->stream));
@@ -450,7 +493,7 @@ int ca3d_slab_region(ca3d_t *h, int region, void **device_ptr, size_t *n_bytes)
 {
 	if (!h || !device_ptr || !n_bytes) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL argument");
 	if (!h->configured || !h->slab) return fail(CA3D_ERR_NOT_CONFIGURED, "engine is not configured as a slab");
-	uint32_t *base = h->buf[h->step & 1u];
+	uint32_t *base = h->buf[h->cur];
 	const size_t pw = h->plane_words;
 	const uint32_t K = h->ghost, nz = h->nz;
 	size_t first = 0, count = K;
@@ -522,7 +565,7 @@ int ca3d_get_info(ca3d_t *h, ca3d_info *out)
 	out->ghost = h->ghost;
 	out->step = h->step;
 	out->state_words = h->configured ? h->state_words() : 0;
-	out->current_buffer = (int32_t)(h->step & 1u);
+	out->current_buffer = (int32_t)h->cur;
 	out->device = h->device;
 	const char *name = "";
 	if (h->configured && h->rules.valid)
@@ -577,7 +620,7 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 	if (!h->r_counters) HIP_TRY(hipMalloc((void **)&h->r_counters, 3 * sizeof(unsigned long long)));
 	HIP_TRY(hipMemsetAsync(h->r_counters, 0, 3 * sizeof(unsigned long long), h->stream));
 	RenderLaunch l;
-	l.cells = h->buf[h->step & 1u];
+	l.cells = h->buf[h->cur];
 	l.G = h->G;
 	l.W = width;
 	l.H = height;
@@ -624,9 +667,10 @@ int ca3d_set_option(ca3d_t *h, const char *name, int64_t value)
 {
 	if (!h || !name) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL argument");
 	if (!strcmp(name, "graph")) { h->use_graph = value ? 1 : 0; return CA3D_OK; }
+	if (!strcmp(name, "fused")) { drop_graph(h); h->use_fused = value ? 1 : 0; return CA3D_OK; }
 	if (!strcmp(name, "variant"))
 	{
-		if (value < 0 || value > 1) return fail(CA3D_ERR_INVALID_ARGUMENT, "variant must be 0 (auto) or 1 (generic kernel)");
+		if (value < 0 || value > 0x2FF) return fail(CA3D_ERR_INVALID_ARGUMENT, "variant must be 0 (auto) or 1 (generic kernel)");
 		drop_graph(h);
 		h->variant = (int)value;
 		return CA3D_OK;

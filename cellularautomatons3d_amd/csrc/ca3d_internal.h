@@ -124,6 +124,9 @@ hipError_t launch_render(const RenderLaunch &l, hipStream_t stream);
 // ca_packed.hip / ca_unpacked.hip
 hipError_t launch_packed_step(const PackedLaunch &l, hipStream_t stream, const char **kernel_name);
 const char *packed_kernel_name(const CanonRules &r, uint32_t G, int variant);
+// Steps one fused launch advances for these rules / grid (0 = no fused kernel applies).
+int packed_fused_steps(const CanonRules &r, uint32_t G, int variant);
+hipError_t launch_packed_fused(const PackedLaunch &l, hipStream_t stream, const char **kernel_name);
 hipError_t launch_unpacked_step(const UnpackedLaunch &l, hipStream_t stream, const char **kernel_name);
 
 } // namespace ca3d

@@ -152,6 +152,129 @@ __device__ __forceinline__ u32 next_state(u32 alive, u32 S, u32 B)
 	return bitop3<((TA & TB) | (~TA & TC)) & 0xFF>(alive, S, B); // alive ? survive : born
 }
 
+// ---- register-resident rule programs ----------------------------------------------------------------------
+// The interpreter above decodes every cube with scalar instructions each time it runs; inside the kernels that
+// becomes the bottleneck (the CU's single scalar unit). Programs of at most kFastCubes cubes — every rule the
+// reference UI produces in practice — are instead expanded ONCE per wave into mask pairs: literal i of a cube is
+// (plane_i & a_i) ^ b_i with (a, b) = (~0, 0) for "plane set", (~0, ~0) for "plane clear", (0, ~0) for "don't
+// care", so a cube is NP bitop3 + one AND-reduction and nothing is decoded in the loops.
+constexpr int kFastCubes = 2;
+
+template <int NP>
+struct FastProg
+{
+	u32 n, invert;
+	u32 a[kFastCubes][NP > 0 ? NP : 1], b[kFastCubes][NP > 0 ? NP : 1];
+};
+
+template <int NP>
+__device__ __forceinline__ FastProg<NP> expand_prog(const RuleProg &pr)
+{
+	FastProg<NP> f;
+	f.n = pr.n;
+	f.invert = pr.invert;
+#pragma unroll
+	for (int c = 0; c < kFastCubes; c++)
+	{
+		const u32 cube = pr.cubes[c];
+#pragma unroll
+		for (int i = 0; i < NP; i++)
+		{
+			const bool care = (cube >> i) & 1u, val = (cube >> (8 + i)) & 1u;
+			f.a[c][i] = care ? 0xFFFFFFFFu : 0u;
+			f.b[c][i] = (care && val) ? 0u : 0xFFFFFFFFu;
+		}
+	}
+	return f;
+}
+
+template <int NP>
+__device__ __forceinline__ u32 cube_fast(const FastProg<NP> &f, int c, const u32 *p)
+{
+	u32 lit[NP > 0 ? NP : 1];
+#pragma unroll
+	for (int i = 0; i < NP; i++) lit[i] = bitop3<((TA & TB) ^ TC)>(p[i], f.a[c][i], f.b[c][i]);
+	if (NP == 1) return lit[0];
+	if (NP == 2) return lit[0] & lit[1];
+	u32 e = bitop3<(TA & TB & TC)>(lit[0], lit[1], lit[2]);
+	if (NP == 4) e &= lit[3];
+	if (NP == 5) e = bitop3<(TA & TB & TC)>(e, lit[3 < NP ? 3 : 0], lit[4 < NP ? 4 : 0]);
+	return e;
+}
+
+template <int NP, int NPA>
+__device__ __forceinline__ void eval_fast4(const FastProg<NP> &f, const u32 (&p)[4][NPA], u32 (&acc)[4])
+{
+	if (NP == 0 || f.n == 0)
+	{
+#pragma unroll
+		for (int w = 0; w < 4; w++) acc[w] |= f.invert;
+		return;
+	}
+	u32 r[4];
+#pragma unroll
+	for (int w = 0; w < 4; w++) r[w] = cube_fast<NP>(f, 0, p[w]);
+	if (f.n > 1)
+	{
+#pragma unroll
+		for (int w = 0; w < 4; w++) r[w] |= cube_fast<NP>(f, 1, p[w]);
+	}
+#pragma unroll
+	for (int w = 0; w < 4; w++) acc[w] |= r[w] ^ f.invert;
+}
+
+template <int MAIN>
+struct MainPlanes
+{
+	static constexpr int value = (MAIN == MAIN_VN || MAIN == MAIN_VN2D) ? 3 : (MAIN == MAIN_MOORE ? 5 : 4);
+};
+
+// The six programs of a kernel instantiation, expanded into registers.
+template <int MAIN, bool E, bool C_>
+struct FastRules
+{
+	FastProg<MainPlanes<MAIN>::value> mb, ms;
+	FastProg<(E ? 4 : 0)> eb, es;
+	FastProg<(C_ ? 4 : 0)> cb, cs;
+};
+
+template <int MAIN, bool E, bool C_>
+__device__ __forceinline__ FastRules<MAIN, E, C_> expand_rules(const PackedRuleArgs &r)
+{
+	FastRules<MAIN, E, C_> f;
+	f.mb = expand_prog<MainPlanes<MAIN>::value>(r.set[0].born);
+	f.ms = expand_prog<MainPlanes<MAIN>::value>(r.set[0].survive);
+	f.eb = expand_prog<(E ? 4 : 0)>(r.set[1].born);
+	f.es = expand_prog<(E ? 4 : 0)>(r.set[1].survive);
+	f.cb = expand_prog<(C_ ? 4 : 0)>(r.set[2].born);
+	f.cs = expand_prog<(C_ ? 4 : 0)>(r.set[2].survive);
+	return f;
+}
+
+template <int MAIN, bool E, bool C_, int NP>
+__device__ __forceinline__ void apply_rules(const PackedRuleArgs &rules, const u32 (&mn)[4][NP], const u32 (&ed)[4][4],
+                                            const u32 (&co)[4][4], u32 (&S)[4], u32 (&B)[4])
+{
+	eval_prog4<NP>(rules.set[0].survive, mn, S);
+	eval_prog4<NP>(rules.set[0].born, mn, B);
+	eval_prog4<(E ? 4 : 0)>(rules.set[1].survive, ed, S);
+	eval_prog4<(E ? 4 : 0)>(rules.set[1].born, ed, B);
+	eval_prog4<(C_ ? 4 : 0)>(rules.set[2].survive, co, S);
+	eval_prog4<(C_ ? 4 : 0)>(rules.set[2].born, co, B);
+}
+
+template <int MAIN, bool E, bool C_, int NP>
+__device__ __forceinline__ void apply_rules(const FastRules<MAIN, E, C_> &f, const u32 (&mn)[4][NP], const u32 (&ed)[4][4],
+                                            const u32 (&co)[4][4], u32 (&S)[4], u32 (&B)[4])
+{
+	eval_fast4<NP>(f.ms, mn, S);
+	eval_fast4<NP>(f.mb, mn, B);
+	eval_fast4<(E ? 4 : 0)>(f.es, ed, S);
+	eval_fast4<(E ? 4 : 0)>(f.eb, ed, B);
+	eval_fast4<(C_ ? 4 : 0)>(f.cs, co, S);
+	eval_fast4<(C_ ? 4 : 0)>(f.cb, co, B);
+}
+
 // ---- plane / row addressing for the generic kernel -------------------------------------------------------
 struct Nbr
 {
@@ -257,17 +380,85 @@ struct PlaneRows
 	Seg ym, c, yp;
 };
 
-template <int MAIN>
-struct MainPlanes
+// New state of the 4 words at the centre of P1 given the planes below (P0, already masked by the caller through
+// `zmask` when z-1 is dead) and above (P2). Shared by the streaming and the fused kernels.
+template <int MAIN, bool E, bool C_, typename RS>
+__device__ __forceinline__ uint4 evolve4(const PlaneRows &P0, const PlaneRows &P1, const PlaneRows &P2, u32 zmask,
+                                         const RS &rules)
 {
-	static constexpr int value = (MAIN == MAIN_VN || MAIN == MAIN_VN2D) ? 3 : (MAIN == MAIN_MOORE ? 5 : 4);
-};
+	constexpr bool kNeedEdges = E || MAIN == MAIN_MOORE || MAIN == MAIN_EDGES;
+	constexpr bool kNeedCorners = C_ || MAIN == MAIN_MOORE || MAIN == MAIN_CORNERS;
+
+	constexpr int NP = MainPlanes<MAIN>::value;
+	u32 mn[4][NP], ed[4][4], co[4][4];
+#pragma unroll
+	for (int i = 0; i < 4; i++)
+	{
+		for (int k = 0; k < 4; k++) { ed[i][k] = 0; co[i][k] = 0; }
+		if (kNeedEdges)
+		{
+			const u32 x[12] = {seg_l(P1.yp, i), seg_r(P1.yp, i), seg_l(P1.ym, i), seg_r(P1.ym, i),
+			                   seg_l(P2.c, i), seg_r(P2.c, i), seg_l(P0.c, i) & zmask, seg_r(P0.c, i) & zmask,
+			                   P2.yp.w[i], P0.yp.w[i] & zmask, P2.ym.w[i], P0.ym.w[i] & zmask};
+			sum12(x, ed[i]);
+		}
+		if (kNeedCorners)
+		{
+			const u32 x[8] = {seg_l(P2.yp, i), seg_r(P2.yp, i), seg_l(P0.yp, i) & zmask, seg_r(P0.yp, i) & zmask,
+			                  seg_l(P2.ym, i), seg_r(P2.ym, i), seg_l(P0.ym, i) & zmask, seg_r(P0.ym, i) & zmask};
+			sum8(x, co[i]);
+		}
+		if (MAIN == MAIN_VN)
+		{
+			u32 p[3];
+			sum6(seg_l(P1.c, i), seg_r(P1.c, i), P1.yp.w[i], P1.ym.w[i], P2.c.w[i], P0.c.w[i] & zmask, p);
+			for (int k = 0; k < 3; k++) mn[i][k] = p[k];
+		}
+		else if (MAIN == MAIN_VN2D)
+		{
+			u32 p[3];
+			sum4(seg_l(P1.c, i), seg_r(P1.c, i), P1.yp.w[i], P1.ym.w[i], p);
+			for (int k = 0; k < 3; k++) mn[i][k] = p[k];
+		}
+		else if (MAIN == MAIN_MOORE)
+		{
+			u32 vn[3], p[5];
+			sum6(seg_l(P1.c, i), seg_r(P1.c, i), P1.yp.w[i], P1.ym.w[i], P2.c.w[i], P0.c.w[i] & zmask, vn);
+			sum_moore(vn, ed[i], co[i], p);
+			for (int k = 0; k < NP; k++) mn[i][k] = p[k];
+		}
+		else if (MAIN == MAIN_MOORE2D)
+		{
+			const u32 x[8] = {seg_l(P1.c, i), seg_r(P1.c, i), P1.yp.w[i], seg_l(P1.yp, i), seg_r(P1.yp, i),
+			                  P1.ym.w[i], seg_l(P1.ym, i), seg_r(P1.ym, i)};
+			u32 p[4];
+			sum8(x, p);
+			for (int k = 0; k < NP; k++) mn[i][k] = p[k];
+		}
+		else if (MAIN == MAIN_EDGES)
+		{
+			for (int k = 0; k < NP; k++) mn[i][k] = ed[i][k];
+		}
+		else
+		{
+			for (int k = 0; k < NP; k++) mn[i][k] = co[i][k];
+		}
+	}
+	u32 S[4] = {0, 0, 0, 0}, B[4] = {0, 0, 0, 0};
+	apply_rules<MAIN, E, C_, NP>(rules, mn, ed, co, S, B);
+	uint4 r;
+	r.x = next_state(P1.c.w[0], S[0], B[0]);
+	r.y = next_state(P1.c.w[1], S[1], B[1]);
+	r.z = next_state(P1.c.w[2], S[2], B[2]);
+	r.w = next_state(P1.c.w[3], S[3], B[3]);
+	return r;
+}
 
 // Each thread owns one dwordx4 column position (y, cx0..cx0+3) and walks ZR consecutive z-planes with the three
 // planes it needs held in registers, so a plane's rows are fetched once per ZR outputs instead of three times.
-template <int MAIN, bool E, bool C_, int ZR>
+template <int MAIN, bool E, bool C_, int ZR, bool FAST>
 __global__ __launch_bounds__(256) void ca_packed_class(const u32 *__restrict__ in, u32 *__restrict__ out,
-                                                       PlaneRange pr, TileGeom g, PackedRuleArgs rules)
+                                                       PlaneRange pr, TileGeom g, PackedRuleArgs rules_in)
 {
 	constexpr bool kMainVN = MAIN == MAIN_VN || MAIN == MAIN_MOORE;
 	constexpr bool kNeedEdges = E || MAIN == MAIN_MOORE || MAIN == MAIN_EDGES;
@@ -307,6 +498,9 @@ __global__ __launch_bounds__(256) void ca_packed_class(const u32 *__restrict__ i
 		ps.shfl = g.use_shfl != 0;
 	}
 
+	FastRules<MAIN, E, C_> frules;
+	if (FAST) frules = expand_rules<MAIN, E, C_>(rules_in);
+
 	const u32 j0 = pr.lo + zr * ZR;
 	// window plane q holds array plane j0 + q - 1 (q = 0 .. ZR+1); out-of-range ends are clamped / wrapped
 	PlaneRows win[ZR + 2];
@@ -335,77 +529,258 @@ __global__ __launch_bounds__(256) void ca_packed_class(const u32 *__restrict__ i
 		if (j >= pr.hi) break;
 		const u32 zmask = zg == 0 ? 0u : 0xFFFFFFFFu; // z-1 == -1 is dropped (compute_clustered.wgsl:104)
 		zg = zg + 1 == (int)pr.G ? 0 : zg + 1;
-		const PlaneRows &P0 = win[q - 1], &P1 = win[q], &P2 = win[q + 1];
-
-		constexpr int NP = MainPlanes<MAIN>::value;
-		u32 mn[4][NP], ed[4][4], co[4][4];
-#pragma unroll
-		for (int i = 0; i < 4; i++)
-		{
-			for (int k = 0; k < 4; k++) { ed[i][k] = 0; co[i][k] = 0; }
-			if (kNeedEdges)
-			{
-				const u32 x[12] = {seg_l(P1.yp, i), seg_r(P1.yp, i), seg_l(P1.ym, i), seg_r(P1.ym, i),
-				                   seg_l(P2.c, i), seg_r(P2.c, i), seg_l(P0.c, i) & zmask, seg_r(P0.c, i) & zmask,
-				                   P2.yp.w[i], P0.yp.w[i] & zmask, P2.ym.w[i], P0.ym.w[i] & zmask};
-				sum12(x, ed[i]);
-			}
-			if (kNeedCorners)
-			{
-				const u32 x[8] = {seg_l(P2.yp, i), seg_r(P2.yp, i), seg_l(P0.yp, i) & zmask, seg_r(P0.yp, i) & zmask,
-				                  seg_l(P2.ym, i), seg_r(P2.ym, i), seg_l(P0.ym, i) & zmask, seg_r(P0.ym, i) & zmask};
-				sum8(x, co[i]);
-			}
-			if (MAIN == MAIN_VN)
-			{
-				u32 p[3];
-				sum6(seg_l(P1.c, i), seg_r(P1.c, i), P1.yp.w[i], P1.ym.w[i], P2.c.w[i], P0.c.w[i] & zmask, p);
-				for (int k = 0; k < 3; k++) mn[i][k] = p[k];
-			}
-			else if (MAIN == MAIN_VN2D)
-			{
-				u32 p[3];
-				sum4(seg_l(P1.c, i), seg_r(P1.c, i), P1.yp.w[i], P1.ym.w[i], p);
-				for (int k = 0; k < 3; k++) mn[i][k] = p[k];
-			}
-			else if (MAIN == MAIN_MOORE)
-			{
-				u32 vn[3], p[5];
-				sum6(seg_l(P1.c, i), seg_r(P1.c, i), P1.yp.w[i], P1.ym.w[i], P2.c.w[i], P0.c.w[i] & zmask, vn);
-				sum_moore(vn, ed[i], co[i], p);
-				for (int k = 0; k < NP; k++) mn[i][k] = p[k];
-			}
-			else if (MAIN == MAIN_MOORE2D)
-			{
-				const u32 x[8] = {seg_l(P1.c, i), seg_r(P1.c, i), P1.yp.w[i], seg_l(P1.yp, i), seg_r(P1.yp, i),
-				                  P1.ym.w[i], seg_l(P1.ym, i), seg_r(P1.ym, i)};
-				u32 p[4];
-				sum8(x, p);
-				for (int k = 0; k < NP; k++) mn[i][k] = p[k];
-			}
-			else if (MAIN == MAIN_EDGES)
-			{
-				for (int k = 0; k < NP; k++) mn[i][k] = ed[i][k];
-			}
-			else
-			{
-				for (int k = 0; k < NP; k++) mn[i][k] = co[i][k];
-			}
-		}
-		u32 S[4] = {0, 0, 0, 0}, B[4] = {0, 0, 0, 0};
-		eval_prog4<NP>(rules.set[0].survive, mn, S);
-		eval_prog4<NP>(rules.set[0].born, mn, B);
-		eval_prog4<(E ? 4 : 0)>(rules.set[1].survive, ed, S);
-		eval_prog4<(E ? 4 : 0)>(rules.set[1].born, ed, B);
-		eval_prog4<(C_ ? 4 : 0)>(rules.set[2].survive, co, S);
-		eval_prog4<(C_ ? 4 : 0)>(rules.set[2].born, co, B);
 		uint4 r;
-		r.x = next_state(P1.c.w[0], S[0], B[0]);
-		r.y = next_state(P1.c.w[1], S[1], B[1]);
-		r.z = next_state(P1.c.w[2], S[2], B[2]);
-		r.w = next_state(P1.c.w[3], S[3], B[3]);
+		if (FAST) r = evolve4<MAIN, E, C_>(win[q - 1], win[q], win[q + 1], zmask, frules);
+		else r = evolve4<MAIN, E, C_>(win[q - 1], win[q], win[q + 1], zmask, rules_in);
 		*reinterpret_cast<uint4 *>(out + (size_t)j * plane_words + ps.off[1]) = r;
 	}
+}
+
+// ---------------------------------------------------------------------------------------------- fused kernel
+// T CA steps in one launch (temporal blocking). A workgroup owns a tile of TY rows x TZ planes x the full x
+// extent plus a halo of T rows / planes; a thread owns one dwordx4 position (row r, cx0) and keeps its whole
+// z-column of Q = TZ + 2T planes in REGISTERS across the T steps. Per step the workgroup publishes its columns
+// to LDS (one ds_write_b128 per plane) and every thread reads only its y+-1 neighbour rows back: z-neighbours are
+// its own registers, x-neighbours come from the neighbour lanes. Halo cells go stale one layer per step, which
+// is exactly the halo depth. HBM sees the grid once per T steps and the launch boundary is paid once per T steps.
+//
+// Boundary: rows / planes at global coordinate -1 are dead (forced to zero every step), coordinates >= G are
+// replicas of coordinate - G and evolve with a dead neighbour below whenever their own coordinate is 0 (mod G) —
+// the same rule the slab ghosts use.
+struct FusedGeom
+{
+	u32 CV, cv_shift; // uint4 per row (power of two)
+	u32 R;            // rows per tile incl. halo
+	u32 ny, nz;       // tiles along y, z
+	u32 dbg;          // profiling aid: 1 = skip the step loop (memory phases only), 2 = skip the stores too
+};
+
+template <int MAIN, bool E, bool C_, int T, int Q, bool FAST>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 8))) void ca_packed_fused(const u32 *__restrict__ in, u32 *__restrict__ out,
+                                                       PlaneRange pr, FusedGeom g, PackedRuleArgs rules_in)
+{
+	constexpr int TZ = Q - 2 * T;
+	constexpr bool kNeedEdges = E || MAIN == MAIN_MOORE || MAIN == MAIN_EDGES;
+	constexpr bool kNeedCorners = C_ || MAIN == MAIN_MOORE || MAIN == MAIN_CORNERS;
+	constexpr bool kMainVN = MAIN == MAIN_VN || MAIN == MAIN_MOORE;
+	constexpr bool kCenterLR = kMainVN || MAIN == MAIN_VN2D || MAIN == MAIN_MOORE2D || kNeedEdges;
+	constexpr bool kYLR = kNeedEdges || kNeedCorners || MAIN == MAIN_MOORE2D;
+	constexpr bool kZYRows = kNeedEdges || kNeedCorners; // y+-1 rows of the z+-1 planes
+
+	extern __shared__ __attribute__((aligned(16))) u32 lds[]; // [Q][R][C]
+
+	const u32 b = blockIdx.x, nb = gridDim.x;
+	const u32 v = (nb & 7u) == 0 ? (b & 7u) * (nb >> 3) + (b >> 3) : b; // XCD k gets a contiguous z range
+	const u32 tz = v / g.ny, ty = v - tz * g.ny;
+	const u32 tid = threadIdx.x;
+	const u32 r = tid >> g.cv_shift, cxv = tid & (g.CV - 1u);
+	const bool active = r < g.R;
+	const u32 C = g.CV * 4u, cx0 = cxv * 4u;
+	const int G = (int)pr.G;
+	const u32 TY = g.R - 2u * T;
+	const u32 plane_words = C * pr.G;
+	const u32 row_words = C;
+
+	// row of this thread
+	const int gy = (int)(ty * TY) - T + (int)r;
+	const bool row_live = gy >= 0;
+	const int gyw = gy < 0 ? 0 : (gy >= G ? gy - G : gy);
+	const u32 live_mask = (row_live && active) ? 0xFFFFFFFFu : 0u;
+	const u32 ym_mask = gyw == 0 ? 0u : 0xFFFFFFFFu; // y-1 == -1 is dropped
+	const u32 rl = active ? r : 0u;
+	const u32 r_m = rl == 0 ? 0u : rl - 1u, r_p = rl + 1u >= g.R ? g.R - 1u : rl + 1u;
+	const int lane = (int)(tid & 63u);
+	const int src_lo = lane - 1, src_hi = cxv + 1u == g.CV ? lane - (int)(g.CV - 1u) : lane + 1;
+	const u32 lo_mask = cx0 == 0 ? 0u : 0xFFFFFFFFu;
+	const u32 lo_rel = cx0 == 0 ? 0u : cx0 - 1u, hi_rel = cx0 + 4u == C ? 0u : cx0 + 4u;
+
+	// planes of this tile: array plane index, liveness, "plane below is dead"
+	const int z0 = (int)pr.lo + (int)(tz * TZ) - T;
+	u32 col[Q][4];
+	u32 zlive_bits = 0, zdead_below_bits = 0; // bit q: plane q exists / its z-1 neighbour is dead
+#pragma unroll
+	for (int q = 0; q < Q; q++)
+	{
+		int jz = z0 + q;
+		bool zl, zd;
+		if (pr.wrap_full)
+		{
+			zl = jz >= 0;
+			jz = jz < 0 ? 0 : (jz >= G ? jz - G : jz);
+			zd = jz == 0;
+		}
+		else
+		{
+			zl = jz >= 0 && jz < (int)pr.nplanes;
+			jz = jz < 0 ? 0 : (jz >= (int)pr.nplanes ? (int)pr.nplanes - 1 : jz);
+			zd = global_z(pr, (u32)jz) == 0;
+		}
+		zlive_bits |= (zl ? 1u : 0u) << q;
+		zdead_below_bits |= (zd ? 1u : 0u) << q;
+		const uint4 w = *reinterpret_cast<const uint4 *>(in + (size_t)jz * plane_words + (size_t)gyw * row_words + cx0);
+		const u32 m = zl ? live_mask : 0u;
+		col[q][0] = w.x & m; col[q][1] = w.y & m; col[q][2] = w.z & m; col[q][3] = w.w & m;
+	}
+	FastRules<MAIN, E, C_> frules;
+	if (FAST) frules = expand_rules<MAIN, E, C_>(rules_in);
+
+	auto lds_row = [&](int q, u32 row) -> const u32 * { return lds + ((size_t)q * g.R + row) * row_words; };
+	auto own_seg = [&](int q) {
+		Seg s2;
+		for (int k = 0; k < 4; k++) s2.w[k] = col[q][k];
+		s2.lo = 0; s2.hi = 0;
+		if (kCenterLR)
+		{
+			s2.lo = (u32)__shfl((int)col[q][3], src_lo) & lo_mask;
+			s2.hi = (u32)__shfl((int)col[q][0], src_hi);
+		}
+		return s2;
+	};
+	auto nbr_seg = [&](int q, u32 row, u32 mask) {
+		Seg s2;
+		const u32 *p = lds_row(q, row);
+		const uint4 w = *reinterpret_cast<const uint4 *>(p + cx0);
+		s2.w[0] = w.x & mask; s2.w[1] = w.y & mask; s2.w[2] = w.z & mask; s2.w[3] = w.w & mask;
+		s2.lo = 0; s2.hi = 0;
+		if (kYLR) { s2.lo = p[lo_rel] & mask & lo_mask; s2.hi = p[hi_rel] & mask; }
+		return s2;
+	};
+	auto plane_rows = [&](int q, bool with_y) {
+		PlaneRows P;
+		P.c = own_seg(q);
+		if (with_y) { P.ym = nbr_seg(q, r_m, ym_mask); P.yp = nbr_seg(q, r_p, 0xFFFFFFFFu); }
+		return P;
+	};
+
+	for (int s = 0; s < (g.dbg ? 0 : T); s++)
+	{
+		if (s) __syncthreads(); // everyone is done reading the previous generation
+		if (active)
+		{
+#pragma unroll
+			for (int q = 0; q < Q; q++)
+			{
+				uint4 w; w.x = col[q][0]; w.y = col[q][1]; w.z = col[q][2]; w.w = col[q][3];
+				*reinterpret_cast<uint4 *>(lds + ((size_t)q * g.R + rl) * row_words + cx0) = w;
+			}
+		}
+		__syncthreads();
+		PlaneRows P0 = plane_rows(0, kZYRows), P1 = plane_rows(1, true);
+#pragma unroll
+		for (int q = 1; q < Q - 1; q++)
+		{
+			const PlaneRows P2 = plane_rows(q + 1, kZYRows || q + 1 < Q - 1);
+			const u32 zmask = ((zdead_below_bits >> q) & 1u) ? 0u : 0xFFFFFFFFu; // the plane's own z decides
+			const u32 zlive = ((zlive_bits >> q) & 1u) ? 0xFFFFFFFFu : 0u;
+			uint4 o;
+			if (FAST) o = evolve4<MAIN, E, C_>(P0, P1, P2, zmask, frules);
+			else o = evolve4<MAIN, E, C_>(P0, P1, P2, zmask, rules_in);
+			const u32 m = live_mask & zlive;
+			col[q][0] = o.x & m; col[q][1] = o.y & m; col[q][2] = o.z & m; col[q][3] = o.w & m;
+			P0 = P1;
+			P1 = P2;
+		}
+	}
+
+	// store the tile's interior: rows [T, T+TY) that are real rows (gy < G), planes [T, T+TZ) inside [lo, hi)
+	if (g.dbg != 2 && active && r >= (u32)T && r < (u32)T + TY && gy < G && gy >= 0)
+	{
+#pragma unroll
+		for (int q = T; q < T + TZ; q++)
+		{
+			const int jz = z0 + q;
+			if (jz >= (int)pr.lo && jz < (int)pr.hi)
+			{
+				uint4 w; w.x = col[q][0]; w.y = col[q][1]; w.z = col[q][2]; w.w = col[q][3];
+				*reinterpret_cast<uint4 *>(out + (size_t)jz * plane_words + (size_t)gy * row_words + cx0) = w;
+			}
+		}
+	}
+}
+
+constexpr int kFuseT = 2, kFuseQ = 12;
+
+// Tile geometry for the fused kernel, or false when the grid does not suit it.
+bool fused_geometry(uint32_t G, FusedGeom *g, u32 *threads, size_t *lds_bytes)
+{
+	const u32 C = G / 32u;
+	if (C % 4u) return false;
+	const u32 CV = C / 4u;
+	if (CV & (CV - 1u)) return false; // rows must sit inside a wave for the lane exchange
+	if (CV > 64u) return false;
+	u32 shift = 0;
+	while ((1u << shift) < CV) shift++;
+	const u32 thr = CV <= 4u ? 192u : 512u;
+	const u32 R = thr / CV;
+	if (R < 2u * kFuseT + 4u) return false;
+	g->CV = CV;
+	g->cv_shift = shift;
+	g->R = R;
+	const u32 TY = R - 2u * kFuseT;
+	g->ny = (G + TY - 1u) / TY;
+	g->nz = 0;
+	g->dbg = 0;
+	*threads = thr;
+	*lds_bytes = (size_t)kFuseQ * R * C * sizeof(u32);
+	return *lds_bytes <= 160u * 1024u;
+}
+
+template <int MAIN, bool E, bool C_>
+hipError_t launch_fused_k(const PackedLaunch &l, hipStream_t stream, const FusedGeom &g, u32 threads, size_t lds_bytes);
+
+template <int MAIN, bool E, bool C_>
+hipError_t launch_fused(const PackedLaunch &l, hipStream_t stream)
+{
+	FusedGeom g;
+	u32 threads;
+	size_t lds_bytes;
+	if (!fused_geometry(l.pr.G, &g, &threads, &lds_bytes)) return hipErrorInvalidValue;
+	constexpr int TZ = kFuseQ - 2 * kFuseT;
+	const u32 planes = l.pr.hi - l.pr.lo;
+	g.nz = (planes + TZ - 1) / TZ;
+	g.dbg = (u32)(l.variant >> 8);
+	return launch_fused_k<MAIN, E, C_>(l, stream, g, threads, lds_bytes);
+}
+
+bool rules_fit_fast(const CanonRules &r)
+{
+	for (int s2 = 0; s2 < 3; s2++)
+		if (r.prog.set[s2].born.n > (u32)kFastCubes || r.prog.set[s2].survive.n > (u32)kFastCubes) return false;
+	return true;
+}
+
+bool rules_fit_fast_fwd(const CanonRules &r) { return rules_fit_fast(r); }
+
+template <int MAIN, bool E, bool C_, bool FAST>
+hipError_t launch_fused_kf(const PackedLaunch &l, hipStream_t stream, const FusedGeom &g, u32 threads, size_t lds_bytes)
+{
+	auto kern = ca_packed_fused<MAIN, E, C_, kFuseT, kFuseQ, FAST>;
+	static bool attr_set = false; // per instantiation
+	if (!attr_set)
+	{
+		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+		if (e != hipSuccess) return e;
+		attr_set = true;
+	}
+	hipLaunchKernelGGL(kern, dim3(g.ny * g.nz), dim3(threads), lds_bytes, stream, l.in, l.out, l.pr, g, l.rules->prog);
+	return hipGetLastError();
+}
+
+template <int MAIN, bool E, bool C_>
+hipError_t launch_fused_k(const PackedLaunch &l, hipStream_t stream, const FusedGeom &g, u32 threads, size_t lds_bytes)
+{
+	return rules_fit_fast(*l.rules) ? launch_fused_kf<MAIN, E, C_, true>(l, stream, g, threads, lds_bytes)
+	                                : launch_fused_kf<MAIN, E, C_, false>(l, stream, g, threads, lds_bytes);
+}
+
+template <int MAIN>
+hipError_t launch_fused_ec(const PackedLaunch &l, hipStream_t stream)
+{
+	const bool e = l.rules->need[1], c = l.rules->need[2];
+	if (e && c) return launch_fused<MAIN, true, true>(l, stream);
+	if (e) return launch_fused<MAIN, true, false>(l, stream);
+	if (c) return launch_fused<MAIN, false, true>(l, stream);
+	return launch_fused<MAIN, false, false>(l, stream);
 }
 
 // -------------------------------------------------------------------------------------------- generic kernel
@@ -450,6 +825,8 @@ __global__ __launch_bounds__(256) void ca_packed_generic(const u32 *__restrict__
 	out[((size_t)j * pr.G + y) * C + cx] = next_state(self, S, B);
 }
 
+bool rules_fit_fast_fwd(const CanonRules &r);
+
 template <int MAIN, bool E, bool C_>
 hipError_t launch_class(const PackedLaunch &l, hipStream_t stream)
 {
@@ -466,12 +843,12 @@ hipError_t launch_class(const PackedLaunch &l, hipStream_t stream)
 	// z-run of 4 planes per thread once that still leaves >= 4 workgroups per CU; small grids keep 1 plane per
 	// thread so all 256 CUs get work.
 	const bool deep = (size_t)g.tiles_per_plane * ((planes + 3u) / 4u) >= 1024u;
-	if (deep)
-		hipLaunchKernelGGL((ca_packed_class<MAIN, E, C_, 4>), dim3(g.tiles_per_plane * ((planes + 3u) / 4u)), dim3(256), 0,
-		                   stream, l.in, l.out, l.pr, g, l.rules->prog);
-	else
-		hipLaunchKernelGGL((ca_packed_class<MAIN, E, C_, 1>), dim3(g.tiles_per_plane * planes), dim3(256), 0, stream, l.in,
-		                   l.out, l.pr, g, l.rules->prog);
+	const bool fast = rules_fit_fast_fwd(*l.rules);
+	const dim3 grid_deep(g.tiles_per_plane * ((planes + 3u) / 4u)), grid_flat(g.tiles_per_plane * planes);
+	if (deep && fast) hipLaunchKernelGGL((ca_packed_class<MAIN, E, C_, 4, true>), grid_deep, dim3(256), 0, stream, l.in, l.out, l.pr, g, l.rules->prog);
+	else if (deep) hipLaunchKernelGGL((ca_packed_class<MAIN, E, C_, 4, false>), grid_deep, dim3(256), 0, stream, l.in, l.out, l.pr, g, l.rules->prog);
+	else if (fast) hipLaunchKernelGGL((ca_packed_class<MAIN, E, C_, 1, true>), grid_flat, dim3(256), 0, stream, l.in, l.out, l.pr, g, l.rules->prog);
+	else hipLaunchKernelGGL((ca_packed_class<MAIN, E, C_, 1, false>), grid_flat, dim3(256), 0, stream, l.in, l.out, l.pr, g, l.rules->prog);
 	return hipGetLastError();
 }
 
@@ -487,7 +864,7 @@ hipError_t launch_class_ec(const PackedLaunch &l, hipStream_t stream)
 
 bool use_class_kernel(const CanonRules &r, uint32_t G, int variant)
 {
-	return variant != 1 && r.fast && ((G / 32u) % 4u) == 0;
+	return (variant & 0xFF) != 1 && r.fast && ((G / 32u) % 4u) == 0;
 }
 
 } // namespace
@@ -503,6 +880,29 @@ const char *packed_kernel_name(const CanonRules &r, uint32_t G, int variant)
 	    {"ca_packed_class<edges>", "ca_packed_class<edges,E>", "ca_packed_class<edges,C>", "ca_packed_class<edges,E,C>"},
 	    {"ca_packed_class<corners>", "ca_packed_class<corners,E>", "ca_packed_class<corners,C>", "ca_packed_class<corners,E,C>"}};
 	return names[r.main][(r.need[1] ? 1 : 0) + (r.need[2] ? 2 : 0)];
+}
+
+int packed_fused_steps(const CanonRules &r, uint32_t G, int variant)
+{
+	FusedGeom g;
+	u32 threads;
+	size_t lds_bytes;
+	if ((variant & 0xFF) != 0 || !use_class_kernel(r, G, variant & 0xFF)) return 0;
+	if (r.main != MAIN_VN && r.main != MAIN_VN2D) return 0; // instantiated for the face neighbourhoods so far
+	if (r.need[1] || r.need[2]) return 0;
+	return fused_geometry(G, &g, &threads, &lds_bytes) ? kFuseT : 0;
+}
+
+hipError_t launch_packed_fused(const PackedLaunch &l, hipStream_t stream, const char **kernel_name)
+{
+	if (kernel_name) *kernel_name = "ca_packed_fused<T=2>";
+	if (l.pr.hi <= l.pr.lo) return hipSuccess;
+	switch (l.rules->main)
+	{
+	case MAIN_VN: return launch_fused<MAIN_VN, false, false>(l, stream);
+	case MAIN_VN2D: return launch_fused<MAIN_VN2D, false, false>(l, stream);
+	default: return hipErrorInvalidValue;
+	}
 }
 
 hipError_t launch_packed_step(const PackedLaunch &l, hipStream_t stream, const char **kernel_name)

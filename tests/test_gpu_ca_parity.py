@@ -268,3 +268,55 @@ def test_error_behaviour(eng):
         assert e.info().step == 0
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("G", [128, 256, 512])
+@pytest.mark.parametrize("name", ["default", "vn2d"])
+def test_fused_two_step_passes(eng, G, name):
+    """Temporal blocking (2 steps per launch) must not change a single bit, for any step count and parity."""
+    r = rules(name)
+    eng.configure(G)
+    set_rules(eng, r)
+    st = host.random_fill(host.words_per_buffer(G), seed=100 + G, and_rounds=1 if name == "default" else 5)
+    eng.set_option("graph", 0)
+    try:
+        eng.upload_state(st)
+        want = st
+        done = 0
+        for n in (3, 4, 1, 5, 8):
+            eng.step(n)
+            want = ol.packed_run(G, want, r, n)
+            done += n
+            np.testing.assert_array_equal(eng.read_state(), want)
+            assert eng.info().step == done and eng.info().current_buffer == done % 2
+        eng.set_option("fused", 0)
+        eng.upload_state(st)
+        eng.step(done)
+        np.testing.assert_array_equal(eng.read_state(), want)
+    finally:
+        eng.set_option("fused", 1)
+        eng.set_option("graph", 1)
+
+
+def test_fused_keeps_previous_state_in_other_buffer(eng):
+    import ctypes as C
+
+    import torch
+
+    G = 256
+    r = rules("default")
+    eng.configure(G)
+    set_rules(eng, r)
+    st = host.random_fill(host.words_per_buffer(G), seed=5, and_rounds=1)
+    eng.upload_state(st)
+    eng.step(70)  # a graph replay (64) + a fused/single tail
+    assert eng.info().current_buffer == 0
+    s69 = ol.packed_run(G, st, r, 69)
+    np.testing.assert_array_equal(eng.read_state(), ol.packed_step(G, s69, r))
+    p, n = eng.device_buffer(1)
+    eng.synchronize()
+    other = torch.empty(n // 4, dtype=torch.int32, device="cuda:0")
+    rt = C.CDLL("libamdhip64.so")
+    rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    assert rt.hipMemcpy(other.data_ptr(), p, n, 3) == 0
+    np.testing.assert_array_equal(other.cpu().numpy().view(np.uint32), s69)

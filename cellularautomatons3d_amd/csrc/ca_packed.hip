@@ -12,6 +12,9 @@
 // of main_pathtraced.js:13-85 is a union of them, so the class kernels are templated on <main table, edges
 // rule-set live, corners rule-set live>. Arbitrary offset lists (legal through the ABI, never produced by the
 // reference host) and grids whose row is not a multiple of 4 words take the generic per-offset kernel.
+#include <algorithm>
+#include <cstdlib>
+
 #include "ca3d_internal.h"
 
 namespace ca3d
@@ -121,30 +124,35 @@ __device__ __forceinline__ u32 eval_prog(const RuleProg &pr, const u32 *p)
 	return acc ^ pr.invert;
 }
 
-// Same for the 4 words a thread owns: the cube is fetched and decoded once (scalar work) per 4 words.
-template <int NP, int NPA>
-__device__ __forceinline__ void eval_prog4(const RuleProg &pr, const u32 (&p)[4][NPA], u32 (&acc)[4])
+// Same for the W words a thread owns: the cube is fetched and decoded once (scalar work) per W words. Literal i is
+// (plane_i & a_i) ^ b_i with wave-uniform masks — pure mask arithmetic, no per-lane selects (v_cndmask is an
+// order of magnitude slower than v_bitop3 on gfx950: tools/ubench/valu_rate.hip).
+template <int W, int NP, int NPA>
+__device__ __forceinline__ void eval_prog4(const RuleProg &pr, const u32 (&p)[W][NPA], u32 (&acc)[W])
 {
-	u32 r[4] = {0, 0, 0, 0};
+	u32 r[W];
+#pragma unroll
+	for (int w = 0; w < W; w++) r[w] = 0;
 	for (u32 c = 0; c < pr.n; c++)
 	{
 		const u32 cube = pr.cubes[c];
-		u32 e[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+		u32 e[W];
+#pragma unroll
+		for (int w = 0; w < W; w++) e[w] = 0xFFFFFFFFu;
 #pragma unroll
 		for (int i = 0; i < NP; i++)
 		{
-			if (cube & (1u << i))
-			{
-				const u32 inv = (cube & (0x100u << i)) ? 0u : 0xFFFFFFFFu;
+			const u32 care = 0u - ((cube >> i) & 1u);                 // ~0 when the plane matters
+			const u32 flip = (0u - ((cube >> (8 + i)) & 1u)) & care;  // ~0 when it must be set
+			const u32 bmask = ~flip;                                  // set: 0, clear: ~0, don't care: ~0
 #pragma unroll
-				for (int w = 0; w < 4; w++) e[w] = bitop3<(TA & (TB ^ TC))>(e[w], p[w][i], inv);
-			}
+			for (int w = 0; w < W; w++) e[w] &= bitop3<((TA & TB) ^ TC)>(p[w][i], care, bmask);
 		}
 #pragma unroll
-		for (int w = 0; w < 4; w++) r[w] |= e[w];
+		for (int w = 0; w < W; w++) r[w] |= e[w];
 	}
 #pragma unroll
-	for (int w = 0; w < 4; w++) acc[w] |= r[w] ^ pr.invert;
+	for (int w = 0; w < W; w++) acc[w] |= r[w] ^ pr.invert;
 }
 
 __device__ __forceinline__ u32 next_state(u32 alive, u32 S, u32 B)
@@ -202,25 +210,25 @@ __device__ __forceinline__ u32 cube_fast(const FastProg<NP> &f, int c, const u32
 	return e;
 }
 
-template <int NP, int NPA>
-__device__ __forceinline__ void eval_fast4(const FastProg<NP> &f, const u32 (&p)[4][NPA], u32 (&acc)[4])
+template <int W, int NP, int NPA>
+__device__ __forceinline__ void eval_fast4(const FastProg<NP> &f, const u32 (&p)[W][NPA], u32 (&acc)[W])
 {
 	if (NP == 0 || f.n == 0)
 	{
 #pragma unroll
-		for (int w = 0; w < 4; w++) acc[w] |= f.invert;
+		for (int w = 0; w < W; w++) acc[w] |= f.invert;
 		return;
 	}
-	u32 r[4];
+	u32 r[W];
 #pragma unroll
-	for (int w = 0; w < 4; w++) r[w] = cube_fast<NP>(f, 0, p[w]);
+	for (int w = 0; w < W; w++) r[w] = cube_fast<NP>(f, 0, p[w]);
 	if (f.n > 1)
 	{
 #pragma unroll
-		for (int w = 0; w < 4; w++) r[w] |= cube_fast<NP>(f, 1, p[w]);
+		for (int w = 0; w < W; w++) r[w] |= cube_fast<NP>(f, 1, p[w]);
 	}
 #pragma unroll
-	for (int w = 0; w < 4; w++) acc[w] |= r[w] ^ f.invert;
+	for (int w = 0; w < W; w++) acc[w] |= r[w] ^ f.invert;
 }
 
 template <int MAIN>
@@ -251,28 +259,28 @@ __device__ __forceinline__ FastRules<MAIN, E, C_> expand_rules(const PackedRuleA
 	return f;
 }
 
-template <int MAIN, bool E, bool C_, int NP>
-__device__ __forceinline__ void apply_rules(const PackedRuleArgs &rules, const u32 (&mn)[4][NP], const u32 (&ed)[4][4],
-                                            const u32 (&co)[4][4], u32 (&S)[4], u32 (&B)[4])
+template <int W, int MAIN, bool E, bool C_, int NP>
+__device__ __forceinline__ void apply_rules(const PackedRuleArgs &rules, const u32 (&mn)[W][NP], const u32 (&ed)[W][4],
+                                            const u32 (&co)[W][4], u32 (&S)[W], u32 (&B)[W])
 {
-	eval_prog4<NP>(rules.set[0].survive, mn, S);
-	eval_prog4<NP>(rules.set[0].born, mn, B);
-	eval_prog4<(E ? 4 : 0)>(rules.set[1].survive, ed, S);
-	eval_prog4<(E ? 4 : 0)>(rules.set[1].born, ed, B);
-	eval_prog4<(C_ ? 4 : 0)>(rules.set[2].survive, co, S);
-	eval_prog4<(C_ ? 4 : 0)>(rules.set[2].born, co, B);
+	eval_prog4<W, NP>(rules.set[0].survive, mn, S);
+	eval_prog4<W, NP>(rules.set[0].born, mn, B);
+	eval_prog4<W, (E ? 4 : 0)>(rules.set[1].survive, ed, S);
+	eval_prog4<W, (E ? 4 : 0)>(rules.set[1].born, ed, B);
+	eval_prog4<W, (C_ ? 4 : 0)>(rules.set[2].survive, co, S);
+	eval_prog4<W, (C_ ? 4 : 0)>(rules.set[2].born, co, B);
 }
 
-template <int MAIN, bool E, bool C_, int NP>
-__device__ __forceinline__ void apply_rules(const FastRules<MAIN, E, C_> &f, const u32 (&mn)[4][NP], const u32 (&ed)[4][4],
-                                            const u32 (&co)[4][4], u32 (&S)[4], u32 (&B)[4])
+template <int W, int MAIN, bool E, bool C_, int NP>
+__device__ __forceinline__ void apply_rules(const FastRules<MAIN, E, C_> &f, const u32 (&mn)[W][NP], const u32 (&ed)[W][4],
+                                            const u32 (&co)[W][4], u32 (&S)[W], u32 (&B)[W])
 {
-	eval_fast4<NP>(f.ms, mn, S);
-	eval_fast4<NP>(f.mb, mn, B);
-	eval_fast4<(E ? 4 : 0)>(f.es, ed, S);
-	eval_fast4<(E ? 4 : 0)>(f.eb, ed, B);
-	eval_fast4<(C_ ? 4 : 0)>(f.cs, co, S);
-	eval_fast4<(C_ ? 4 : 0)>(f.cb, co, B);
+	eval_fast4<W, NP>(f.ms, mn, S);
+	eval_fast4<W, NP>(f.mb, mn, B);
+	eval_fast4<W, (E ? 4 : 0)>(f.es, ed, S);
+	eval_fast4<W, (E ? 4 : 0)>(f.eb, ed, B);
+	eval_fast4<W, (C_ ? 4 : 0)>(f.cs, co, S);
+	eval_fast4<W, (C_ ? 4 : 0)>(f.cb, co, B);
 }
 
 // ---- plane / row addressing for the generic kernel -------------------------------------------------------
@@ -317,14 +325,18 @@ __device__ __forceinline__ Nbr neighbours(const u32 *in, const PlaneRange &pr, u
 // ---------------------------------------------------------------------------------------------- class kernel
 // One row segment of 4 words plus the word on either side (x-1 of word 0 is dead at cx0 == 0; x+1 of the last
 // word of the row wraps to word 0 of the same row).
-struct Seg
+template <int W>
+struct SegT
 {
-	u32 w[4];
+	u32 w[W];
 	u32 lo, hi;
 };
+using Seg = SegT<4>;
 
-__device__ __forceinline__ u32 seg_l(const Seg &s, int i) { return from_left(s.w[i], i ? s.w[i - 1] : s.lo); }
-__device__ __forceinline__ u32 seg_r(const Seg &s, int i) { return from_right(i < 3 ? s.w[i + 1] : s.hi, s.w[i]); }
+template <int W>
+__device__ __forceinline__ u32 seg_l(const SegT<W> &s, int i) { return from_left(s.w[i], i ? s.w[i > 0 ? i - 1 : 0] : s.lo); }
+template <int W>
+__device__ __forceinline__ u32 seg_r(const SegT<W> &s, int i) { return from_right(i < W - 1 ? s.w[i < W - 1 ? i + 1 : 0] : s.hi, s.w[i]); }
 
 struct TileGeom
 {
@@ -375,24 +387,26 @@ __device__ __forceinline__ Seg load_seg(const u32 *plane, const Pos &ps, int r, 
 	return s;
 }
 
-struct PlaneRows
+template <int W>
+struct PlaneRowsT
 {
-	Seg ym, c, yp;
+	SegT<W> ym, c, yp;
 };
+using PlaneRows = PlaneRowsT<4>;
 
-// New state of the 4 words at the centre of P1 given the planes below (P0, already masked by the caller through
+// New state of the W words at the centre of P1 given the planes below (P0, already masked by the caller through
 // `zmask` when z-1 is dead) and above (P2). Shared by the streaming and the fused kernels.
-template <int MAIN, bool E, bool C_, typename RS>
-__device__ __forceinline__ uint4 evolve4(const PlaneRows &P0, const PlaneRows &P1, const PlaneRows &P2, u32 zmask,
-                                         const RS &rules)
+template <int W, int MAIN, bool E, bool C_, typename RS>
+__device__ __forceinline__ void evolve(const PlaneRowsT<W> &P0, const PlaneRowsT<W> &P1, const PlaneRowsT<W> &P2, u32 zmask,
+                                       const RS &rules, u32 (&out)[W])
 {
 	constexpr bool kNeedEdges = E || MAIN == MAIN_MOORE || MAIN == MAIN_EDGES;
 	constexpr bool kNeedCorners = C_ || MAIN == MAIN_MOORE || MAIN == MAIN_CORNERS;
 
 	constexpr int NP = MainPlanes<MAIN>::value;
-	u32 mn[4][NP], ed[4][4], co[4][4];
+	u32 mn[W][NP], ed[W][4], co[W][4];
 #pragma unroll
-	for (int i = 0; i < 4; i++)
+	for (int i = 0; i < W; i++)
 	{
 		for (int k = 0; k < 4; k++) { ed[i][k] = 0; co[i][k] = 0; }
 		if (kNeedEdges)
@@ -444,13 +458,21 @@ __device__ __forceinline__ uint4 evolve4(const PlaneRows &P0, const PlaneRows &P
 			for (int k = 0; k < NP; k++) mn[i][k] = co[i][k];
 		}
 	}
-	u32 S[4] = {0, 0, 0, 0}, B[4] = {0, 0, 0, 0};
-	apply_rules<MAIN, E, C_, NP>(rules, mn, ed, co, S, B);
+	u32 S[W], B[W];
+#pragma unroll
+	for (int i = 0; i < W; i++) { S[i] = 0; B[i] = 0; }
+	apply_rules<W, MAIN, E, C_, NP>(rules, mn, ed, co, S, B);
+#pragma unroll
+	for (int i = 0; i < W; i++) out[i] = next_state(P1.c.w[i], S[i], B[i]);
+}
+
+template <int MAIN, bool E, bool C_, typename RS>
+__device__ __forceinline__ uint4 evolve4(const PlaneRows &P0, const PlaneRows &P1, const PlaneRows &P2, u32 zmask, const RS &rules)
+{
+	u32 o[4];
+	evolve<4, MAIN, E, C_>(P0, P1, P2, zmask, rules, o);
 	uint4 r;
-	r.x = next_state(P1.c.w[0], S[0], B[0]);
-	r.y = next_state(P1.c.w[1], S[1], B[1]);
-	r.z = next_state(P1.c.w[2], S[2], B[2]);
-	r.w = next_state(P1.c.w[3], S[3], B[3]);
+	r.x = o[0]; r.y = o[1]; r.z = o[2]; r.w = o[3];
 	return r;
 }
 
@@ -537,209 +559,227 @@ __global__ __launch_bounds__(256) void ca_packed_class(const u32 *__restrict__ i
 }
 
 // ---------------------------------------------------------------------------------------------- fused kernel
-// T CA steps in one launch (temporal blocking). A workgroup owns a tile of TY rows x TZ planes x the full x
-// extent plus a halo of T rows / planes; a thread owns one dwordx4 position (row r, cx0) and keeps its whole
-// z-column of Q = TZ + 2T planes in REGISTERS across the T steps. Per step the workgroup publishes its columns
-// to LDS (one ds_write_b128 per plane) and every thread reads only its y+-1 neighbour rows back: z-neighbours are
-// its own registers, x-neighbours come from the neighbour lanes. Halo cells go stale one layer per step, which
-// is exactly the halo depth. HBM sees the grid once per T steps and the launch boundary is paid once per T steps.
+// Two CA steps per launch (temporal blocking) with NO shared memory and NO barriers: every wavefront is an
+// independent worker. A wave owns a strip of ROWS = 64 / LPR consecutive rows x the full x extent (LPR lanes per
+// row, W words per lane) and streams along z over a chunk of ZC planes. Per plane it keeps three-plane windows
+// of generation 0 (loaded) and generation 1 (after one step) in registers; the z neighbours are the thread's
+// own registers and the x / y neighbours come from other lanes of the same wave (ds_bpermute, no LDS memory).
+// Two rows on each side of the strip and two planes on each side of the chunk are halo: they go stale one
+// layer per step, which is exactly their depth. HBM sees the grid once per two steps, the launch boundary is
+// paid once per two steps, and because waves never synchronise their load / compute / store phases drift apart
+// and overlap instead of marching in lock-step.
 //
-// Boundary: rows / planes at global coordinate -1 are dead (forced to zero every step), coordinates >= G are
-// replicas of coordinate - G and evolve with a dead neighbour below whenever their own coordinate is 0 (mod G) —
-// the same rule the slab ghosts use.
+// Boundary: rows / planes at global coordinate -1 are dead (forced to zero in every generation); coordinates
+// >= G are replicas of coordinate - G and evolve with a dead neighbour below whenever their own coordinate is
+// 0 (mod G) — the same rule the slab ghosts use.
 struct FusedGeom
 {
-	u32 CV, cv_shift; // uint4 per row (power of two)
-	u32 R;            // rows per tile incl. halo
-	u32 ny, nz;       // tiles along y, z
-	u32 dbg;          // profiling aid: 1 = skip the step loop (memory phases only), 2 = skip the stores too
+	u32 LPR, lpr_shift; // lanes per row (C / W), power of two, <= 8
+	u32 nstrips;        // strips along y
+	u32 nchunks;        // chunks along z
+	u32 dbg;            // profiling aid: 1 = skip the compute (memory phases only), 2 = skip the stores too
 };
 
-template <int MAIN, bool E, bool C_, int T, int Q, bool FAST>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 8))) void ca_packed_fused(const u32 *__restrict__ in, u32 *__restrict__ out,
-                                                       PlaneRange pr, FusedGeom g, PackedRuleArgs rules_in)
+template <int W> struct VecT;
+template <> struct VecT<2> { typedef uint2 type; };
+template <> struct VecT<4> { typedef uint4 type; };
+
+template <int W>
+__device__ __forceinline__ void vec_load(const u32 *p, u32 (&w)[W])
 {
-	constexpr int TZ = Q - 2 * T;
+	if (W <= 4)
+	{
+		constexpr int V = W <= 2 ? 2 : 4;
+		const typename VecT<V>::type v = *reinterpret_cast<const typename VecT<V>::type *>(p);
+		const u32 *e = reinterpret_cast<const u32 *>(&v);
+#pragma unroll
+		for (int k = 0; k < W; k++) w[k] = e[k];
+	}
+	else
+	{
+#pragma unroll
+		for (int c = 0; c < W / 4; c++)
+		{
+			const uint4 v = *reinterpret_cast<const uint4 *>(p + 4 * c);
+			w[4 * c] = v.x; w[4 * c + 1] = v.y; w[4 * c + 2] = v.z; w[4 * c + 3] = v.w;
+		}
+	}
+}
+
+template <int W>
+__device__ __forceinline__ void vec_store(u32 *p, const u32 (&w)[W])
+{
+	if (W <= 4)
+	{
+		constexpr int V = W <= 2 ? 2 : 4;
+		typename VecT<V>::type v;
+		u32 *e = reinterpret_cast<u32 *>(&v);
+#pragma unroll
+		for (int k = 0; k < W; k++) e[k] = w[k];
+		*reinterpret_cast<typename VecT<V>::type *>(p) = v;
+	}
+	else
+	{
+#pragma unroll
+		for (int c = 0; c < W / 4; c++)
+		{
+			uint4 v;
+			v.x = w[4 * c]; v.y = w[4 * c + 1]; v.z = w[4 * c + 2]; v.w = w[4 * c + 3];
+			*reinterpret_cast<uint4 *>(p + 4 * c) = v;
+		}
+	}
+}
+
+template <int MAIN, bool E, bool C_, int W, int ZC, bool FAST>
+__global__ __launch_bounds__(64) void ca_packed_fused(const u32 *__restrict__ in, u32 *__restrict__ out,
+                                                      PlaneRange pr, FusedGeom g, PackedRuleArgs rules_in)
+{
+	constexpr int T = 2;
 	constexpr bool kNeedEdges = E || MAIN == MAIN_MOORE || MAIN == MAIN_EDGES;
 	constexpr bool kNeedCorners = C_ || MAIN == MAIN_MOORE || MAIN == MAIN_CORNERS;
 	constexpr bool kMainVN = MAIN == MAIN_VN || MAIN == MAIN_MOORE;
 	constexpr bool kCenterLR = kMainVN || MAIN == MAIN_VN2D || MAIN == MAIN_MOORE2D || kNeedEdges;
 	constexpr bool kYLR = kNeedEdges || kNeedCorners || MAIN == MAIN_MOORE2D;
-	constexpr bool kZYRows = kNeedEdges || kNeedCorners; // y+-1 rows of the z+-1 planes
-
-	extern __shared__ __attribute__((aligned(16))) u32 lds[]; // [Q][R][C]
 
 	const u32 b = blockIdx.x, nb = gridDim.x;
 	const u32 v = (nb & 7u) == 0 ? (b & 7u) * (nb >> 3) + (b >> 3) : b; // XCD k gets a contiguous z range
-	const u32 tz = v / g.ny, ty = v - tz * g.ny;
-	const u32 tid = threadIdx.x;
-	const u32 r = tid >> g.cv_shift, cxv = tid & (g.CV - 1u);
-	const bool active = r < g.R;
-	const u32 C = g.CV * 4u, cx0 = cxv * 4u;
+	const u32 chunk = v / g.nstrips, strip = v - chunk * g.nstrips;
+	const int lane = (int)threadIdx.x;
+	const u32 rr = (u32)lane >> g.lpr_shift, cxl = (u32)lane & (g.LPR - 1u);
+	const u32 ROWS = 64u >> g.lpr_shift, UR = ROWS - 2u * T;
+	const u32 C = g.LPR * W, cx0 = cxl * W;
 	const int G = (int)pr.G;
-	const u32 TY = g.R - 2u * T;
 	const u32 plane_words = C * pr.G;
-	const u32 row_words = C;
 
-	// row of this thread
-	const int gy = (int)(ty * TY) - T + (int)r;
-	const bool row_live = gy >= 0;
+	const int gy = (int)(strip * UR) - T + (int)rr;
 	const int gyw = gy < 0 ? 0 : (gy >= G ? gy - G : gy);
-	const u32 live_mask = (row_live && active) ? 0xFFFFFFFFu : 0u;
+	const u32 live_mask = gy >= 0 ? 0xFFFFFFFFu : 0u;
 	const u32 ym_mask = gyw == 0 ? 0u : 0xFFFFFFFFu; // y-1 == -1 is dropped
-	const u32 rl = active ? r : 0u;
-	const u32 r_m = rl == 0 ? 0u : rl - 1u, r_p = rl + 1u >= g.R ? g.R - 1u : rl + 1u;
-	const int lane = (int)(tid & 63u);
-	const int src_lo = lane - 1, src_hi = cxv + 1u == g.CV ? lane - (int)(g.CV - 1u) : lane + 1;
-	const u32 lo_mask = cx0 == 0 ? 0u : 0xFFFFFFFFu;
-	const u32 lo_rel = cx0 == 0 ? 0u : cx0 - 1u, hi_rel = cx0 + 4u == C ? 0u : cx0 + 4u;
+	const int src_ym = rr == 0 ? lane : lane - (int)g.LPR, src_yp = rr + 1u == ROWS ? lane : lane + (int)g.LPR;
+	const int src_lo = lane - 1, src_hi = cxl + 1u == g.LPR ? lane - (int)(g.LPR - 1u) : lane + 1;
+	const u32 lo_mask = cxl == 0 ? 0u : 0xFFFFFFFFu;
+	const size_t row_off = (size_t)gyw * C + cx0;
+	const bool store_row = rr >= (u32)T && rr < ROWS - (u32)T && gy >= 0 && gy < G;
 
-	// planes of this tile: array plane index, liveness, "plane below is dead"
-	const int z0 = (int)pr.lo + (int)(tz * TZ) - T;
-	u32 col[Q][4];
-	u32 zlive_bits = 0, zdead_below_bits = 0; // bit q: plane q exists / its z-1 neighbour is dead
-#pragma unroll
-	for (int q = 0; q < Q; q++)
-	{
-		int jz = z0 + q;
-		bool zl, zd;
-		if (pr.wrap_full)
-		{
-			zl = jz >= 0;
-			jz = jz < 0 ? 0 : (jz >= G ? jz - G : jz);
-			zd = jz == 0;
-		}
-		else
-		{
-			zl = jz >= 0 && jz < (int)pr.nplanes;
-			jz = jz < 0 ? 0 : (jz >= (int)pr.nplanes ? (int)pr.nplanes - 1 : jz);
-			zd = global_z(pr, (u32)jz) == 0;
-		}
-		zlive_bits |= (zl ? 1u : 0u) << q;
-		zdead_below_bits |= (zd ? 1u : 0u) << q;
-		const uint4 w = *reinterpret_cast<const uint4 *>(in + (size_t)jz * plane_words + (size_t)gyw * row_words + cx0);
-		const u32 m = zl ? live_mask : 0u;
-		col[q][0] = w.x & m; col[q][1] = w.y & m; col[q][2] = w.z & m; col[q][3] = w.w & m;
-	}
 	FastRules<MAIN, E, C_> frules;
 	if (FAST) frules = expand_rules<MAIN, E, C_>(rules_in);
 
-	auto lds_row = [&](int q, u32 row) -> const u32 * { return lds + ((size_t)q * g.R + row) * row_words; };
-	auto own_seg = [&](int q) {
-		Seg s2;
-		for (int k = 0; k < 4; k++) s2.w[k] = col[q][k];
-		s2.lo = 0; s2.hi = 0;
-		if (kCenterLR)
+	// neighbour rows of one plane of one generation, built from the thread's own W words by lane exchange
+	auto rows_of = [&](const u32 (&val)[W]) {
+		PlaneRowsT<W> P;
+#pragma unroll
+		for (int k = 0; k < W; k++) P.c.w[k] = val[k];
+		P.c.lo = 0; P.c.hi = 0;
+		if (kCenterLR || kYLR)
 		{
-			s2.lo = (u32)__shfl((int)col[q][3], src_lo) & lo_mask;
-			s2.hi = (u32)__shfl((int)col[q][0], src_hi);
+			P.c.lo = (u32)__shfl((int)val[W - 1], src_lo) & lo_mask;
+			P.c.hi = (u32)__shfl((int)val[0], src_hi);
 		}
-		return s2;
-	};
-	auto nbr_seg = [&](int q, u32 row, u32 mask) {
-		Seg s2;
-		const u32 *p = lds_row(q, row);
-		const uint4 w = *reinterpret_cast<const uint4 *>(p + cx0);
-		s2.w[0] = w.x & mask; s2.w[1] = w.y & mask; s2.w[2] = w.z & mask; s2.w[3] = w.w & mask;
-		s2.lo = 0; s2.hi = 0;
-		if (kYLR) { s2.lo = p[lo_rel] & mask & lo_mask; s2.hi = p[hi_rel] & mask; }
-		return s2;
-	};
-	auto plane_rows = [&](int q, bool with_y) {
-		PlaneRows P;
-		P.c = own_seg(q);
-		if (with_y) { P.ym = nbr_seg(q, r_m, ym_mask); P.yp = nbr_seg(q, r_p, 0xFFFFFFFFu); }
+#pragma unroll
+		for (int k = 0; k < W; k++)
+		{
+			P.ym.w[k] = (u32)__shfl((int)val[k], src_ym) & ym_mask;
+			P.yp.w[k] = (u32)__shfl((int)val[k], src_yp);
+		}
+		P.ym.lo = P.ym.hi = P.yp.lo = P.yp.hi = 0;
+		if (kYLR)
+		{
+			P.ym.lo = (u32)__shfl((int)P.c.lo, src_ym) & ym_mask;
+			P.ym.hi = (u32)__shfl((int)P.c.hi, src_ym) & ym_mask;
+			P.yp.lo = (u32)__shfl((int)P.c.lo, src_yp);
+			P.yp.hi = (u32)__shfl((int)P.c.hi, src_yp);
+		}
 		return P;
 	};
 
-	for (int s = 0; s < (g.dbg ? 0 : T); s++)
+	const int zc0 = (int)pr.lo + (int)(chunk * ZC); // first output plane of the chunk
+	constexpr int NI = ZC + 2 * T;                   // planes streamed: zc0 - 2 .. zc0 + ZC + 1
+	// Issue every load of the chunk up front: the data returns in order, so the first planes can be worked on while
+	// the rest of the chunk is still in flight (the waits the compiler inserts are counted vmcnt waits).
+	u32 raw[NI][W];
+#pragma unroll
+	for (int i = 0; i < NI; i++)
 	{
-		if (s) __syncthreads(); // everyone is done reading the previous generation
-		if (active)
-		{
-#pragma unroll
-			for (int q = 0; q < Q; q++)
-			{
-				uint4 w; w.x = col[q][0]; w.y = col[q][1]; w.z = col[q][2]; w.w = col[q][3];
-				*reinterpret_cast<uint4 *>(lds + ((size_t)q * g.R + rl) * row_words + cx0) = w;
-			}
-		}
-		__syncthreads();
-		PlaneRows P0 = plane_rows(0, kZYRows), P1 = plane_rows(1, true);
-#pragma unroll
-		for (int q = 1; q < Q - 1; q++)
-		{
-			const PlaneRows P2 = plane_rows(q + 1, kZYRows || q + 1 < Q - 1);
-			const u32 zmask = ((zdead_below_bits >> q) & 1u) ? 0u : 0xFFFFFFFFu; // the plane's own z decides
-			const u32 zlive = ((zlive_bits >> q) & 1u) ? 0xFFFFFFFFu : 0u;
-			uint4 o;
-			if (FAST) o = evolve4<MAIN, E, C_>(P0, P1, P2, zmask, frules);
-			else o = evolve4<MAIN, E, C_>(P0, P1, P2, zmask, rules_in);
-			const u32 m = live_mask & zlive;
-			col[q][0] = o.x & m; col[q][1] = o.y & m; col[q][2] = o.z & m; col[q][3] = o.w & m;
-			P0 = P1;
-			P1 = P2;
-		}
+		const int p = zc0 - T + i;
+		int jz;
+		if (pr.wrap_full) jz = p < 0 ? 0 : (p >= G ? p - G : p);
+		else jz = p < 0 ? 0 : (p >= (int)pr.nplanes ? (int)pr.nplanes - 1 : p);
+		vec_load<W>(in + (size_t)jz * plane_words + row_off, raw[i]);
 	}
-
-	// store the tile's interior: rows [T, T+TY) that are real rows (gy < G), planes [T, T+TZ) inside [lo, hi)
-	if (g.dbg != 2 && active && r >= (u32)T && r < (u32)T + TY && gy < G && gy >= 0)
-	{
+	PlaneRowsT<W> R0[NI], R1[NI]; // generation 0 / 1 rows by stream index (compile-time indices)
 #pragma unroll
-		for (int q = T; q < T + TZ; q++)
+	for (int i = 0; i < NI; i++)
+	{
+		// ---- plane p of generation 0
+		const int p = zc0 - T + i;
+		const bool zl = pr.wrap_full ? p >= 0 : (p >= 0 && p < (int)pr.nplanes);
+		u32 val[W];
+		const u32 m0 = zl ? live_mask : 0u;
+#pragma unroll
+		for (int k = 0; k < W; k++) val[k] = raw[i][k] & m0;
+		R0[i] = rows_of(val);
+		if (g.dbg) { R1[i] = R0[i]; }
+		// ---- generation 1 of plane p-1 (stream index i-1)
+		if (!g.dbg && i >= 2)
 		{
-			const int jz = z0 + q;
-			if (jz >= (int)pr.lo && jz < (int)pr.hi)
+			const int p1 = p - 1;
+			bool zl1, zd1;
+			if (pr.wrap_full) { zl1 = p1 >= 0; const int w1 = p1 < 0 ? 1 : (p1 >= G ? p1 - G : p1); zd1 = w1 == 0; }
+			else { zl1 = p1 >= 0 && p1 < (int)pr.nplanes; zd1 = global_z(pr, (u32)(p1 < 0 ? 0 : p1)) == 0; }
+			u32 o[W];
+			if (FAST) evolve<W, MAIN, E, C_>(R0[i - 2], R0[i - 1], R0[i], zd1 ? 0u : 0xFFFFFFFFu, frules, o);
+			else evolve<W, MAIN, E, C_>(R0[i - 2], R0[i - 1], R0[i], zd1 ? 0u : 0xFFFFFFFFu, rules_in, o);
+			const u32 m1 = zl1 ? live_mask : 0u;
+#pragma unroll
+			for (int k = 0; k < W; k++) o[k] &= m1;
+			R1[i - 1] = rows_of(o);
+		}
+		// ---- generation 2 of plane p-2 (stream index i-2): needs generation 1 of stream indices i-3, i-2, i-1
+		if (i >= 4)
+		{
+			const int p2 = p - 2;
+			u32 o[W];
+			if (!g.dbg)
 			{
-				uint4 w; w.x = col[q][0]; w.y = col[q][1]; w.z = col[q][2]; w.w = col[q][3];
-				*reinterpret_cast<uint4 *>(out + (size_t)jz * plane_words + (size_t)gy * row_words + cx0) = w;
+				bool zd2;
+				if (pr.wrap_full) { const int w2 = p2 >= G ? p2 - G : p2; zd2 = w2 == 0; }
+				else { zd2 = global_z(pr, (u32)p2) == 0; }
+				if (FAST) evolve<W, MAIN, E, C_>(R1[i - 3], R1[i - 2], R1[i - 1], zd2 ? 0u : 0xFFFFFFFFu, frules, o);
+				else evolve<W, MAIN, E, C_>(R1[i - 3], R1[i - 2], R1[i - 1], zd2 ? 0u : 0xFFFFFFFFu, rules_in, o);
 			}
+			else
+			{
+#pragma unroll
+				for (int k = 0; k < W; k++) o[k] = R1[i - 2].c.w[k];
+			}
+			if (g.dbg != 2 && store_row && p2 >= (int)pr.lo && p2 < (int)pr.hi && p2 < zc0 + ZC)
+				vec_store<W>(out + (size_t)p2 * plane_words + (size_t)gy * C + cx0, o);
 		}
 	}
 }
 
-constexpr int kFuseT = 2, kFuseQ = 12;
+constexpr int kFuseZC = 12;
 
-// Tile geometry for the fused kernel, or false when the grid does not suit it.
-bool fused_geometry(uint32_t G, FusedGeom *g, u32 *threads, size_t *lds_bytes)
+// Geometry of the fused kernel for a grid, or false when the grid does not suit it (then single steps are used).
+bool fused_geometry(uint32_t G, FusedGeom *g, int *words_per_lane)
 {
 	const u32 C = G / 32u;
-	if (C % 4u) return false;
-	const u32 CV = C / 4u;
-	if (CV & (CV - 1u)) return false; // rows must sit inside a wave for the lane exchange
-	if (CV > 64u) return false;
+	int W;
+	if (C == 8u) W = 2;
+	else if (C == 16u) W = 4;
+	else if (C == 32u) W = 8;
+	else return false; // 256^3, 512^3, 1024^3: 4 lanes per row, 16 rows per wave
+	const u32 LPR = C / (u32)W;
 	u32 shift = 0;
-	while ((1u << shift) < CV) shift++;
-	const u32 thr = CV <= 4u ? 192u : 512u;
-	const u32 R = thr / CV;
-	if (R < 2u * kFuseT + 4u) return false;
-	g->CV = CV;
-	g->cv_shift = shift;
-	g->R = R;
-	const u32 TY = R - 2u * kFuseT;
-	g->ny = (G + TY - 1u) / TY;
-	g->nz = 0;
+	while ((1u << shift) < LPR) shift++;
+	g->LPR = LPR;
+	g->lpr_shift = shift;
+	const u32 UR = 64u / LPR - 4u;
+	g->nstrips = (G + UR - 1u) / UR;
+	g->nchunks = 0;
 	g->dbg = 0;
-	*threads = thr;
-	*lds_bytes = (size_t)kFuseQ * R * C * sizeof(u32);
-	return *lds_bytes <= 160u * 1024u;
-}
-
-template <int MAIN, bool E, bool C_>
-hipError_t launch_fused_k(const PackedLaunch &l, hipStream_t stream, const FusedGeom &g, u32 threads, size_t lds_bytes);
-
-template <int MAIN, bool E, bool C_>
-hipError_t launch_fused(const PackedLaunch &l, hipStream_t stream)
-{
-	FusedGeom g;
-	u32 threads;
-	size_t lds_bytes;
-	if (!fused_geometry(l.pr.G, &g, &threads, &lds_bytes)) return hipErrorInvalidValue;
-	constexpr int TZ = kFuseQ - 2 * kFuseT;
-	const u32 planes = l.pr.hi - l.pr.lo;
-	g.nz = (planes + TZ - 1) / TZ;
-	g.dbg = (u32)(l.variant >> 8);
-	return launch_fused_k<MAIN, E, C_>(l, stream, g, threads, lds_bytes);
+	*words_per_lane = W;
+	return true;
 }
 
 bool rules_fit_fast(const CanonRules &r)
@@ -751,36 +791,32 @@ bool rules_fit_fast(const CanonRules &r)
 
 bool rules_fit_fast_fwd(const CanonRules &r) { return rules_fit_fast(r); }
 
-template <int MAIN, bool E, bool C_, bool FAST>
-hipError_t launch_fused_kf(const PackedLaunch &l, hipStream_t stream, const FusedGeom &g, u32 threads, size_t lds_bytes)
+template <int MAIN, bool E, bool C_, int W>
+hipError_t launch_fused_w(const PackedLaunch &l, hipStream_t stream, FusedGeom g)
 {
-	auto kern = ca_packed_fused<MAIN, E, C_, kFuseT, kFuseQ, FAST>;
-	static bool attr_set = false; // per instantiation
-	if (!attr_set)
-	{
-		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-		if (e != hipSuccess) return e;
-		attr_set = true;
-	}
-	hipLaunchKernelGGL(kern, dim3(g.ny * g.nz), dim3(threads), lds_bytes, stream, l.in, l.out, l.pr, g, l.rules->prog);
+	const u32 planes = l.pr.hi - l.pr.lo;
+	g.nchunks = (planes + kFuseZC - 1) / kFuseZC;
+	g.dbg = (u32)(l.variant >> 8);
+	const dim3 grid(g.nstrips * g.nchunks);
+	if (rules_fit_fast(*l.rules))
+		hipLaunchKernelGGL((ca_packed_fused<MAIN, E, C_, W, kFuseZC, true>), grid, dim3(64), 0, stream, l.in, l.out, l.pr, g, l.rules->prog);
+	else
+		hipLaunchKernelGGL((ca_packed_fused<MAIN, E, C_, W, kFuseZC, false>), grid, dim3(64), 0, stream, l.in, l.out, l.pr, g, l.rules->prog);
 	return hipGetLastError();
 }
 
 template <int MAIN, bool E, bool C_>
-hipError_t launch_fused_k(const PackedLaunch &l, hipStream_t stream, const FusedGeom &g, u32 threads, size_t lds_bytes)
+hipError_t launch_fused(const PackedLaunch &l, hipStream_t stream)
 {
-	return rules_fit_fast(*l.rules) ? launch_fused_kf<MAIN, E, C_, true>(l, stream, g, threads, lds_bytes)
-	                                : launch_fused_kf<MAIN, E, C_, false>(l, stream, g, threads, lds_bytes);
-}
-
-template <int MAIN>
-hipError_t launch_fused_ec(const PackedLaunch &l, hipStream_t stream)
-{
-	const bool e = l.rules->need[1], c = l.rules->need[2];
-	if (e && c) return launch_fused<MAIN, true, true>(l, stream);
-	if (e) return launch_fused<MAIN, true, false>(l, stream);
-	if (c) return launch_fused<MAIN, false, true>(l, stream);
-	return launch_fused<MAIN, false, false>(l, stream);
+	FusedGeom g;
+	int W;
+	if (!fused_geometry(l.pr.G, &g, &W)) return hipErrorInvalidValue;
+	switch (W)
+	{
+	case 2: return launch_fused_w<MAIN, E, C_, 2>(l, stream, g);
+	case 4: return launch_fused_w<MAIN, E, C_, 4>(l, stream, g);
+	default: return launch_fused_w<MAIN, E, C_, 8>(l, stream, g);
+	}
 }
 
 // -------------------------------------------------------------------------------------------- generic kernel
@@ -842,11 +878,16 @@ hipError_t launch_class(const PackedLaunch &l, hipStream_t stream)
 	const u32 planes = l.pr.hi - l.pr.lo;
 	// z-run of 4 planes per thread once that still leaves >= 4 workgroups per CU; small grids keep 1 plane per
 	// thread so all 256 CUs get work.
-	const bool deep = (size_t)g.tiles_per_plane * ((planes + 3u) / 4u) >= 1024u;
+	// Planes per thread (measured on MI355X, 512^3 / 1024^3): kernels that read only face neighbours are
+	// latency-bound and want many small waves (2 planes: 7.2 us vs 7.9 us with 4 and 9.0 us with 8 at 512^3);
+	// kernels that need the diagonal rows re-read 9 rows per plane and amortise them over 4 planes (28 us vs 35 us).
+	constexpr bool kDiagonals = E || C_ || MAIN == MAIN_MOORE || MAIN == MAIN_EDGES || MAIN == MAIN_CORNERS;
+	constexpr int ZRUN = kDiagonals ? 4 : 2;
+	const bool deep = (size_t)g.tiles_per_plane * ((planes + ZRUN - 1u) / ZRUN) >= 1024u;
 	const bool fast = rules_fit_fast_fwd(*l.rules);
-	const dim3 grid_deep(g.tiles_per_plane * ((planes + 3u) / 4u)), grid_flat(g.tiles_per_plane * planes);
-	if (deep && fast) hipLaunchKernelGGL((ca_packed_class<MAIN, E, C_, 4, true>), grid_deep, dim3(256), 0, stream, l.in, l.out, l.pr, g, l.rules->prog);
-	else if (deep) hipLaunchKernelGGL((ca_packed_class<MAIN, E, C_, 4, false>), grid_deep, dim3(256), 0, stream, l.in, l.out, l.pr, g, l.rules->prog);
+	const dim3 grid_deep(g.tiles_per_plane * ((planes + ZRUN - 1u) / ZRUN)), grid_flat(g.tiles_per_plane * planes);
+	if (deep && fast) hipLaunchKernelGGL((ca_packed_class<MAIN, E, C_, ZRUN, true>), grid_deep, dim3(256), 0, stream, l.in, l.out, l.pr, g, l.rules->prog);
+	else if (deep) hipLaunchKernelGGL((ca_packed_class<MAIN, E, C_, ZRUN, false>), grid_deep, dim3(256), 0, stream, l.in, l.out, l.pr, g, l.rules->prog);
 	else if (fast) hipLaunchKernelGGL((ca_packed_class<MAIN, E, C_, 1, true>), grid_flat, dim3(256), 0, stream, l.in, l.out, l.pr, g, l.rules->prog);
 	else hipLaunchKernelGGL((ca_packed_class<MAIN, E, C_, 1, false>), grid_flat, dim3(256), 0, stream, l.in, l.out, l.pr, g, l.rules->prog);
 	return hipGetLastError();
@@ -885,12 +926,11 @@ const char *packed_kernel_name(const CanonRules &r, uint32_t G, int variant)
 int packed_fused_steps(const CanonRules &r, uint32_t G, int variant)
 {
 	FusedGeom g;
-	u32 threads;
-	size_t lds_bytes;
+	int W;
 	if ((variant & 0xFF) != 0 || !use_class_kernel(r, G, variant & 0xFF)) return 0;
 	if (r.main != MAIN_VN && r.main != MAIN_VN2D) return 0; // instantiated for the face neighbourhoods so far
 	if (r.need[1] || r.need[2]) return 0;
-	return fused_geometry(G, &g, &threads, &lds_bytes) ? kFuseT : 0;
+	return fused_geometry(G, &g, &W) ? 2 : 0;
 }
 
 hipError_t launch_packed_fused(const PackedLaunch &l, hipStream_t stream, const char **kernel_name)

@@ -98,7 +98,9 @@ void compile_rule_prog(uint32_t onset_mask, uint32_t max_count, RuleProg *out)
 	const uint32_t dc = universe & ~reachable;
 	std::vector<Imp> pos = qm_cover(on, dc, nvars);
 	std::vector<Imp> neg = qm_cover(off, dc, nvars);
-	const bool use_neg = (off == 0) || (on != 0 && cost_of(neg) < cost_of(pos));
+	// Prefer a cover the kernels can keep in registers (<= 2 cubes), then the cheaper one.
+	auto key = [](const std::vector<Imp> &c) { return (c.size() > 2 ? 1000 : 0) + cost_of(c); };
+	const bool use_neg = (off == 0) || (on != 0 && key(neg) < key(pos));
 	const std::vector<Imp> &c = use_neg ? neg : pos;
 	*out = RuleProg{};
 	out->invert = use_neg ? 0xFFFFFFFFu : 0u;

@@ -279,6 +279,7 @@ def test_fused_two_step_passes(eng, G, name):
     set_rules(eng, r)
     st = host.random_fill(host.words_per_buffer(G), seed=100 + G, and_rounds=1 if name == "default" else 5)
     eng.set_option("graph", 0)
+    eng.set_option("fused", 1)
     try:
         eng.upload_state(st)
         want = st
@@ -294,7 +295,7 @@ def test_fused_two_step_passes(eng, G, name):
         eng.step(done)
         np.testing.assert_array_equal(eng.read_state(), want)
     finally:
-        eng.set_option("fused", 1)
+        eng.set_option("fused", 0)
         eng.set_option("graph", 1)
 
 
@@ -308,8 +309,10 @@ def test_fused_keeps_previous_state_in_other_buffer(eng):
     eng.configure(G)
     set_rules(eng, r)
     st = host.random_fill(host.words_per_buffer(G), seed=5, and_rounds=1)
+    eng.set_option("fused", 1)
     eng.upload_state(st)
     eng.step(70)  # a graph replay (64) + a fused/single tail
+    eng.set_option("fused", 0)
     assert eng.info().current_buffer == 0
     s69 = ol.packed_run(G, st, r, 69)
     np.testing.assert_array_equal(eng.read_state(), ol.packed_step(G, s69, r))

@@ -15,10 +15,15 @@ typedef unsigned u32;
 #define XOR3(i) "v_xor3_b32 %" #i ", %" #i ", %8, %9\n"
 #define ADD(i) "v_add_u32 %" #i ", %" #i ", %8\n"
 #define CNDM(i) "v_cndmask_b32 %" #i ", %" #i ", %8, vcc\n"
+#define CNDE(i) "v_cndmask_b32_e64 %" #i ", %" #i ", %8, s[10:11]\n"
+#define ANDB(i) "v_and_b32 %" #i ", %" #i ", %8\n"
+#define LSHL(i) "v_lshlrev_b32 %" #i ", 1, %" #i "\n"
+#define MOVS(i) "v_mov_b32 %" #i ", s10\n"
 template <int OP> __global__ void k(u32 *out, int iters)
 {
 	u32 r0 = threadIdx.x, r1 = r0 * 3, r2 = r0 * 5, r3 = r0 * 7, r4 = r0 * 11, r5 = r0 * 13, r6 = r0 * 17, r7 = r0 * 19;
 	u32 x = blockIdx.x * 2654435761u + threadIdx.x, y = threadIdx.x * 7u + 1;
+	asm volatile("s_mov_b64 s[10:11], 0x5555\ns_mov_b64 vcc, 0x3333" ::: "s10", "s11", "vcc");
 	for (int it = 0; it < iters; it++)
 	{
 #pragma unroll
@@ -32,6 +37,10 @@ template <int OP> __global__ void k(u32 *out, int iters)
 			if (OP == 5) { CHAIN8(BFI) }
 			if (OP == 7) { CHAIN8(ADD) }
 			if (OP == 8) { CHAIN8(CNDM) }
+			if (OP == 9) { CHAIN8(CNDE) }
+			if (OP == 10) { CHAIN8(ANDB) }
+			if (OP == 11) { CHAIN8(LSHL) }
+			if (OP == 12) { CHAIN8(MOVS) }
 		}
 	}
 	out[blockIdx.x * blockDim.x + threadIdx.x] = r0 ^ r1 ^ r2 ^ r3 ^ r4 ^ r5 ^ r6 ^ r7;
@@ -61,7 +70,7 @@ int main()
 	for (int w : {1, 2, 4})
 	{
 		run<0>("bitop3 xor3", w); run<1>("bitop3 maj", w); run<2>("alignbit", w); run<3>("xor", w); run<4>("and_or", w);
-		run<5>("bfi", w); run<7>("add_u32", w); run<8>("cndmask", w);
+		run<5>("bfi", w); run<7>("add_u32", w); run<8>("cndmask vcc", w); run<9>("cndmask e64", w); run<10>("and", w); run<11>("lshlrev", w); run<12>("mov sgpr", w);
 	}
 	return 0;
 }

@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--render-size", default="1920x1080")
     ap.add_argument("--render-spp", type=int, default=4)
     ap.add_argument("--render-frames", type=int, default=10)
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="gloo = rehearsal transport through host memory")
+    ap.add_argument("--device-map", default="", help="comma list: GPU index per rank (default: LOCAL_RANK)")
     ap.add_argument("--check", action="store_true", help="verify the final state against the oracle (small grids)")
     return ap.parse_args()
 
@@ -149,10 +151,15 @@ def main():
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         raise SystemExit(f"--gpus {a.gpus} does not match WORLD_SIZE {world}")
+    if a.device_map:
+        local_rank = int(a.device_map.split(",")[rank])
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     G = a.grid or (512 if world == 1 else 1024)
     rule_kw = RULES[a.rule]
@@ -175,7 +182,7 @@ def main():
         run = eng.step
         core = eng
     else:
-        se = slab.SlabEngine(G, rank, world, ghost=a.ghost, device=local_rank)
+        se = slab.SlabEngine(G, rank, world, ghost=a.ghost, device=local_rank, host_staging=a.backend == "gloo")
         se.engine.set_rules(*offs, s, b)
         se.engine.upload_state(full[se.z0 * pw:(se.z0 + se.nz) * pw])
         run = se.run
@@ -189,7 +196,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if a.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -209,6 +216,10 @@ def main():
         got = core.read_state()
         lo = 0 if world == 1 else se.z0 * pw
         ok = bool(np.array_equal(got, want[lo:lo + got.size]))
+        if world > 1:
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda" if a.backend == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = bool(flag.item())
 
     if rank == 0:
         # dominant kernel: HIP events on the engine's stream around the last step batch (get_stats), divided by the

@@ -886,7 +886,8 @@ hipError_t launch_class(const PackedLaunch &l, hipStream_t stream)
 	const bool deep = (size_t)g.tiles_per_plane * ((planes + ZRUN - 1u) / ZRUN) >= 1024u;
 	const bool fast = rules_fit_fast_fwd(*l.rules);
 	const dim3 grid_deep(g.tiles_per_plane * ((planes + ZRUN - 1u) / ZRUN)), grid_flat(g.tiles_per_plane * planes);
-	if (deep && fast) hipLaunchKernelGGL((ca_packed_class<MAIN, E, C_, ZRUN, true>), grid_deep, dim3(256), 0, stream, l.in, l.out, l.pr, g, l.rules->prog);
+	static const size_t cap_lds = [] { const char *e = getenv("CA3D_CLASS_LDS_KB"); return e ? (size_t)atoi(e) * 1024u : 0u; }();
+	if (deep && fast) hipLaunchKernelGGL((ca_packed_class<MAIN, E, C_, ZRUN, true>), grid_deep, dim3(256), cap_lds, stream, l.in, l.out, l.pr, g, l.rules->prog);
 	else if (deep) hipLaunchKernelGGL((ca_packed_class<MAIN, E, C_, ZRUN, false>), grid_deep, dim3(256), 0, stream, l.in, l.out, l.pr, g, l.rules->prog);
 	else if (fast) hipLaunchKernelGGL((ca_packed_class<MAIN, E, C_, 1, true>), grid_flat, dim3(256), 0, stream, l.in, l.out, l.pr, g, l.rules->prog);
 	else hipLaunchKernelGGL((ca_packed_class<MAIN, E, C_, 1, false>), grid_flat, dim3(256), 0, stream, l.in, l.out, l.pr, g, l.rules->prog);

@@ -63,13 +63,24 @@ def halo_plan(rank: int, world: int, layout: int = LAYOUT_PACKED32) -> HaloPlan:
     )
 
 
-def exchange_halos(regions: Dict[str, "object"], plan: HaloPlan, rank: int, group=None) -> None:
+def exchange_halos(regions: Dict[str, "object"], plan: HaloPlan, rank: int, group=None, host_staging: bool = False) -> None:
     """Refresh the ghost planes. `regions` maps 'send_low', 'send_high', 'recv_low', 'recv_high' to torch tensors
     (views of the current state buffer). Sends are posted low-then-high and receives high-then-low so that the
     two messages a pair of ranks may exchange in one direction (world == 2) match in order under RCCL, which
     ignores tags; gloo uses the tags."""
     import torch.distributed as dist
 
+    if host_staging:
+        # Transport without device-to-device support (gloo): bounce the planes through host memory. Test /
+        # rehearsal path only; RCCL moves the device buffers directly.
+        staged = {k: v.cpu() for k, v in regions.items() if k.startswith("send")}
+        staged.update({k: regions[k].new_empty(regions[k].shape, device="cpu") for k in ("recv_low", "recv_high")})
+        exchange_halos(staged, plan, rank, group, host_staging=False)
+        if plan.recv_high_from is not None:
+            regions["recv_high"].copy_(staged["recv_high"])
+        if plan.recv_low_from is not None:
+            regions["recv_low"].copy_(staged["recv_low"])
+        return
     ops: List = []
     if plan.send_low_to is not None:
         if plan.send_low_to == rank:
@@ -111,7 +122,7 @@ class SlabEngine:
     """
 
     def __init__(self, grid_size: int, rank: int, world: int, ghost: int, layout: int = LAYOUT_PACKED32,
-                 device: int = 0, group=None, engine=None):
+                 device: int = 0, group=None, engine=None, host_staging: bool = False):
         import torch
 
         from .engine import Engine
@@ -121,6 +132,7 @@ class SlabEngine:
         self.z0, self.nz = slab_bounds(grid_size, world, rank)
         self.plan = halo_plan(rank, world, layout)
         self.device = device
+        self.host_staging = host_staging
         torch.cuda.set_device(device)
         self.engine = engine or Engine(device)
         self.engine.configure_slab(grid_size, self.z0, self.nz, ghost, layout)
@@ -136,7 +148,7 @@ class SlabEngine:
         return self._regions[parity]
 
     def exchange(self) -> None:
-        exchange_halos(self._current_regions(), self.plan, self.rank, self.group)
+        exchange_halos(self._current_regions(), self.plan, self.rank, self.group, self.host_staging)
 
     def run(self, n_steps: int) -> None:
         """n CA steps: [exchange ghosts, up to `ghost` sub-steps] repeated. Asynchronous on the GPU."""

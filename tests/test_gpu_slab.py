@@ -98,3 +98,28 @@ def test_slab_step_limits():
             e.step(1)
     finally:
         e.close()
+
+
+def test_bench_two_ranks_on_one_gpu_gloo_rehearsal():
+    """bench.py's N > 1 path end to end with two processes sharing GPU 0 and gloo as a stand-in transport:
+    slab engines, product halo plan, exchange every `ghost` steps, final state checked against the oracle."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "21", "--warmup", "5",
+           "--grid", "256", "--ghost", "4", "--backend", "gloo", "--device-map", "0,0", "--check", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["oracle_match"] is True and d["scaling"] == "strong"
+    assert d["roofline"]["kernel"].startswith("ca_packed_class")

@@ -270,23 +270,25 @@ int ca3d_create(int device, ca3d_t **out)
 		return fail(CA3D_ERR_DEVICE, "no HIP device available (%s); this engine has no CPU fallback",
 		            e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
 	if (device < 0 || device >= n) return fail(CA3D_ERR_INVALID_ARGUMENT, "device %d out of range [0,%d)", device, n);
-	ca3d_engine *h = new (std::nothrow) ca3d_engine();
-	if (!h) return fail(CA3D_ERR_OUT_OF_MEMORY, "out of host memory");
-	h->device = device;
 	HIP_TRY(hipSetDevice(device));
 	hipDeviceProp_t prop;
 	HIP_TRY(hipGetDeviceProperties(&prop, device));
 	if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-	{
-		delete h;
 		return fail(CA3D_ERR_UNSUPPORTED, "device %d is %s; this library carries gfx950 (MI355X) code objects only", device, prop.gcnArchName);
+	ca3d_engine *h = new (std::nothrow) ca3d_engine();
+	if (!h) return fail(CA3D_ERR_OUT_OF_MEMORY, "out of host memory");
+	h->device = device;
+	hipError_t err = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
+	if (err == hipSuccess) err = hipEventCreate(&h->ev_start);
+	if (err == hipSuccess) err = hipEventCreate(&h->ev_stop);
+	if (err == hipSuccess) err = hipEventCreate(&h->rev_start);
+	if (err == hipSuccess) err = hipEventCreate(&h->rev_stop);
+	if (err != hipSuccess)
+	{
+		ca3d_destroy(h); // releases whatever was created
+		return fail(CA3D_ERR_DEVICE, "engine set-up failed: %s", hipGetErrorString(err));
 	}
-	HIP_TRY(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
 	h->stream = h->own_stream;
-	HIP_TRY(hipEventCreate(&h->ev_start));
-	HIP_TRY(hipEventCreate(&h->ev_stop));
-	HIP_TRY(hipEventCreate(&h->rev_start));
-	HIP_TRY(hipEventCreate(&h->rev_stop));
 	*out = h;
 	return CA3D_OK;
 }
@@ -295,7 +297,7 @@ int ca3d_destroy(ca3d_t *h)
 {
 	if (!h) return CA3D_OK;
 	hipSetDevice(h->device);
-	hipStreamSynchronize(h->stream);
+	if (h->stream || h->own_stream) hipStreamSynchronize(h->stream);
 	free_buffers(h);
 	free_render_targets(h);
 	if (h->r_counters) hipFree(h->r_counters);

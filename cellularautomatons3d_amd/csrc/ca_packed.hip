@@ -211,12 +211,11 @@ __device__ __forceinline__ u32 cube_fast(const FastProg<NP> &f, int c, const u32
 }
 
 template <int W, int NP, int NPA>
-__device__ __forceinline__ void eval_fast4(const FastProg<NP> &f, const u32 (&p)[W][NPA], u32 (&acc)[W])
+__device__ __forceinline__ void eval_fast4(const FastProg<NP> &f, const u32 (&p)[W][NPA], u32 (&acc)[W], u32 &constant)
 {
 	if (NP == 0 || f.n == 0)
 	{
-#pragma unroll
-		for (int w = 0; w < W; w++) acc[w] |= f.invert;
+		constant |= f.invert; // a program without cubes is the constant `invert`: fold it into one scalar
 		return;
 	}
 	u32 r[W];
@@ -275,12 +274,23 @@ template <int W, int MAIN, bool E, bool C_, int NP>
 __device__ __forceinline__ void apply_rules(const FastRules<MAIN, E, C_> &f, const u32 (&mn)[W][NP], const u32 (&ed)[W][4],
                                             const u32 (&co)[W][4], u32 (&S)[W], u32 (&B)[W])
 {
-	eval_fast4<W, NP>(f.ms, mn, S);
-	eval_fast4<W, NP>(f.mb, mn, B);
-	eval_fast4<W, (E ? 4 : 0)>(f.es, ed, S);
-	eval_fast4<W, (E ? 4 : 0)>(f.eb, ed, B);
-	eval_fast4<W, (C_ ? 4 : 0)>(f.cs, co, S);
-	eval_fast4<W, (C_ ? 4 : 0)>(f.cb, co, B);
+	u32 sc = 0, bc = 0;
+	eval_fast4<W, NP>(f.ms, mn, S, sc);
+	eval_fast4<W, NP>(f.mb, mn, B, bc);
+	eval_fast4<W, (E ? 4 : 0)>(f.es, ed, S, sc);
+	eval_fast4<W, (E ? 4 : 0)>(f.eb, ed, B, bc);
+	eval_fast4<W, (C_ ? 4 : 0)>(f.cs, co, S, sc);
+	eval_fast4<W, (C_ ? 4 : 0)>(f.cb, co, B, bc);
+#pragma unroll
+	for (int w = 0; w < W; w++) { S[w] |= sc; B[w] |= bc; }
+}
+
+// Host side: can every program of these rules be expanded into registers (<= kFastCubes cubes)?
+bool rules_fit_fast(const CanonRules &r)
+{
+	for (int s2 = 0; s2 < 3; s2++)
+		if (r.prog.set[s2].born.n > (u32)kFastCubes || r.prog.set[s2].survive.n > (u32)kFastCubes) return false;
+	return true;
 }
 
 // ---- plane / row addressing for the generic kernel -------------------------------------------------------
@@ -784,14 +794,6 @@ bool fused_geometry(uint32_t G, FusedGeom *g, int *words_per_lane)
 	return true;
 }
 
-bool rules_fit_fast(const CanonRules &r)
-{
-	for (int s2 = 0; s2 < 3; s2++)
-		if (r.prog.set[s2].born.n > (u32)kFastCubes || r.prog.set[s2].survive.n > (u32)kFastCubes) return false;
-	return true;
-}
-
-bool rules_fit_fast_fwd(const CanonRules &r) { return rules_fit_fast(r); }
 
 template <int MAIN, bool E, bool C_, int W>
 hipError_t launch_fused_w(const PackedLaunch &l, hipStream_t stream, FusedGeom g)
@@ -863,8 +865,6 @@ __global__ __launch_bounds__(256) void ca_packed_generic(const u32 *__restrict__
 	out[((size_t)j * pr.G + y) * C + cx] = next_state(self, S, B);
 }
 
-bool rules_fit_fast_fwd(const CanonRules &r);
-
 template <int MAIN, bool E, bool C_>
 hipError_t launch_class(const PackedLaunch &l, hipStream_t stream)
 {
@@ -891,10 +891,9 @@ hipError_t launch_class(const PackedLaunch &l, hipStream_t stream)
 	constexpr bool kDiagonals = E || C_ || MAIN == MAIN_MOORE || MAIN == MAIN_EDGES || MAIN == MAIN_CORNERS;
 	constexpr int ZRUN = kDiagonals ? 4 : 2;
 	const bool deep = (size_t)g.tiles_per_plane * ((planes + ZRUN - 1u) / ZRUN) >= 1024u;
-	const bool fast = rules_fit_fast_fwd(*l.rules);
+	const bool fast = rules_fit_fast(*l.rules);
 	const dim3 grid_deep(g.tiles_per_plane * ((planes + ZRUN - 1u) / ZRUN)), grid_flat(g.tiles_per_plane * planes);
-	static const size_t cap_lds = [] { const char *e = getenv("CA3D_CLASS_LDS_KB"); return e ? (size_t)atoi(e) * 1024u : 0u; }();
-	if (deep && fast) hipLaunchKernelGGL((ca_packed_class<MAIN, E, C_, ZRUN, true>), grid_deep, dim3(256), cap_lds, stream, l.in, l.out, l.pr, g, l.rules->prog);
+	if (deep && fast) hipLaunchKernelGGL((ca_packed_class<MAIN, E, C_, ZRUN, true>), grid_deep, dim3(256), 0, stream, l.in, l.out, l.pr, g, l.rules->prog);
 	else if (deep) hipLaunchKernelGGL((ca_packed_class<MAIN, E, C_, ZRUN, false>), grid_deep, dim3(256), 0, stream, l.in, l.out, l.pr, g, l.rules->prog);
 	else if (fast) hipLaunchKernelGGL((ca_packed_class<MAIN, E, C_, 1, true>), grid_flat, dim3(256), 0, stream, l.in, l.out, l.pr, g, l.rules->prog);
 	else hipLaunchKernelGGL((ca_packed_class<MAIN, E, C_, 1, false>), grid_flat, dim3(256), 0, stream, l.in, l.out, l.pr, g, l.rules->prog);

@@ -109,8 +109,6 @@ void compile_rule_prog(uint32_t onset_mask, uint32_t max_count, RuleProg *out)
 	// A 5-variable function needs at most 16 cubes (parity), so the clamp above never drops one.
 }
 
-static const int32_t kVN[] = {1, 0, 0, -1, 0, 0, 0, 1, 0, 0, -1, 0, 0, 0, 1, 0, 0, -1};
-
 static uint32_t class_set(MainKind k)
 {
 	// 27-bit set over codes c = (dx+1) + 3*(dy+1) + 9*(dz+1)
@@ -140,7 +138,6 @@ int canonicalize_rules(const int32_t *main_offs, uint32_t n_main, const int32_t 
                        const int32_t *corner_offs, uint32_t n_corner, const uint32_t *survive,
                        const uint32_t *born, CanonRules *out, std::string *err)
 {
-	(void)kVN;
 	const int32_t *lists[3] = {main_offs, edge_offs, corner_offs};
 	const uint32_t ns[3] = {n_main, n_edge, n_corner};
 	static const char *names[3] = {"main", "edges", "corners"};

@@ -99,6 +99,18 @@ class Engine:
         _capi.check(self._lib.ca3d_read_state(self._h, out.ctypes.data_as(_u32p), out.size))
         return out
 
+    def save_checkpoint(self, path) -> None:
+        i = self.info()
+        host.save_checkpoint(path, self.read_state(), i.grid_size, i.step, i.layout)
+
+    def load_checkpoint(self, path) -> int:
+        """Configure for the checkpoint's grid, upload its state; returns the step it was taken at (the engine's own
+        counter restarts at 0, like after any upload)."""
+        words, grid_size, step, layout = host.load_checkpoint(path)
+        self.configure(grid_size, layout)
+        self.upload_state(words)
+        return step
+
     # -- stepping -------------------------------------------------------------------------------------------
     def step(self, n_steps: int = 1) -> None:
         _capi.check(self._lib.ca3d_step(self._h, n_steps))

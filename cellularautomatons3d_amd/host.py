@@ -309,3 +309,41 @@ def uniform_block(width: int, height: int, view_mat: Optional[np.ndarray] = None
     u[I["baseReflectivity"]:I["baseReflectivity"] + 3] = p["baseReflectivity"]
     u[I["materialColor"]:I["materialColor"] + 3] = p["materialColor"]
     return u
+
+
+# --------------------------------------------------------------------------------------------- checkpoints
+# The reference keeps its state only in GPU buffers and never reads it back; the engine's
+# read_state / upload_state on the raw little-endian words IS the checkpoint payload. The file adds a header.
+
+CHECKPOINT_MAGIC = b"CA3D"
+CHECKPOINT_VERSION = 1
+
+
+def save_checkpoint(path, words: np.ndarray, grid_size: int, step: int = 0, layout: int = 0) -> None:
+    """magic 'CA3D' | u32 version | u32 grid size | u32 layout | u64 step | u64 word count | LE u32 words."""
+    import struct
+
+    w = np.ascontiguousarray(words, dtype="<u4")
+    with open(path, "wb") as f:
+        f.write(CHECKPOINT_MAGIC + struct.pack("<IIIQQ", CHECKPOINT_VERSION, grid_size, layout, step, w.size))
+        f.write(w.tobytes())
+
+
+def load_checkpoint(path):
+    """-> (words, grid_size, step, layout); raises ValueError on a malformed file."""
+    import struct
+
+    with open(path, "rb") as f:
+        head = f.read(4 + 28)
+        if len(head) != 32 or head[:4] != CHECKPOINT_MAGIC:
+            raise ValueError("not a CA3D checkpoint")
+        version, grid_size, layout, step, n = struct.unpack("<IIIQQ", head[4:])
+        if version != CHECKPOINT_VERSION:
+            raise ValueError(f"unsupported checkpoint version {version}")
+        expect = (grid_size // 32) * grid_size * grid_size if layout == 0 else grid_size ** 3
+        if n != expect:
+            raise ValueError("word count does not match the grid size")
+        words = np.frombuffer(f.read(n * 4), dtype="<u4")
+        if words.size != n:
+            raise ValueError("truncated checkpoint")
+    return words.astype(np.uint32), grid_size, step, layout

@@ -135,6 +135,29 @@ function randomFill(nWords, seed, andRounds)
 	return out;
 }
 
+// Checkpoint file: 'CA3D' | u32 version | u32 grid | u32 layout | u64 step | u64 words | LE u32 words (host.py twin)
+function saveCheckpoint(file, words, gridSize, step, layout)
+{
+	const fs = require("fs");
+	const head = Buffer.alloc(32);
+	head.write("CA3D", 0, "latin1");
+	head.writeUInt32LE(1, 4); head.writeUInt32LE(gridSize, 8); head.writeUInt32LE(layout || 0, 12);
+	head.writeBigUInt64LE(BigInt(step || 0), 16); head.writeBigUInt64LE(BigInt(words.length), 24);
+	fs.writeFileSync(file, Buffer.concat([head, Buffer.from(words.buffer, words.byteOffset, words.byteLength)]));
+}
+
+function loadCheckpoint(file)
+{
+	const fs = require("fs");
+	const b = fs.readFileSync(file);
+	if (b.length < 32 || b.toString("latin1", 0, 4) !== "CA3D" || b.readUInt32LE(4) !== 1) { throw new Error("not a CA3D checkpoint"); }
+	const gridSize = b.readUInt32LE(8), layout = b.readUInt32LE(12), step = Number(b.readBigUInt64LE(16)), n = Number(b.readBigUInt64LE(24));
+	if (b.length !== 32 + 4 * n) { throw new Error("truncated checkpoint"); }
+	const words = new Uint32Array(n);
+	Buffer.from(words.buffer).set(b.subarray(32));
+	return { words, gridSize, layout, step };
+}
+
 let addon = null;
 function loadAddon()
 {
@@ -206,5 +229,5 @@ class Engine
 module.exports = {
 	Engine, NEIGHBOURHOOD_MAP, DEFAULT_RULES, LAYOUT_PACKED32, LAYOUT_UNPACKED, NEIGHBOURS_STORAGE_LEN,
 	rulesComponentsToValues, recalculateRulesValues, gridSizeUIFormatter, getClusterIdxFromGridCoordinates,
-	initialState, dispatchShape, randomFill, loadAddon
+	initialState, dispatchShape, randomFill, loadAddon, saveCheckpoint, loadCheckpoint
 };

@@ -323,3 +323,20 @@ def test_fused_keeps_previous_state_in_other_buffer(eng):
     rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     assert rt.hipMemcpy(other.data_ptr(), p, n, 3) == 0
     np.testing.assert_array_equal(other.cpu().numpy().view(np.uint32), s69)
+
+
+def test_checkpoint_resume(eng, tmp_path):
+    G = 128
+    r = rules("clustered")
+    eng.configure(G)
+    set_rules(eng, r)
+    st = host.random_fill(host.words_per_buffer(G), seed=41, and_rounds=1)
+    eng.upload_state(st)
+    eng.step(4)
+    eng.save_checkpoint(tmp_path / "s4.ca3d")
+    eng.step(6)
+    want = eng.read_state()
+    assert eng.load_checkpoint(tmp_path / "s4.ca3d") == 4
+    set_rules(eng, r)
+    eng.step(6)
+    np.testing.assert_array_equal(eng.read_state(), want)

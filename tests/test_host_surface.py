@@ -91,3 +91,29 @@ def test_bind_group_wiring(golden):
 def test_bad_grid():
     with pytest.raises(ValueError):
         host.words_per_buffer(48)
+
+
+def test_checkpoint_roundtrip_python_and_js(tmp_path):
+    import shutil
+    import subprocess
+
+    w = host.random_fill(host.words_per_buffer(64), seed=3)
+    p = tmp_path / "a.ca3d"
+    host.save_checkpoint(p, w, 64, step=123)
+    w2, G, step, layout = host.load_checkpoint(p)
+    np.testing.assert_array_equal(w, w2)
+    assert (G, step, layout) == (64, 123, 0)
+    (tmp_path / "bad").write_bytes(b"nope")
+    with pytest.raises(ValueError):
+        host.load_checkpoint(tmp_path / "bad")
+    node = shutil.which("node")
+    if node:
+        q = tmp_path / "b.ca3d"
+        js = ("const c=require('./cellularautomatons3d_amd/js/ca3d.js');const k=c.loadCheckpoint(process.argv[1]);"
+              "c.saveCheckpoint(process.argv[2],k.words,k.gridSize,k.step+1,k.layout);")
+        import os
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        subprocess.run([node, "-e", js, str(p), str(q)], cwd=root, check=True)
+        w3, G3, step3, _ = host.load_checkpoint(q)
+        np.testing.assert_array_equal(w, w3)
+        assert (G3, step3) == (64, 124)

@@ -54,6 +54,7 @@ struct ca3d_engine
 	size_t plane_words = 0; // u32 per z-plane
 	uint32_t *buf[2] = {nullptr, nullptr};
 	bool has_state = false;
+	bool binary_state = false; // unpacked layout: every cell is 0 or 1 (checked on upload, true after any step)
 	uint64_t step = 0;
 	uint32_t cur = 0; // physical buffer holding the current state (== step % 2 whenever control returns to the caller)
 
@@ -169,8 +170,9 @@ int enqueue_step(ca3d_engine *h, int src, uint32_t lo, uint32_t hi, hipStream_t 
 	}
 	else
 	{
-		UnpackedLaunch l{h->buf[src], h->buf[src ^ 1], pr, &h->rules};
+		UnpackedLaunch l{h->buf[src], h->buf[src ^ 1], pr, &h->rules, h->binary_state && h->variant == 0};
 		e = launch_unpacked_step(l, s, &h->kernel_name);
+		h->binary_state = true; // the kernel writes only 0 / 1 (compute.wgsl:160-174)
 	}
 	if (e != hipSuccess) return fail(CA3D_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(e));
 	return CA3D_OK;
@@ -396,6 +398,13 @@ int ca3d_upload_state(ca3d_t *h, const uint32_t *words, size_t n_words)
 	h->step = 0;
 	h->cur = 0;
 	h->has_state = true;
+	h->binary_state = false;
+	if (h->layout == CA3D_LAYOUT_UNPACKED)
+	{
+		bool bin = true;
+		for (size_t i = 0; i < n_words && bin; i++) bin = words[i] <= 1u;
+		h->binary_state = bin;
+	}
 	return CA3D_OK;
 }
 
@@ -571,7 +580,8 @@ int ca3d_get_info(ca3d_t *h, ca3d_info *out)
 	out->device = h->device;
 	const char *name = "";
 	if (h->configured && h->rules.valid)
-		name = h->layout == CA3D_LAYOUT_PACKED32 ? packed_kernel_name(h->rules, h->G, h->variant) : "ca_unpacked_literal";
+		name = h->layout == CA3D_LAYOUT_PACKED32 ? packed_kernel_name(h->rules, h->G, h->variant)
+		                                          : (h->step > 0 && h->kernel_name[0] ? h->kernel_name : "ca_unpacked");
 	snprintf(out->kernel_name, sizeof out->kernel_name, "%s", name);
 	return CA3D_OK;
 }

@@ -66,6 +66,8 @@ struct CanonRules
 	PackedRuleArgs prog{};
 	// unpacked layout: main list + slots 0..26 with `> 0`
 	uint32_t unpacked_survive = 0, unpacked_born = 0; // bit k = LUT[k] > 0
+	RuleSetProg unpacked_prog{};                        // the same as cube programs over the main list's count
+	bool unpacked_fast = false;                         // main list is a named class union (ballot kernel applies)
 	// raw copies (returned for diagnostics)
 	uint32_t survive_raw[CA3D_LUT_LEN]{}, born_raw[CA3D_LUT_LEN]{};
 };
@@ -105,6 +107,7 @@ struct UnpackedLaunch
 	uint32_t *out;
 	PlaneRange pr;
 	const CanonRules *rules;
+	bool binary_state; // every cell is 0 or 1 (true after any step; checked on upload)
 };
 
 struct RenderLaunch

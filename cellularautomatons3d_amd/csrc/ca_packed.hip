@@ -22,469 +22,7 @@ namespace ca3d
 namespace
 {
 
-using u32 = uint32_t;
-
-constexpr u32 TA = 0xF0, TB = 0xCC, TC = 0xAA; // truth-table columns of the three v_bitop3 inputs
-
-template <u32 IMM>
-__device__ __forceinline__ u32 bitop3(u32 a, u32 b, u32 c)
-{
-	return __builtin_amdgcn_bitop3_b32(a, b, c, IMM);
-}
-__device__ __forceinline__ u32 xor3(u32 a, u32 b, u32 c) { return bitop3<(TA ^ TB ^ TC)>(a, b, c); }
-__device__ __forceinline__ u32 maj3(u32 a, u32 b, u32 c) { return bitop3<((TA & TB) | (TA & TC) | (TB & TC))>(a, b, c); }
-// bit i of the result = bit i-1 of the row (neighbour at x-1): (w << 1) | (lower >> 31)
-__device__ __forceinline__ u32 from_left(u32 w, u32 lower) { return __builtin_amdgcn_alignbit(w, lower, 31); }
-// bit i of the result = bit i+1 of the row (neighbour at x+1): (w >> 1) | (upper << 31)
-__device__ __forceinline__ u32 from_right(u32 upper, u32 w) { return __builtin_amdgcn_alignbit(upper, w, 1); }
-
-__device__ __forceinline__ void fa(u32 a, u32 b, u32 c, u32 &s, u32 &k) { s = xor3(a, b, c); k = maj3(a, b, c); }
-__device__ __forceinline__ void ha(u32 a, u32 b, u32 &s, u32 &k) { s = a ^ b; k = a & b; }
-
-// ---- sums of 1-bit planes (carry-save trees) -------------------------------------------------------------
-__device__ __forceinline__ void sum4(u32 a, u32 b, u32 c, u32 d, u32 (&p)[3])
-{
-	u32 s, k, k2;
-	fa(a, b, c, s, k);
-	ha(s, d, p[0], k2);
-	ha(k, k2, p[1], p[2]);
-}
-
-__device__ __forceinline__ void sum6(u32 a, u32 b, u32 c, u32 d, u32 e, u32 f, u32 (&p)[3])
-{
-	u32 s0, k0, s1, k1, c0;
-	fa(a, b, c, s0, k0);
-	fa(d, e, f, s1, k1);
-	ha(s0, s1, p[0], c0);
-	fa(k0, k1, c0, p[1], p[2]);
-}
-
-__device__ __forceinline__ void sum8(const u32 (&x)[8], u32 (&p)[4])
-{
-	u32 s0, k0, s1, k1, s2, k2, k3, t, u, v;
-	fa(x[0], x[1], x[2], s0, k0);
-	fa(x[3], x[4], x[5], s1, k1);
-	ha(x[6], x[7], s2, k2);
-	fa(s0, s1, s2, p[0], k3);
-	fa(k0, k1, k2, t, u);
-	ha(t, k3, p[1], v);
-	ha(u, v, p[2], p[3]);
-}
-
-__device__ __forceinline__ void sum12(const u32 (&x)[12], u32 (&p)[4])
-{
-	u32 s0, s1, s2, s3, k0, k1, k2, k3, t, u, v, a, b, c, d, e;
-	fa(x[0], x[1], x[2], s0, k0);
-	fa(x[3], x[4], x[5], s1, k1);
-	fa(x[6], x[7], x[8], s2, k2);
-	fa(x[9], x[10], x[11], s3, k3);
-	fa(s0, s1, s2, t, u);
-	ha(t, s3, p[0], v);
-	fa(k0, k1, k2, a, b);
-	fa(k3, u, v, c, d);
-	ha(a, c, p[1], e);
-	fa(b, d, e, p[2], p[3]);
-}
-
-// vn (0..6, 3 planes) + corners (0..8, 4 planes) + edges (0..12, 4 planes) -> 0..26, 5 planes
-__device__ __forceinline__ void sum_moore(const u32 (&vn)[3], const u32 (&ed)[4], const u32 (&co)[4], u32 (&p)[5])
-{
-	u32 q0, q1, q2, q3, c;
-	ha(vn[0], co[0], q0, c);
-	fa(vn[1], co[1], c, q1, c);
-	fa(vn[2], co[2], c, q2, c);
-	q3 = co[3] ^ c; // <= 14: no carry out of plane 3
-	ha(q0, ed[0], p[0], c);
-	fa(q1, ed[1], c, p[1], c);
-	fa(q2, ed[2], c, p[2], c);
-	fa(q3, ed[3], c, p[3], p[4]);
-}
-
-// ---- rule program interpreter ----------------------------------------------------------------------------
-// OR over cubes of AND over cared planes of (plane == required value); wave-uniform control flow only.
-template <int NP>
-__device__ __forceinline__ u32 eval_prog(const RuleProg &pr, const u32 *p)
-{
-	u32 acc = 0;
-	for (u32 c = 0; c < pr.n; c++)
-	{
-		const u32 cube = pr.cubes[c];
-		u32 e = 0xFFFFFFFFu;
-#pragma unroll
-		for (int i = 0; i < NP; i++)
-		{
-			if (cube & (1u << i))
-			{
-				const u32 inv = (cube & (0x100u << i)) ? 0u : 0xFFFFFFFFu;
-				e = bitop3<(TA & (TB ^ TC))>(e, p[i], inv);
-			}
-		}
-		acc |= e;
-	}
-	return acc ^ pr.invert;
-}
-
-// Same for the W words a thread owns: the cube is fetched and decoded once (scalar work) per W words. Literal i is
-// (plane_i & a_i) ^ b_i with wave-uniform masks — pure mask arithmetic, no per-lane selects (v_cndmask is an
-// order of magnitude slower than v_bitop3 on gfx950: tools/ubench/valu_rate.hip).
-template <int W, int NP, int NPA>
-__device__ __forceinline__ void eval_prog4(const RuleProg &pr, const u32 (&p)[W][NPA], u32 (&acc)[W])
-{
-	u32 r[W];
-#pragma unroll
-	for (int w = 0; w < W; w++) r[w] = 0;
-	for (u32 c = 0; c < pr.n; c++)
-	{
-		const u32 cube = pr.cubes[c];
-		u32 e[W];
-#pragma unroll
-		for (int w = 0; w < W; w++) e[w] = 0xFFFFFFFFu;
-#pragma unroll
-		for (int i = 0; i < NP; i++)
-		{
-			const u32 care = 0u - ((cube >> i) & 1u);                 // ~0 when the plane matters
-			const u32 flip = (0u - ((cube >> (8 + i)) & 1u)) & care;  // ~0 when it must be set
-			const u32 bmask = ~flip;                                  // set: 0, clear: ~0, don't care: ~0
-#pragma unroll
-			for (int w = 0; w < W; w++) e[w] &= bitop3<((TA & TB) ^ TC)>(p[w][i], care, bmask);
-		}
-#pragma unroll
-		for (int w = 0; w < W; w++) r[w] |= e[w];
-	}
-#pragma unroll
-	for (int w = 0; w < W; w++) acc[w] |= r[w] ^ pr.invert;
-}
-
-__device__ __forceinline__ u32 next_state(u32 alive, u32 S, u32 B)
-{
-	return bitop3<((TA & TB) | (~TA & TC)) & 0xFF>(alive, S, B); // alive ? survive : born
-}
-
-// ---- register-resident rule programs ----------------------------------------------------------------------
-// The interpreter above decodes every cube with scalar instructions each time it runs; inside the kernels that
-// becomes the bottleneck (the CU's single scalar unit). Programs of at most kFastCubes cubes — every rule the
-// reference UI produces in practice — are instead expanded ONCE per wave into mask pairs: literal i of a cube is
-// (plane_i & a_i) ^ b_i with (a, b) = (~0, 0) for "plane set", (~0, ~0) for "plane clear", (0, ~0) for "don't
-// care", so a cube is NP bitop3 + one AND-reduction and nothing is decoded in the loops.
-constexpr int kFastCubes = 2;
-
-template <int NP>
-struct FastProg
-{
-	u32 n, invert;
-	u32 a[kFastCubes][NP > 0 ? NP : 1], b[kFastCubes][NP > 0 ? NP : 1];
-};
-
-template <int NP>
-__device__ __forceinline__ FastProg<NP> expand_prog(const RuleProg &pr)
-{
-	FastProg<NP> f;
-	f.n = pr.n;
-	f.invert = pr.invert;
-#pragma unroll
-	for (int c = 0; c < kFastCubes; c++)
-	{
-		const u32 cube = pr.cubes[c];
-#pragma unroll
-		for (int i = 0; i < NP; i++)
-		{
-			const bool care = (cube >> i) & 1u, val = (cube >> (8 + i)) & 1u;
-			f.a[c][i] = care ? 0xFFFFFFFFu : 0u;
-			f.b[c][i] = (care && val) ? 0u : 0xFFFFFFFFu;
-		}
-	}
-	return f;
-}
-
-template <int NP>
-__device__ __forceinline__ u32 cube_fast(const FastProg<NP> &f, int c, const u32 *p)
-{
-	u32 lit[NP > 0 ? NP : 1];
-#pragma unroll
-	for (int i = 0; i < NP; i++) lit[i] = bitop3<((TA & TB) ^ TC)>(p[i], f.a[c][i], f.b[c][i]);
-	if (NP == 1) return lit[0];
-	if (NP == 2) return lit[0] & lit[1];
-	u32 e = bitop3<(TA & TB & TC)>(lit[0], lit[1], lit[2]);
-	if (NP == 4) e &= lit[3];
-	if (NP == 5) e = bitop3<(TA & TB & TC)>(e, lit[3 < NP ? 3 : 0], lit[4 < NP ? 4 : 0]);
-	return e;
-}
-
-template <int W, int NP, int NPA>
-__device__ __forceinline__ void eval_fast4(const FastProg<NP> &f, const u32 (&p)[W][NPA], u32 (&acc)[W], u32 &constant)
-{
-	if (NP == 0 || f.n == 0)
-	{
-		constant |= f.invert; // a program without cubes is the constant `invert`: fold it into one scalar
-		return;
-	}
-	u32 r[W];
-#pragma unroll
-	for (int w = 0; w < W; w++) r[w] = cube_fast<NP>(f, 0, p[w]);
-	if (f.n > 1)
-	{
-#pragma unroll
-		for (int w = 0; w < W; w++) r[w] |= cube_fast<NP>(f, 1, p[w]);
-	}
-#pragma unroll
-	for (int w = 0; w < W; w++) acc[w] |= r[w] ^ f.invert;
-}
-
-template <int MAIN>
-struct MainPlanes
-{
-	static constexpr int value = (MAIN == MAIN_VN || MAIN == MAIN_VN2D) ? 3 : (MAIN == MAIN_MOORE ? 5 : 4);
-};
-
-// The six programs of a kernel instantiation, expanded into registers.
-template <int MAIN, bool E, bool C_>
-struct FastRules
-{
-	FastProg<MainPlanes<MAIN>::value> mb, ms;
-	FastProg<(E ? 4 : 0)> eb, es;
-	FastProg<(C_ ? 4 : 0)> cb, cs;
-};
-
-template <int MAIN, bool E, bool C_>
-__device__ __forceinline__ FastRules<MAIN, E, C_> expand_rules(const PackedRuleArgs &r)
-{
-	FastRules<MAIN, E, C_> f;
-	f.mb = expand_prog<MainPlanes<MAIN>::value>(r.set[0].born);
-	f.ms = expand_prog<MainPlanes<MAIN>::value>(r.set[0].survive);
-	f.eb = expand_prog<(E ? 4 : 0)>(r.set[1].born);
-	f.es = expand_prog<(E ? 4 : 0)>(r.set[1].survive);
-	f.cb = expand_prog<(C_ ? 4 : 0)>(r.set[2].born);
-	f.cs = expand_prog<(C_ ? 4 : 0)>(r.set[2].survive);
-	return f;
-}
-
-template <int W, int MAIN, bool E, bool C_, int NP>
-__device__ __forceinline__ void apply_rules(const PackedRuleArgs &rules, const u32 (&mn)[W][NP], const u32 (&ed)[W][4],
-                                            const u32 (&co)[W][4], u32 (&S)[W], u32 (&B)[W])
-{
-	eval_prog4<W, NP>(rules.set[0].survive, mn, S);
-	eval_prog4<W, NP>(rules.set[0].born, mn, B);
-	eval_prog4<W, (E ? 4 : 0)>(rules.set[1].survive, ed, S);
-	eval_prog4<W, (E ? 4 : 0)>(rules.set[1].born, ed, B);
-	eval_prog4<W, (C_ ? 4 : 0)>(rules.set[2].survive, co, S);
-	eval_prog4<W, (C_ ? 4 : 0)>(rules.set[2].born, co, B);
-}
-
-template <int W, int MAIN, bool E, bool C_, int NP>
-__device__ __forceinline__ void apply_rules(const FastRules<MAIN, E, C_> &f, const u32 (&mn)[W][NP], const u32 (&ed)[W][4],
-                                            const u32 (&co)[W][4], u32 (&S)[W], u32 (&B)[W])
-{
-	u32 sc = 0, bc = 0;
-	eval_fast4<W, NP>(f.ms, mn, S, sc);
-	eval_fast4<W, NP>(f.mb, mn, B, bc);
-	eval_fast4<W, (E ? 4 : 0)>(f.es, ed, S, sc);
-	eval_fast4<W, (E ? 4 : 0)>(f.eb, ed, B, bc);
-	eval_fast4<W, (C_ ? 4 : 0)>(f.cs, co, S, sc);
-	eval_fast4<W, (C_ ? 4 : 0)>(f.cb, co, B, bc);
-#pragma unroll
-	for (int w = 0; w < W; w++) { S[w] |= sc; B[w] |= bc; }
-}
-
-// Host side: can every program of these rules be expanded into registers (<= kFastCubes cubes)?
-bool rules_fit_fast(const CanonRules &r)
-{
-	for (int s2 = 0; s2 < 3; s2++)
-		if (r.prog.set[s2].born.n > (u32)kFastCubes || r.prog.set[s2].survive.n > (u32)kFastCubes) return false;
-	return true;
-}
-
-// ---- plane / row addressing for the generic kernel -------------------------------------------------------
-struct Nbr
-{
-	const u32 *plane[3]; // z-1, z, z+1 (dead planes point at a valid plane and carry mask 0)
-	u32 zmask[3];
-	u32 yrow[3]; // y-1, y, y+1 (clamped / wrapped)
-	u32 ymask[3];
-};
-
-__device__ __forceinline__ int global_z(const PlaneRange &pr, u32 j)
-{
-	int zg = pr.zbase + (int)j; // zbase in (-G, G), j <= G + 2*ghost: one conditional fold each way is enough
-	if (zg < 0) zg += (int)pr.G;
-	if (zg >= (int)pr.G) zg -= (int)pr.G;
-	return zg;
-}
-
-__device__ __forceinline__ Nbr neighbours(const u32 *in, const PlaneRange &pr, u32 C, u32 j, u32 y)
-{
-	Nbr n;
-	const size_t plane_words = (size_t)C * pr.G;
-	const bool below_dead = global_z(pr, j) == 0; // z-1 == -1 is dropped by the >= 0 test (compute_clustered.wgsl:104)
-	const u32 jb = below_dead ? j : j - 1;
-	const u32 ja = (pr.wrap_full && j + 1 == pr.nplanes) ? 0u : j + 1; // z == G passes `<= G` and wraps to 0
-	n.plane[0] = in + jb * plane_words;
-	n.plane[1] = in + j * plane_words;
-	n.plane[2] = in + ja * plane_words;
-	n.zmask[0] = below_dead ? 0u : 0xFFFFFFFFu;
-	n.zmask[1] = 0xFFFFFFFFu;
-	n.zmask[2] = 0xFFFFFFFFu;
-	n.yrow[0] = y == 0 ? 0u : y - 1;
-	n.yrow[1] = y;
-	n.yrow[2] = (y + 1 == pr.G) ? 0u : y + 1;
-	n.ymask[0] = y == 0 ? 0u : 0xFFFFFFFFu;
-	n.ymask[1] = 0xFFFFFFFFu;
-	n.ymask[2] = 0xFFFFFFFFu;
-	return n;
-}
-
-// ---------------------------------------------------------------------------------------------- class kernel
-// One row segment of 4 words plus the word on either side (x-1 of word 0 is dead at cx0 == 0; x+1 of the last
-// word of the row wraps to word 0 of the same row).
-template <int W>
-struct SegT
-{
-	u32 w[W];
-	u32 lo, hi;
-};
-using Seg = SegT<4>;
-
-template <int W>
-__device__ __forceinline__ u32 seg_l(const SegT<W> &s, int i) { return from_left(s.w[i], i ? s.w[i > 0 ? i - 1 : 0] : s.lo); }
-template <int W>
-__device__ __forceinline__ u32 seg_r(const SegT<W> &s, int i) { return from_right(i < W - 1 ? s.w[i < W - 1 ? i + 1 : 0] : s.hi, s.w[i]); }
-
-struct TileGeom
-{
-	u32 CV;              // uint4 per row (C / 4)
-	int cv_shift;        // log2(CV) or -1
-	u32 tiles_per_plane; // 256-thread tiles per plane
-	int tpp_shift;       // log2(tiles_per_plane) or -1
-	u32 use_shfl;        // rows sit inside one wave: edge words come from neighbour lanes
-};
-
-// Per-thread constants of the (y, cx) position.
-struct Pos
-{
-	u32 off[3];   // word offset of the segment inside a plane for rows y-1, y, y+1
-	u32 ymask[3];
-	u32 lo_rel, hi_rel; // word offset of the edge words relative to the row start (load path)
-	u32 row0[3];        // row starts
-	u32 lo_mask;        // 0 at cx0 == 0
-	int src_lo, src_hi; // source lanes (shuffle path)
-	bool shfl;
-};
-
-template <bool LR>
-__device__ __forceinline__ Seg load_seg(const u32 *plane, const Pos &ps, int r, u32 zmask)
-{
-	const u32 m = zmask & ps.ymask[r];
-	const uint4 v = *reinterpret_cast<const uint4 *>(plane + ps.off[r]);
-	Seg s;
-	s.w[0] = v.x & m;
-	s.w[1] = v.y & m;
-	s.w[2] = v.z & m;
-	s.w[3] = v.w & m;
-	s.lo = 0;
-	s.hi = 0;
-	if (LR)
-	{
-		if (ps.shfl)
-		{
-			s.lo = (u32)__shfl((int)s.w[3], ps.src_lo) & ps.lo_mask;
-			s.hi = (u32)__shfl((int)s.w[0], ps.src_hi);
-		}
-		else
-		{
-			s.lo = plane[ps.row0[r] + ps.lo_rel] & m & ps.lo_mask;
-			s.hi = plane[ps.row0[r] + ps.hi_rel] & m;
-		}
-	}
-	return s;
-}
-
-template <int W>
-struct PlaneRowsT
-{
-	SegT<W> ym, c, yp;
-};
-using PlaneRows = PlaneRowsT<4>;
-
-// New state of the W words at the centre of P1 given the planes below (P0, already masked by the caller through
-// `zmask` when z-1 is dead) and above (P2). Shared by the streaming and the fused kernels.
-template <int W, int MAIN, bool E, bool C_, typename RS>
-__device__ __forceinline__ void evolve(const PlaneRowsT<W> &P0, const PlaneRowsT<W> &P1, const PlaneRowsT<W> &P2, u32 zmask,
-                                       const RS &rules, u32 (&out)[W])
-{
-	constexpr bool kNeedEdges = E || MAIN == MAIN_MOORE || MAIN == MAIN_EDGES;
-	constexpr bool kNeedCorners = C_ || MAIN == MAIN_MOORE || MAIN == MAIN_CORNERS;
-
-	constexpr int NP = MainPlanes<MAIN>::value;
-	u32 mn[W][NP], ed[W][4], co[W][4];
-#pragma unroll
-	for (int i = 0; i < W; i++)
-	{
-		for (int k = 0; k < 4; k++) { ed[i][k] = 0; co[i][k] = 0; }
-		if (kNeedEdges)
-		{
-			const u32 x[12] = {seg_l(P1.yp, i), seg_r(P1.yp, i), seg_l(P1.ym, i), seg_r(P1.ym, i),
-			                   seg_l(P2.c, i), seg_r(P2.c, i), seg_l(P0.c, i) & zmask, seg_r(P0.c, i) & zmask,
-			                   P2.yp.w[i], P0.yp.w[i] & zmask, P2.ym.w[i], P0.ym.w[i] & zmask};
-			sum12(x, ed[i]);
-		}
-		if (kNeedCorners)
-		{
-			const u32 x[8] = {seg_l(P2.yp, i), seg_r(P2.yp, i), seg_l(P0.yp, i) & zmask, seg_r(P0.yp, i) & zmask,
-			                  seg_l(P2.ym, i), seg_r(P2.ym, i), seg_l(P0.ym, i) & zmask, seg_r(P0.ym, i) & zmask};
-			sum8(x, co[i]);
-		}
-		if (MAIN == MAIN_VN)
-		{
-			u32 p[3];
-			sum6(seg_l(P1.c, i), seg_r(P1.c, i), P1.yp.w[i], P1.ym.w[i], P2.c.w[i], P0.c.w[i] & zmask, p);
-			for (int k = 0; k < 3; k++) mn[i][k] = p[k];
-		}
-		else if (MAIN == MAIN_VN2D)
-		{
-			u32 p[3];
-			sum4(seg_l(P1.c, i), seg_r(P1.c, i), P1.yp.w[i], P1.ym.w[i], p);
-			for (int k = 0; k < 3; k++) mn[i][k] = p[k];
-		}
-		else if (MAIN == MAIN_MOORE)
-		{
-			u32 vn[3], p[5];
-			sum6(seg_l(P1.c, i), seg_r(P1.c, i), P1.yp.w[i], P1.ym.w[i], P2.c.w[i], P0.c.w[i] & zmask, vn);
-			sum_moore(vn, ed[i], co[i], p);
-			for (int k = 0; k < NP; k++) mn[i][k] = p[k];
-		}
-		else if (MAIN == MAIN_MOORE2D)
-		{
-			const u32 x[8] = {seg_l(P1.c, i), seg_r(P1.c, i), P1.yp.w[i], seg_l(P1.yp, i), seg_r(P1.yp, i),
-			                  P1.ym.w[i], seg_l(P1.ym, i), seg_r(P1.ym, i)};
-			u32 p[4];
-			sum8(x, p);
-			for (int k = 0; k < NP; k++) mn[i][k] = p[k];
-		}
-		else if (MAIN == MAIN_EDGES)
-		{
-			for (int k = 0; k < NP; k++) mn[i][k] = ed[i][k];
-		}
-		else
-		{
-			for (int k = 0; k < NP; k++) mn[i][k] = co[i][k];
-		}
-	}
-	u32 S[W], B[W];
-#pragma unroll
-	for (int i = 0; i < W; i++) { S[i] = 0; B[i] = 0; }
-	apply_rules<W, MAIN, E, C_, NP>(rules, mn, ed, co, S, B);
-#pragma unroll
-	for (int i = 0; i < W; i++) out[i] = next_state(P1.c.w[i], S[i], B[i]);
-}
-
-template <int MAIN, bool E, bool C_, typename RS>
-__device__ __forceinline__ uint4 evolve4(const PlaneRows &P0, const PlaneRows &P1, const PlaneRows &P2, u32 zmask, const RS &rules)
-{
-	u32 o[4];
-	evolve<4, MAIN, E, C_>(P0, P1, P2, zmask, rules, o);
-	uint4 r;
-	r.x = o[0]; r.y = o[1]; r.z = o[2]; r.w = o[3];
-	return r;
-}
+#include "ca_bitslice.inc"
 
 // Each thread owns one dwordx4 column position (y, cx0..cx0+3) and walks ZR consecutive z-planes with the three
 // planes it needs held in registers, so a plane's rows are fetched once per ZR outputs instead of three times.

@@ -5,6 +5,12 @@
 //
 // ca_unpacked_literal: one thread per cell, exact for ANY u32 cell values (the count is the u32 sum of raw
 // neighbour values, `state == 1` / `== 0` tests, LUT entries tested with `> 0`), any G.
+//
+// ca_unpacked_ballot: the HBM-bound path (8 B per cell-step) for 0/1 states on power-of-two grids, where the
+// legacy kernel is a true torus. A workgroup packs a tile (+1 halo in y and z, full x) into bit-planes in LDS
+// with one __ballot per 64 cells — the loads are plain coalesced dwords —, updates it with the same bit-sliced
+// adders and rule programs as the packed kernel, and expands the result back to one u32 per cell on the way
+// out. HBM sees each cell ~1.2 times in and once out instead of 7-27 cached re-reads per cell.
 #include "ca3d_internal.h"
 
 namespace ca3d
@@ -12,7 +18,7 @@ namespace ca3d
 namespace
 {
 
-using u32 = uint32_t;
+#include "ca_bitslice.inc"
 
 struct UnpackedArgs
 {
@@ -57,12 +63,176 @@ __global__ __launch_bounds__(256) void ca_unpacked_literal(const u32 *__restrict
 	out[idx] = o;
 }
 
+constexpr int kBTY = 32, kBTZ = 16; // tile rows x planes (interior)
+constexpr int kBThreads = 1024;     // 16 waves per workgroup: the pack / unpack phases are load-latency-bound
+
+template <int MAIN, bool FAST>
+__global__ __launch_bounds__(kBThreads) void ca_unpacked_ballot(const u32 *__restrict__ in, u32 *__restrict__ out, PlaneRange pr,
+                                                          u32 ny, u32 cv_shift, PackedRuleArgs rules_in)
+{
+	extern __shared__ __attribute__((aligned(16))) u32 lds[]; // in bits [(TZ+2)][(TY+2)][C], then out bits [TZ][TY][C]
+	const u32 G = pr.G, C = G / 32u, X64 = G / 64u;
+	const size_t plane_cells = (size_t)G * G;
+	const u32 tid = threadIdx.x, lane = tid & 63u;
+	const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6)); // wave-uniform: keeps the row maths scalar
+	const u32 tz = blockIdx.x / ny, ty = blockIdx.x - tz * ny;
+	const int y0 = (int)(ty * kBTY), z0 = (int)pr.lo + (int)(tz * kBTZ);
+	constexpr u32 RY = kBTY + 2, RZ = kBTZ + 2;
+	u32 *in_bits = lds;
+	u32 *out_bits = lds + RZ * RY * C;
+
+	// ---- phase 1: pack (tile + halo) into bits: one coalesced dword per lane, one ballot per 64 cells.
+	// A wave takes whole rows; the loads of a row (X64 of them, up to 8 at a time) are issued before the ballots.
+	constexpr u32 NW = kBThreads / 64u, RB = 1; // waves per workgroup, rows in flight per wave
+	for (u32 row0 = wave; row0 < RZ * RY; row0 += NW * RB)
+	{
+		const u32 *src[RB];
+#pragma unroll
+		for (u32 q = 0; q < RB; q++)
+		{
+			const u32 row = row0 + q * NW < RZ * RY ? row0 + q * NW : row0;
+			const u32 zz = row / RY, yy = row - zz * RY;
+			int gy = y0 + (int)yy - 1, gz = z0 + (int)zz - 1;
+			gy = gy < 0 ? gy + (int)G : (gy >= (int)G ? gy - (int)G : gy); // toroidal (power-of-two G)
+			if (pr.wrap_full) gz = gz < 0 ? gz + (int)G : (gz >= (int)G ? gz - (int)G : gz);
+			else gz = gz < 0 ? 0 : (gz >= (int)pr.nplanes ? (int)pr.nplanes - 1 : gz); // slab: ghosts are adjacent planes
+			src[q] = in + (size_t)gz * plane_cells + (size_t)gy * G + lane;
+		}
+		for (u32 x0 = 0; x0 < X64; x0 += 8u)
+		{
+			u32 vals[RB][8];
+#pragma unroll
+			for (u32 q = 0; q < RB; q++)
+#pragma unroll
+				for (int k = 0; k < 8; k++) vals[q][k] = x0 + (u32)k < X64 ? src[q][(x0 + (u32)k) * 64u] : 0u;
+#pragma unroll
+			for (u32 q = 0; q < RB; q++)
+			{
+				const u32 row = row0 + q * NW;
+				u32 *dst = in_bits + row * C;
+#pragma unroll
+				for (int k = 0; k < 8; k++)
+				{
+					const unsigned long long m = __ballot(vals[q][k] != 0u);
+					if (lane == 0 && x0 + (u32)k < X64 && row < RZ * RY)
+					{
+						dst[(x0 + (u32)k) * 2u] = (u32)m;
+						dst[(x0 + (u32)k) * 2u + 1u] = (u32)(m >> 32);
+					}
+				}
+			}
+		}
+	}
+	__syncthreads();
+
+	// ---- phase 2: the packed update on the tile (4 words per item), torus in x through the row ends
+	FastRules<MAIN, false, false> frules;
+	if (FAST) frules = expand_rules<MAIN, false, false>(rules_in);
+	const u32 CV = C / 4u;
+	const u32 nitems = (kBTZ * kBTY) << cv_shift;
+	for (u32 it = tid; it < nitems; it += (u32)kBThreads)
+	{
+		const u32 cxv = it & (CV - 1u), rrow = it >> cv_shift;
+		const u32 ry = rrow % kBTY, rz = rrow / kBTY;
+		const u32 cx0 = cxv * 4u;
+		auto seg = [&](u32 zz, u32 yy) {
+			SegT<4> sg;
+			const u32 *row = in_bits + (zz * RY + yy) * C;
+			const uint4 w = *reinterpret_cast<const uint4 *>(row + cx0);
+			sg.w[0] = w.x; sg.w[1] = w.y; sg.w[2] = w.z; sg.w[3] = w.w;
+			sg.lo = row[cx0 == 0 ? C - 1u : cx0 - 1u];
+			sg.hi = row[cx0 + 4u == C ? 0u : cx0 + 4u];
+			return sg;
+		};
+		PlaneRowsT<4> P[3];
+#pragma unroll
+		for (int dz = 0; dz < 3; dz++)
+		{
+			P[dz].ym = seg(rz + (u32)dz, ry);
+			P[dz].c = seg(rz + (u32)dz, ry + 1u);
+			P[dz].yp = seg(rz + (u32)dz, ry + 2u);
+		}
+		u32 o[4];
+		if (FAST) evolve<4, MAIN, false, false>(P[0], P[1], P[2], 0xFFFFFFFFu, frules, o);
+		else evolve<4, MAIN, false, false>(P[0], P[1], P[2], 0xFFFFFFFFu, rules_in, o);
+		uint4 ov;
+		ov.x = o[0]; ov.y = o[1]; ov.z = o[2]; ov.w = o[3];
+		*reinterpret_cast<uint4 *>(out_bits + rrow * C + cx0) = ov;
+	}
+	__syncthreads();
+
+	// ---- phase 3: expand bits to one u32 per cell, coalesced dword stores, whole rows per wave
+	for (u32 row = wave; row < kBTZ * kBTY; row += kBThreads / 64u)
+	{
+		const u32 rz = row / kBTY, ry = row - rz * kBTY;
+		const int gy = y0 + (int)ry, gz = z0 + (int)rz;
+		if (gy >= (int)G || gz >= (int)pr.hi) continue;
+		u32 *dstc = out + (size_t)gz * plane_cells + (size_t)gy * G + lane;
+		const u32 *srcb = out_bits + row * C + (lane >> 5);
+		for (u32 xc = 0; xc < X64; xc++) dstc[xc * 64u] = (srcb[xc * 2u] >> (lane & 31u)) & 1u;
+	}
+}
+
+template <int MAIN, bool FAST>
+hipError_t launch_ballot_f(const UnpackedLaunch &l, hipStream_t stream, const PackedRuleArgs &prog)
+{
+	const u32 G = l.pr.G, C = G / 32u;
+	const u32 ny = (G + kBTY - 1) / kBTY, nz = (l.pr.hi - l.pr.lo + kBTZ - 1) / kBTZ;
+	const size_t lds_bytes = ((size_t)(kBTZ + 2) * (kBTY + 2) + (size_t)kBTZ * kBTY) * C * sizeof(u32);
+	if (lds_bytes > 160u * 1024u) return hipErrorInvalidValue;
+	auto kern = ca_unpacked_ballot<MAIN, FAST>;
+	u32 cv_shift = 0;
+	while ((1u << cv_shift) < C / 4u) cv_shift++;
+	static bool attr_set = false;
+	if (!attr_set)
+	{
+		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+		if (e != hipSuccess) return e;
+		attr_set = true;
+	}
+	hipLaunchKernelGGL(kern, dim3(ny * nz), dim3(kBThreads), lds_bytes, stream, l.in, l.out, l.pr, ny, cv_shift, prog);
+	return hipGetLastError();
+}
+
+template <int MAIN>
+hipError_t launch_ballot(const UnpackedLaunch &l, hipStream_t stream, const PackedRuleArgs &prog)
+{
+	const bool fast = prog.set[0].born.n <= (u32)kFastCubes && prog.set[0].survive.n <= (u32)kFastCubes;
+	return fast ? launch_ballot_f<MAIN, true>(l, stream, prog) : launch_ballot_f<MAIN, false>(l, stream, prog);
+}
+
+bool ballot_applies(const UnpackedLaunch &l)
+{
+	const CanonRules &r = *l.rules;
+	const u32 G = l.pr.G;
+	if (!l.binary_state || !r.unpacked_fast) return false;
+	if (G < 128u || (G & (G - 1u))) return false; // torus only for power-of-two G; rows of >= 4 words
+	const size_t lds_bytes = ((size_t)(kBTZ + 2) * (kBTY + 2) + (size_t)kBTZ * kBTY) * (G / 32u) * sizeof(u32);
+	return lds_bytes <= 160u * 1024u;
+}
+
 } // namespace
 
 hipError_t launch_unpacked_step(const UnpackedLaunch &l, hipStream_t stream, const char **kernel_name)
 {
-	if (kernel_name) *kernel_name = "ca_unpacked_literal";
 	if (l.pr.hi <= l.pr.lo) return hipSuccess;
+	if (ballot_applies(l))
+	{
+		if (kernel_name) *kernel_name = "ca_unpacked_ballot";
+		PackedRuleArgs prog{};
+		prog.set[0] = l.rules->unpacked_prog; // rule-sets 1 and 2 stay constant-false: the legacy kernel has one rule-set
+		switch (l.rules->main)
+		{
+		case MAIN_VN: return launch_ballot<MAIN_VN>(l, stream, prog);
+		case MAIN_VN2D: return launch_ballot<MAIN_VN2D>(l, stream, prog);
+		case MAIN_MOORE: return launch_ballot<MAIN_MOORE>(l, stream, prog);
+		case MAIN_MOORE2D: return launch_ballot<MAIN_MOORE2D>(l, stream, prog);
+		case MAIN_EDGES: return launch_ballot<MAIN_EDGES>(l, stream, prog);
+		case MAIN_CORNERS: return launch_ballot<MAIN_CORNERS>(l, stream, prog);
+		default: break;
+		}
+	}
+	if (kernel_name) *kernel_name = "ca_unpacked_literal";
 	const CanonRules &r = *l.rules;
 	UnpackedArgs a{};
 	a.n_offs = r.lists.n[0];

@@ -186,6 +186,8 @@ int canonicalize_rules(const int32_t *main_offs, uint32_t n_main, const int32_t 
 		if (born[k] > 0u) r.unpacked_born |= 1u << k;
 		if (survive[k] > 0u) r.unpacked_survive |= 1u << k;
 	}
+	compile_rule_prog(r.unpacked_born, r.lists.n[0], &r.unpacked_prog.born);
+	compile_rule_prog(r.unpacked_survive, r.lists.n[0], &r.unpacked_prog.survive);
 	// fast path: every list that matters is a plain set equal to a named class union
 	r.main = MAIN_GENERIC;
 	if (simple[0])
@@ -194,6 +196,7 @@ int canonicalize_rules(const int32_t *main_offs, uint32_t n_main, const int32_t 
 	const bool edges_ok = !r.need[1] || (simple[1] && set_mask[1] == class_set(MAIN_EDGES));
 	const bool corners_ok = !r.need[2] || (simple[2] && set_mask[2] == class_set(MAIN_CORNERS));
 	r.fast = r.main != MAIN_GENERIC && edges_ok && corners_ok;
+	r.unpacked_fast = r.main != MAIN_GENERIC;
 	r.valid = true;
 	*out = r;
 	return CA3D_OK;

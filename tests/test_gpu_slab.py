@@ -56,8 +56,9 @@ def test_packed_slabs_equal_full_grid(P, K, steps, name):
     np.testing.assert_array_equal(got, ol.packed_run(G, full, r, steps))
 
 
-def test_unpacked_slabs_equal_full_grid():
-    G, P, K, steps = 32, 2, 2, 5
+@pytest.mark.parametrize("G", [32, 128])
+def test_unpacked_slabs_equal_full_grid(G):
+    P, K, steps = 2, 2, 5
     r = ol.Rules.from_strings("moore", "5-7", "4-9")
     full = (host.random_fill(G ** 3, seed=8) & 1).astype(np.uint32)
     got = _run_slabs(G, P, K, steps, r, LAYOUT_UNPACKED, full)

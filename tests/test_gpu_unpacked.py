@@ -41,3 +41,52 @@ def test_unpacked_non_binary_states_follow_the_literal_kernel():
         e.upload_state(st)
         e.step(1)
         np.testing.assert_array_equal(e.read_state(), ol.unpacked_step(G, st, r.main, r.survive, r.born))
+
+
+@pytest.mark.parametrize("G", [128, 256])
+@pytest.mark.parametrize("kw", [dict(), dict(neighbourhood="moore", born="5-7", survive="4-9"),
+                                dict(neighbourhood="moore 2D", born="3", survive="2,3"),
+                                dict(neighbourhood="edges", born="2-3", survive="1-4"),
+                                dict(neighbourhood="corners", born="1", survive="0-8")])
+def test_ballot_kernel(G, kw):
+    """0/1 states on a power-of-two grid take the ballot-packing kernel; it must equal the literal restatement."""
+    from cellularautomatons3d_amd import Engine
+
+    r = ol.Rules.from_strings(**kw)
+    with Engine(0) as e:
+        e.configure(G, LAYOUT_UNPACKED)
+        set_rules(e, r)
+        st = (host.random_fill(G ** 3, seed=G + 1) & 1).astype(np.uint32)
+        e.upload_state(st)
+        e.step(3)
+        assert e.info().kernel_name == b"ca_unpacked_ballot"
+        cur = st
+        for _ in range(3):
+            cur = ol.unpacked_step(G, cur, r.main, r.survive, r.born)
+        np.testing.assert_array_equal(e.read_state(), cur)
+        # the literal kernel on the same input
+        e.set_option("variant", 1)
+        e.upload_state(st)
+        e.step(3)
+        assert e.info().kernel_name == b"ca_unpacked_literal"
+        np.testing.assert_array_equal(e.read_state(), cur)
+
+
+def test_non_binary_upload_takes_the_literal_kernel_first():
+    from cellularautomatons3d_amd import Engine
+
+    G = 128
+    r = ol.Rules.from_strings("von neumann", "1,2,3", "0-6")
+    st = (host.random_fill(G ** 3, seed=3) % 3).astype(np.uint32)
+    with Engine(0) as e:
+        e.configure(G, LAYOUT_UNPACKED)
+        set_rules(e, r)
+        e.upload_state(st)
+        e.step(1)
+        assert e.info().kernel_name == b"ca_unpacked_literal"
+        s1 = ol.unpacked_step(G, st, r.main, r.survive, r.born)
+        np.testing.assert_array_equal(e.read_state(), s1)
+        e.step(2)
+        assert e.info().kernel_name == b"ca_unpacked_ballot"  # every cell is 0 / 1 after a step
+        s3 = ol.unpacked_step(G, ol.unpacked_step(G, s1, r.main, r.survive, r.born), r.main, r.survive, r.born)
+        np.testing.assert_array_equal(e.read_state(), s3)

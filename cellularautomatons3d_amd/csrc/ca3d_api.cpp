@@ -61,6 +61,7 @@ struct ca3d_engine
 	CanonRules rules;
 	int variant = 0;
 	int use_graph = 1;
+	int render_mode = 0;
 	int use_fused = 0; // the two-step fused kernel is bit-exact but measured slower than two single steps
 
 	// hipGraph of an even number of full-grid steps starting from buffer 0 (invalidated on any change)
@@ -609,6 +610,7 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 	if (!uniforms) return fail(CA3D_ERR_INVALID_ARGUMENT, "uniforms is NULL");
 	if (width == 0 || height == 0 || width > 16384u || height > 16384u) return fail(CA3D_ERR_INVALID_ARGUMENT, "bad target size %ux%u", width, height);
 	if (spp != 1 && spp != 4) return fail(CA3D_ERR_INVALID_ARGUMENT, "spp must be 1 or 4");
+	if (h->render_mode == 1 && spp != 1) return fail(CA3D_ERR_INVALID_ARGUMENT, "the literal frame mode takes one jittered sample per pixel (spp = 1)");
 	int rc = bind_device(h);
 	if (rc) return rc;
 	const size_t px = (size_t)width * height;
@@ -642,6 +644,9 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 	l.light = h->r_light[h->r_swap];
 	l.depth = h->r_depth[h->r_swap];
 	l.counters = h->r_counters;
+	l.mode = h->render_mode;
+	l.prev_light = h->r_light[h->r_swap ^ 1]; // group 1 of the render pass: last frame's targets (1519-1555, 1787)
+	l.prev_depth = h->r_depth[h->r_swap ^ 1];
 	HIP_TRY(hipEventRecord(h->rev_start, h->stream));
 	hipError_t e = launch_render(l, h->stream);
 	if (e != hipSuccess) return fail(CA3D_ERR_DEVICE, "render launch failed: %s", hipGetErrorString(e));
@@ -679,6 +684,25 @@ int ca3d_set_option(ca3d_t *h, const char *name, int64_t value)
 {
 	if (!h || !name) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL argument");
 	if (!strcmp(name, "graph")) { h->use_graph = value ? 1 : 0; return CA3D_OK; }
+	if (!strcmp(name, "render_mode"))
+	{
+		if (value != 0 && value != 1) return fail(CA3D_ERR_INVALID_ARGUMENT, "render_mode must be 0 (converged frame) or 1 (one literal reference frame)");
+		h->render_mode = (int)value;
+		return CA3D_OK;
+	}
+	if (!strcmp(name, "render_reset_history"))
+	{
+		// forget the temporal history (a fresh canvas): the next literal frame sees zeros, as on the reference's first frame
+		int rc2 = bind_device(h);
+		if (rc2) return rc2;
+		const size_t px = (size_t)h->rw * h->rh;
+		for (int i = 0; i < 2 && px; i++)
+		{
+			HIP_TRY(hipMemsetAsync(h->r_light[i], 0, px * 8, h->stream));
+			HIP_TRY(hipMemsetAsync(h->r_depth[i], 0, px * 4, h->stream));
+		}
+		return CA3D_OK;
+	}
 	if (!strcmp(name, "fused")) { drop_graph(h); h->use_fused = value ? 1 : 0; return CA3D_OK; }
 	if (!strcmp(name, "variant"))
 	{

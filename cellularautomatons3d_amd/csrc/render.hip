@@ -312,6 +312,267 @@ __global__ __launch_bounds__(256) void ca_render_packed(RenderParams P)
 	}
 }
 
+// ================================================================================================ literal frame
+// One frame exactly as fragment_main (800-890) produces it — jittered fixed-step marches, history look-ups,
+// depth repair, temporal blend — for hosts that want the reference's own accumulation behaviour
+// (ca3d_set_option("render_mode", 1)). sin() of the jitter hash is evaluated in double precision and rounded to
+// f32 (WGSL leaves it implementation-defined); history fetches outside the target or at NaN coordinates read 0.
+struct FrameParams
+{
+	RenderParams base;
+	const uint2 *prev_light; // RGBA16F written by the previous frame
+	const u32 *prev_depth;   // RG16F
+};
+
+__device__ __forceinline__ float fract1(float x) { return x - floorf(x); }
+
+__device__ float n1rand(const RenderParams &P, float u, float v)
+{
+	const float t = 0.07f * fract1(P.u[U_TIME]);
+	const float d = (t + u) * 12.9898f + (t + v) * 78.233f;
+	const float s = (float)sin((double)d);
+	return fract1(s * 43758.5453f);
+}
+
+__device__ __forceinline__ u32 f2u(float f) { return !(f >= 0.0f) ? 0u : (f >= 4294967296.0f ? 0xFFFFFFFFu : (u32)f); }
+
+__device__ void reprojected_uv(const RenderParams &P, v3 p, float &ux, float &uy)
+{
+	const float *m = P.u + U_PREVPROJVIEWINV;
+	const float q0 = m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12];
+	const float q1 = m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13];
+	const float q3 = m[3] * p.x + m[7] * p.y + m[11] * p.z + m[15];
+	const float cx = q0 / q3, cy = q1 / q3;
+	ux = cx * 0.5f + 0.5f;
+	uy = -cy * 0.5f + 0.5f;
+}
+
+__device__ bool texel_xy(const RenderParams &P, float fx, float fy, size_t &idx)
+{
+	if (!(fx == fx) || !(fy == fy)) return false;
+	if (fx <= -1.0f || fy <= -1.0f || fx >= (float)P.W || fy >= (float)P.H) return false;
+	const int x = (int)fx, y = (int)fy;
+	if (x < 0 || y < 0 || x >= (int)P.W || y >= (int)P.H) return false;
+	idx = (size_t)y * P.W + (size_t)x;
+	return true;
+}
+
+struct CellU
+{
+	v3 origin;
+	u32 x, y, z, idx;
+};
+
+__device__ CellU cell_u(const RenderParams &P, v3 p)
+{
+	const float cs = 1.0f / (float)P.G;
+	const v3 f = V(floorf((p.x + kHalf) / cs), floorf((p.y + kHalf) / cs), floorf((p.z + kHalf) / cs));
+	CellU r;
+	r.origin = V(f.x * cs + cs * 0.5f - kHalf, f.y * cs + cs * 0.5f - kHalf, f.z * cs + cs * 0.5f - kHalf);
+	r.x = f2u(f.x); r.y = f2u(f.y); r.z = f2u(f.z);
+	r.idx = r.x + r.y * P.G + r.z * (u32)((float)P.G * (float)P.G);
+	return r;
+}
+
+__global__ __launch_bounds__(256) void ca_render_frame_packed(FrameParams F)
+{
+	const RenderParams &P = F.base;
+	const u32 px = blockIdx.x * 16u + (threadIdx.x & 15u);
+	const u32 py = blockIdx.y * 16u + (threadIdx.x >> 4);
+	if (px >= P.W || py >= P.H) return;
+	const float *u = P.u;
+	const float *view = u + U_VIEW;
+	const float vu = ((float)px + 0.5f) / (float)P.W, vv = 1.0f - ((float)py + 0.5f) / (float)P.H;
+	float out[4] = {0.0f, 0.0f, 0.0f, 1.0f};
+	float mixed_depth = 0.0f;
+	u32 shadow = 0, pvis = 0, svis = 0;
+	const v3 cam = V(view[12], view[13], view[14]);
+	const float ar = u[U_WINDOW] / u[U_WINDOW + 1];
+	const v3 rl = norm3(V((vu - 0.5f) * ar, vv - 0.5f, -(0.5f * P.cot_half_fov)));
+	const v3 ray = V(view[0] * rl.x + view[4] * rl.y + view[8] * rl.z, view[1] * rl.x + view[5] * rl.y + view[9] * rl.z,
+	                 view[2] * rl.x + view[6] * rl.y + view[10] * rl.z);
+	const v3 half = V(kHalf, kHalf, kHalf);
+	const float cs = 1.0f / (float)P.G;
+	const float vis = cs * u[U_CELLSIZE] * 0.5f;
+	const v3 vhalf = V(vis, vis, vis);
+	float tn, tf;
+	ray_cube(cam, ray, V(0.0f, 0.0f, 0.0f), half, tn, tf);
+	const float cam_dist = sd_box(cam, half);
+	if (tn <= tf && tf >= 0.0f)
+	{
+		v3 enter = cam;
+		const v3 exitp = cam + ray * tf;
+		if (cam_dist >= 0.0f) enter = cam + ray * tn;
+		// rayMarchDepth :682-741
+		v3 final_point = exitp;
+		{
+			const v3 seg = exitp - enter;
+			const v3 dir = norm3(seg);
+			const float march = len3(seg);
+			const float step = march / u[U_DEPTHSAMPLES];
+			const float rnd = n1rand(P, vu, vv);
+			float depth = step * rnd + 0.01f;
+			for (int guard = 0; depth < march && guard < 100000; guard++)
+			{
+				pvis++;
+				const v3 sp = enter + dir * depth;
+				const v3 cc = V(floorf((sp.x + kHalf) / cs), floorf((sp.y + kHalf) / cs), floorf((sp.z + kHalf) / cs));
+				const v3 origin = V(cc.x * cs + cs * 0.5f - kHalf, cc.y * cs + cs * 0.5f - kHalf, cc.z * cs + cs * 0.5f - kHalf);
+				if (cell_state(P, f2u(cc.x), f2u(cc.y), f2u(cc.z)) != 0u)
+				{
+					float a, b;
+					ray_cube(enter, dir, origin, vhalf, a, b);
+					if (b >= 0.0f && a <= b) { final_point = enter + dir * a; break; }
+				}
+				depth += step;
+			}
+		}
+		float uvx, uvy;
+		reprojected_uv(P, final_point, uvx, uvy);
+		float pdr = 0.0f;
+		{
+			size_t ti;
+			if (F.prev_depth && texel_xy(P, uvx * u[U_WINDOW], uvy * u[U_WINDOW + 1], ti))
+			{
+				const u32 raw = F.prev_depth[ti];
+				pdr = __half2float(__ushort_as_half((unsigned short)(raw & 0xFFFFu)));
+			}
+		}
+		// estimateLikelyDepth :743-798
+		const float *pview = u + U_PREVVIEW;
+		const v3 pcam = V(pview[12], pview[13], pview[14]);
+		{
+			const float current = len3(final_point - cam);
+			const v3 view_ray = norm3(ray);
+			const v3 view_ray2 = norm3(final_point - pcam);
+			const v3 reproj_point = pcam + view_ray2 * pdr;
+			mixed_depth = current;
+			const CellU rc = cell_u(P, reproj_point), cc = cell_u(P, final_point);
+			if (cell_state(P, rc.x, rc.y, rc.z) == 1u && cc.idx != rc.idx && pdr < current)
+			{
+				float a, b;
+				ray_cube(cam, view_ray, rc.origin, vhalf, a, b);
+				if (a <= b && a >= 0.0f) mixed_depth = a;
+			}
+		}
+		const v3 p = cam + ray * mixed_depth;
+		reprojected_uv(P, p, uvx, uvy);
+		// calculateLightingAndOcclusionAt :379-427
+		float col[3] = {0.0f, 0.0f, 0.0f};
+		{
+			const CellU cell = cell_u(P, p);
+			const u32 st = cell_state(P, cell.x, cell.y, cell.z);
+			const float dist = sd_box(p - cell.origin, vhalf);
+			if (st == 1u && !(dist > 0.001f))
+			{
+				const v3 light_pos = V(u[U_LIGHT], u[U_LIGHT + 1], u[U_LIGHT + 2]);
+				const v3 ldir = norm3(light_pos - p);
+				const float rnd = n1rand(P, vu, vv);
+				float vn, vf;
+				ray_cube(p, ldir, V(0.0f, 0.0f, 0.0f), half, vn, vf);
+				const v3 vexit = p + ldir * vf;
+				// rayMarchShadow :635-680
+				float occ = 1.0f;
+				{
+					const v3 seg = vexit - p;
+					const v3 dir = norm3(seg);
+					const float march = len3(seg);
+					const float step = fmaxf(cs * u[U_CELLSIZE], march / u[U_SHADOWSAMPLES]);
+					float depth = step * rnd + 0.0025f;
+					for (int guard = 0; depth < march && guard < 100000; guard++)
+					{
+						svis++;
+						const v3 sp = p + dir * depth;
+						const v3 cc = V(floorf((sp.x + kHalf) / cs), floorf((sp.y + kHalf) / cs), floorf((sp.z + kHalf) / cs));
+						const u32 ux = f2u(cc.x), uy = f2u(cc.y), uz = f2u(cc.z);
+						const u32 st2 = cell_state(P, ux, uy, uz);
+						const v3 origin = V(cc.x * cs + cs * 0.5f - kHalf, cc.y * cs + cs * 0.5f - kHalf, cc.z * cs + cs * 0.5f - kHalf);
+						if ((ux != cell.x || uy != cell.y || uz != cell.z) && st2 == 1u)
+						{
+							float a, b;
+							ray_cube(p, dir, origin, vhalf, a, b);
+							if (a <= b && a >= 0.0f) { occ = kOcclusion; break; }
+						}
+						depth += step;
+					}
+				}
+				shadow = 1u;
+				const v3 N = face_normal(p, cell.origin);
+				const float Gf = (float)P.G;
+				const float cxn = (float)cell.x / Gf, cyn = (float)cell.y / Gf;
+				v3 albedo = V(cxn, cyn, 1.0f - cxn);
+				if (u[U_MATERIALCOLOR] != 0.0f || u[U_MATERIALCOLOR + 1] != 0.0f || u[U_MATERIALCOLOR + 2] != 0.0f)
+					albedo = V(u[U_MATERIALCOLOR], u[U_MATERIALCOLOR + 1], u[U_MATERIALCOLOR + 2]);
+				const v3 Vd = norm3(cam - p);
+				const v3 L = norm3(light_pos - p);
+				const v3 F0 = V(u[U_REFLECTIVITY], u[U_REFLECTIVITY + 1], u[U_REFLECTIVITY + 2]);
+				const v3 brdf = surface_brdf(L, Vd, N, u[U_ROUGHNESS], albedo, F0);
+				const float mag = u[U_LIGHT + 3];
+				const float LoN = dot3(L, N);
+				col[0] = occ * fmaxf(0.0f, brdf.x * mag * LoN);
+				col[1] = occ * fmaxf(0.0f, brdf.y * mag * LoN);
+				col[2] = occ * fmaxf(0.0f, brdf.z * mag * LoN);
+			}
+		}
+		// mixWithReprojectedColor :429-471
+		{
+			float pc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+			size_t ti;
+			if (F.prev_light && texel_xy(P, uvx * u[U_WINDOW], uvy * u[U_WINDOW + 1], ti))
+			{
+				const uint2 raw = F.prev_light[ti];
+				pc[0] = __half2float(__ushort_as_half((unsigned short)(raw.x & 0xFFFFu)));
+				pc[1] = __half2float(__ushort_as_half((unsigned short)(raw.x >> 16)));
+				pc[2] = __half2float(__ushort_as_half((unsigned short)(raw.y & 0xFFFFu)));
+				pc[3] = __half2float(__ushort_as_half((unsigned short)(raw.y >> 16)));
+			}
+			const v3 rdir = norm3(p - pcam);
+			const v3 rpoint = pcam + rdir * pdr;
+			const CellU rcell = cell_u(P, rpoint), ccell = cell_u(P, p);
+			const bool outside = uvx < 0.0f || uvx > 1.0f || uvy < 0.0f || uvy > 1.0f;
+			if (outside || ccell.idx != rcell.idx) { out[0] = col[0]; out[1] = col[1]; out[2] = col[2]; out[3] = 1.0f; }
+			else
+			{
+				const float a = u[U_TEMPORALALPHA];
+				const float cur[4] = {col[0], col[1], col[2], 1.0f};
+				for (int k = 0; k < 4; k++) out[k] = fminf(fmaxf(pc[k] * (1.0f - a) + cur[k] * a, 0.0f), 1.0f);
+			}
+		}
+	}
+	{
+		const v3 light_pos = V(u[U_LIGHT], u[U_LIGHT + 1], u[U_LIGHT + 2]);
+		float ln, lf;
+		ray_cube(cam, ray, light_pos, V(0.005f, 0.005f, 0.005f), ln, lf);
+		if (ln <= lf && lf >= 0.0f && out[0] == 0.0f && out[1] == 0.0f && out[2] == 0.0f) { out[0] = out[1] = out[2] = out[3] = 1.0f; }
+	}
+	if (u[U_SHOWDEPTH] == 1.0f && vu < 0.5f) { out[0] = mixed_depth; out[1] = 0.0f; out[2] = 0.0f; out[3] = 1.0f; }
+	const size_t i = (size_t)py * P.W + px;
+	if (P.light)
+	{
+		const __half2 rg = __floats2half2_rn(out[0], out[1]), ba = __floats2half2_rn(out[2], 1.0f);
+		uint2 v;
+		v.x = *reinterpret_cast<const u32 *>(&rg);
+		v.y = *reinterpret_cast<const u32 *>(&ba);
+		P.light[i] = v;
+	}
+	if (P.depth)
+	{
+		const __half2 d = __floats2half2_rn(mixed_depth, 1.0f);
+		P.depth[i] = *reinterpret_cast<const u32 *>(&d);
+	}
+	if (P.presentation)
+	{
+		const float ig = 1.0f / u[U_GAMMA];
+		P.presentation[i] = unorm8(powf(out[0], ig)) | (unorm8(powf(out[1], ig)) << 8) | (unorm8(powf(out[2], ig)) << 16) | (unorm8(out[3]) << 24);
+	}
+	if (P.counters)
+	{
+		atomicAdd(&P.counters[0], (unsigned long long)shadow);
+		atomicAdd(&P.counters[1], (unsigned long long)pvis);
+		atomicAdd(&P.counters[2], (unsigned long long)svis);
+	}
+}
+
 } // namespace
 
 hipError_t launch_render(const RenderLaunch &l, hipStream_t stream)
@@ -330,7 +591,16 @@ hipError_t launch_render(const RenderLaunch &l, hipStream_t stream)
 	P.depth = l.depth;
 	P.counters = l.counters;
 	const dim3 grid((l.W + 15u) / 16u, (l.H + 15u) / 16u);
-	hipLaunchKernelGGL(ca_render_packed, grid, dim3(256), 0, stream, P);
+	if (l.mode == 1)
+	{
+		FrameParams F;
+		F.base = P;
+		F.prev_light = reinterpret_cast<const uint2 *>(l.prev_light);
+		F.prev_depth = l.prev_depth;
+		hipLaunchKernelGGL(ca_render_frame_packed, grid, dim3(256), 0, stream, F);
+	}
+	else
+		hipLaunchKernelGGL(ca_render_packed, grid, dim3(256), 0, stream, P);
 	return hipGetLastError();
 }
 

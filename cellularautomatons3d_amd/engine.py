@@ -160,6 +160,14 @@ class Engine:
         _capi.check(self._lib.ca3d_render(self._h, up, width, height, spp, pres.ctypes.data, light.ctypes.data, depth.ctypes.data))
         return pres, light, depth
 
+    def set_render_mode(self, literal_frame: bool) -> None:
+        """False (default): the converged frame (exact cell walk). True: one literal reference frame per call —
+        jittered fixed-step marches, history look-ups and the temporal blend of fragment_main (800-890)."""
+        self.set_option("render_mode", 1 if literal_frame else 0)
+
+    def reset_render_history(self) -> None:
+        self.set_option("render_reset_history", 1)
+
     def render_stats(self) -> RenderStats:
         s = RenderStats()
         _capi.check(self._lib.ca3d_get_render_stats(self._h, C.byref(s)))

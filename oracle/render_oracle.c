@@ -372,3 +372,248 @@ float ca3d_oracle_primary_bruteforce(const uint32_t *cells, uint32_t G, const fl
 	const v3 fp = *hit_cell >= 0 ? add(enter, scale(dir, best)) : exitp;
 	return length3(sub(fp, cam));
 }
+
+/* ================================================================================================ literal frame
+ * ONE frame exactly as fragment_main (800-890) produces it: jittered fixed-step primary march (682-741), history
+ * look-ups and depth repair (473-487, 743-798), jittered shadow march (635-680), temporal blend (429-471). The
+ * jitter hash fract(sin(x) * 43758.5453) (172-180) is evaluated with sin in double precision and rounded to f32 —
+ * one concrete choice for a function WGSL leaves implementation-defined. History texel fetches outside the
+ * target, and NaN coordinates (first frame: previous matrices are zero), read (0,0,0,0), like a robust
+ * textureLoad. prev_light / prev_depth hold what the previous frame wrote, already rounded to binary16.
+ */
+static inline float fractf_(float x) { return x - floorf(x); }
+
+static float n1rand(const Ctx *c, float u, float v)
+{
+	const float t = 0.07f * fractf_(c->u[U_TIME]);
+	const float d = (t + u) * 12.9898f + (t + v) * 78.233f; /* dot(n, vec2(12.9898, 78.233)) */
+	const float s = (float)sin((double)d);
+	return fractf_(s * 43758.5453f);
+}
+
+static inline uint32_t f2u(float f) { return !(f >= 0.0f) ? 0u : (f >= 4294967296.0f ? 0xFFFFFFFFu : (uint32_t)f); }
+
+static void mat_point(const float *m, v3 p, float out[4])
+{
+	for (int r = 0; r < 4; r++) out[r] = m[r] * p.x + m[4 + r] * p.y + m[8 + r] * p.z + m[12 + r];
+}
+
+/* :473-487 */
+static void reprojected_uv(const Ctx *c, v3 p, float uv[2])
+{
+	float q[4];
+	mat_point(c->u + U_PREVPROJVIEWINV, p, q);
+	const float cx = q[0] / q[3], cy = q[1] / q[3];
+	uv[0] = cx * 0.5f + 0.5f;
+	uv[1] = -cy * 0.5f + 0.5f;
+}
+
+static void texel(const float *tex, int comps, uint32_t W, uint32_t H, float fx, float fy, float *out)
+{
+	/* vec2i(uv * windowSize): truncation; NaN and out-of-range coordinates fetch zeros */
+	for (int k = 0; k < comps; k++) out[k] = 0.0f;
+	if (!(fx == fx) || !(fy == fy) || !tex) return;
+	if (fx <= -1.0f || fy <= -1.0f || fx >= (float)W || fy >= (float)H) return;
+	const int x = (int)fx, y = (int)fy;
+	if (x < 0 || y < 0 || x >= (int)W || y >= (int)H) return;
+	for (int k = 0; k < comps; k++) out[k] = tex[((size_t)y * W + x) * comps + k];
+}
+
+typedef struct { v3 final_point, farthest; } MarchOut;
+
+/* :682-741 */
+static MarchOut ray_march_depth(const Ctx *c, v3 start, v3 end, float vu, float vv, float steps)
+{
+	MarchOut o;
+	o.farthest = end;
+	const v3 seg = sub(end, start);
+	const v3 dir = normalize3(seg);
+	const float march = length3(seg);
+	const float step = march / steps;
+	const float rnd = n1rand(c, vu, vv);
+	float depth = step * rnd + 0.01f;
+	const float cs = 1.0f / (float)c->G;
+	const float vis = cs * c->u[U_CELLSIZE] * 0.5f;
+	for (int guard = 0; depth < march && guard < 100000; guard++)
+	{
+		const v3 sp = add(start, scale(dir, depth));
+		const v3 cc = V(floorf((sp.x + HALF_CUBE_SIZE) / cs), floorf((sp.y + HALF_CUBE_SIZE) / cs), floorf((sp.z + HALF_CUBE_SIZE) / cs));
+		const v3 origin = V(cc.x * cs + cs * 0.5f - HALF_CUBE_SIZE, cc.y * cs + cs * 0.5f - HALF_CUBE_SIZE, cc.z * cs + cs * 0.5f - HALF_CUBE_SIZE);
+		if (cell_state(c, f2u(cc.x), f2u(cc.y), f2u(cc.z)) != 0u)
+		{
+			float tn, tf;
+			ray_cube(start, dir, origin, V(vis, vis, vis), &tn, &tf);
+			if (tf >= 0.0f && tn <= tf) { o.final_point = add(start, scale(dir, tn)); return o; }
+		}
+		depth += step;
+	}
+	o.final_point = end;
+	return o;
+}
+
+/* :635-680 */
+static float ray_march_shadow(const Ctx *c, v3 start, v3 end, uint32_t sx, uint32_t sy, uint32_t sz, float rnd, float steps)
+{
+	const v3 seg = sub(end, start);
+	const v3 dir = normalize3(seg);
+	const float march = length3(seg);
+	const float cs = 1.0f / (float)c->G;
+	const float vis = cs * c->u[U_CELLSIZE] * 0.5f;
+	const float step = maxf(cs * c->u[U_CELLSIZE], march / steps);
+	float depth = step * rnd + 0.0025f;
+	for (int guard = 0; depth < march && guard < 100000; guard++)
+	{
+		const v3 sp = add(start, scale(dir, depth));
+		const v3 cc = V(floorf((sp.x + HALF_CUBE_SIZE) / cs), floorf((sp.y + HALF_CUBE_SIZE) / cs), floorf((sp.z + HALF_CUBE_SIZE) / cs));
+		const uint32_t ux = f2u(cc.x), uy = f2u(cc.y), uz = f2u(cc.z);
+		const uint32_t st = cell_state(c, ux, uy, uz);
+		const v3 origin = V(cc.x * cs + cs * 0.5f - HALF_CUBE_SIZE, cc.y * cs + cs * 0.5f - HALF_CUBE_SIZE, cc.z * cs + cs * 0.5f - HALF_CUBE_SIZE);
+		if ((ux != sx || uy != sy || uz != sz) && st == 1u)
+		{
+			float tn, tf;
+			ray_cube(start, dir, origin, V(vis, vis, vis), &tn, &tf);
+			if (tn <= tf && tn >= 0.0f) return OCCLUSION_FACTOR;
+		}
+		depth += step;
+	}
+	return 1.0f;
+}
+
+typedef struct { v3 origin; uint32_t x, y, z, idx; } CellU;
+
+/* :292-304 with vec3u conversion and getCellIdx (258-266) */
+static CellU cell_u(const Ctx *c, v3 p)
+{
+	const float cs = 1.0f / (float)c->G;
+	const v3 f = V(floorf((p.x + HALF_CUBE_SIZE) / cs), floorf((p.y + HALF_CUBE_SIZE) / cs), floorf((p.z + HALF_CUBE_SIZE) / cs));
+	CellU r;
+	r.origin = V(f.x * cs + cs * 0.5f - HALF_CUBE_SIZE, f.y * cs + cs * 0.5f - HALF_CUBE_SIZE, f.z * cs + cs * 0.5f - HALF_CUBE_SIZE);
+	r.x = f2u(f.x); r.y = f2u(f.y); r.z = f2u(f.z);
+	r.idx = r.x + r.y * c->G + r.z * (uint32_t)((float)c->G * (float)c->G);
+	return r;
+}
+
+static void frame_pixel(const Ctx *c, uint32_t W, uint32_t H, uint32_t px, uint32_t py, const float *prev_light,
+                        const float *prev_depth, float out_rgba[4], float *out_depth)
+{
+	const float *u = c->u;
+	const float *view = u + U_VIEW;
+	const float vu = ((float)px + 0.5f) / (float)W, vv = 1.0f - ((float)py + 0.5f) / (float)H;
+	float out[4] = { 0, 0, 0, 1 };
+	float mixed_depth = 0.0f;
+	const v3 cam = V(view[12], view[13], view[14]);
+	const v3 ray = mat_dir(view, get_ray(c, vu, vv));
+	const v3 half = V(HALF_CUBE_SIZE, HALF_CUBE_SIZE, HALF_CUBE_SIZE);
+	float tn, tf;
+	ray_cube(cam, ray, V(0, 0, 0), half, &tn, &tf);
+	const float cam_dist = sd_box(cam, half);
+	if (tn <= tf && tf >= 0.0f)
+	{
+		v3 enter = cam;
+		const v3 exitp = add(cam, scale(ray, tf));
+		if (cam_dist >= 0.0f) enter = add(cam, scale(ray, tn));
+		const MarchOut mo = ray_march_depth(c, enter, exitp, vu, vv, u[U_DEPTHSAMPLES]);
+		float uvr[2];
+		reprojected_uv(c, mo.final_point, uvr);
+		float pd[2], pdr[2];
+		texel(prev_depth, 2, W, H, vu * u[U_WINDOW], (1.0f - vv) * u[U_WINDOW + 1], pd);
+		texel(prev_depth, 2, W, H, uvr[0] * u[U_WINDOW], uvr[1] * u[U_WINDOW + 1], pdr);
+		/* estimateLikelyDepth :743-798 */
+		float likely;
+		{
+			const float *pview = u + U_PREVVIEW;
+			const v3 pcam = V(pview[12], pview[13], pview[14]);
+			const float current = length3(sub(mo.final_point, cam));
+			const v3 view_ray = normalize3(ray);
+			const v3 view_ray2 = normalize3(sub(mo.final_point, pcam));
+			const v3 reproj_point = add(pcam, scale(view_ray2, pdr[0]));
+			likely = current;
+			const float cs = 1.0f / (float)c->G, vis = cs * u[U_CELLSIZE] * 0.5f;
+			const CellU rc = cell_u(c, reproj_point), cc = cell_u(c, mo.final_point);
+			if (cell_state(c, rc.x, rc.y, rc.z) == 1u && cc.idx != rc.idx && pdr[0] < current)
+			{
+				float a, b;
+				ray_cube(cam, view_ray, rc.origin, V(vis, vis, vis), &a, &b);
+				if (a <= b && a >= 0.0f) likely = a;
+			}
+			(void)pd;
+		}
+		mixed_depth = likely;
+		const v3 p = add(cam, scale(ray, mixed_depth));
+		reprojected_uv(c, p, uvr);
+		/* calculateLightingAndOcclusionAt :379-427 */
+		float col[3] = { 0, 0, 0 };
+		{
+			const float cs = 1.0f / (float)c->G, vis = cs * u[U_CELLSIZE] * 0.5f;
+			const CellU cell = cell_u(c, p);
+			const uint32_t st = cell_state(c, cell.x, cell.y, cell.z);
+			const float dist = sd_box(sub(p, cell.origin), V(vis, vis, vis));
+			if (st == 1u && !(dist > 0.001f))
+			{
+				const v3 lightPos = V(u[U_LIGHT], u[U_LIGHT + 1], u[U_LIGHT + 2]);
+				const v3 ldir = normalize3(sub(lightPos, p));
+				const float rnd = n1rand(c, vu, vv);
+				float vn, vf;
+				ray_cube(p, ldir, V(0, 0, 0), half, &vn, &vf);
+				const v3 vexit = add(p, scale(ldir, vf));
+				const float occ = ray_march_shadow(c, p, vexit, cell.x, cell.y, cell.z, rnd, u[U_SHADOWSAMPLES]);
+				Cell ci; ci.origin = cell.origin; ci.cx = (int32_t)cell.x; ci.cy = (int32_t)cell.y; ci.cz = (int32_t)cell.z;
+				const v3 lit = lighting_at(c, p, ci, cam);
+				col[0] = occ * lit.x; col[1] = occ * lit.y; col[2] = occ * lit.z;
+			}
+		}
+		/* mixWithReprojectedColor :429-471 */
+		{
+			float pc[4];
+			texel(prev_light, 4, W, H, uvr[0] * u[U_WINDOW], uvr[1] * u[U_WINDOW + 1], pc);
+			const float *pview = u + U_PREVVIEW;
+			const v3 pcam = V(pview[12], pview[13], pview[14]);
+			const v3 rdir = normalize3(sub(p, pcam));
+			const v3 rpoint = add(pcam, scale(rdir, pdr[0]));
+			const CellU rcell = cell_u(c, rpoint), ccell = cell_u(c, p);
+			const int outside = uvr[0] < 0.0f || uvr[0] > 1.0f || uvr[1] < 0.0f || uvr[1] > 1.0f;
+			if (outside || ccell.idx != rcell.idx) { out[0] = col[0]; out[1] = col[1]; out[2] = col[2]; out[3] = 1.0f; }
+			else
+			{
+				const float a = u[U_TEMPORALALPHA];
+				const float cur[4] = { col[0], col[1], col[2], 1.0f };
+				for (int k = 0; k < 4; k++) out[k] = clampf(pc[k] * (1.0f - a) + cur[k] * a, 0.0f, 1.0f); /* mix(x, y, a) = x*(1-a) + y*a */
+			}
+		}
+	}
+	{
+		const v3 lightPos = V(u[U_LIGHT], u[U_LIGHT + 1], u[U_LIGHT + 2]);
+		float ln, lf;
+		ray_cube(cam, ray, lightPos, V(0.005f, 0.005f, 0.005f), &ln, &lf);
+		if (ln <= lf && lf >= 0.0f && out[0] == 0.0f && out[1] == 0.0f && out[2] == 0.0f) { out[0] = out[1] = out[2] = out[3] = 1.0f; }
+	}
+	if (u[U_SHOWDEPTH] == 1.0f && vu < 0.5f) { out[0] = mixed_depth; out[1] = 0; out[2] = 0; out[3] = 1; }
+	for (int k = 0; k < 4; k++) out_rgba[k] = out[k];
+	*out_depth = mixed_depth;
+}
+
+int ca3d_oracle_render_frame(const uint32_t *cells, uint32_t G, const float *uniforms, uint32_t W, uint32_t H,
+                             const float *prev_light, const float *prev_depth, float *light, float *depth, float *presentation)
+{
+	if (!cells || !uniforms || G == 0 || (G % 32u)) return -1;
+	Ctx c = { cells, G, uniforms, (float)(1.0 / tan(37.5 * 3.14159265359 / 180.0)) };
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 4)
+#endif
+	for (uint32_t py = 0; py < H; py++)
+		for (uint32_t px = 0; px < W; px++)
+		{
+			float o[4], d;
+			frame_pixel(&c, W, H, px, py, prev_light, prev_depth, o, &d);
+			const size_t i = (size_t)py * W + px;
+			if (light) { light[4 * i] = o[0]; light[4 * i + 1] = o[1]; light[4 * i + 2] = o[2]; light[4 * i + 3] = 1.0f; }
+			if (depth) { depth[2 * i] = d; depth[2 * i + 1] = 1.0f; }
+			if (presentation)
+			{
+				const float ig = 1.0f / uniforms[U_GAMMA];
+				presentation[4 * i] = powf(o[0], ig); presentation[4 * i + 1] = powf(o[1], ig); presentation[4 * i + 2] = powf(o[2], ig);
+				presentation[4 * i + 3] = o[3];
+			}
+		}
+	return 0;
+}

@@ -174,3 +174,22 @@ def primary_bruteforce(cells, G, uniforms, W, H, px, py):
     d = fn(cp, C.c_uint32(G), u.ctypes.data_as(C.POINTER(C.c_float)), C.c_uint32(W), C.c_uint32(H), C.c_uint32(px),
            C.c_uint32(py), C.byref(cell))
     return float(d), int(cell.value)
+
+
+def render_frame(cells, G, uniforms, W, H, prev_light=None, prev_depth=None):
+    """One literal reference frame (stochastic march + temporal history). prev_* are what the previous frame wrote,
+    already rounded to binary16 (float arrays [H,W,4] / [H,W,2]) or None for an empty history."""
+    c, cp = _u32(cells)
+    u = np.ascontiguousarray(uniforms, dtype=np.float32)
+    fp = C.POINTER(C.c_float)
+    light = np.zeros((H, W, 4), dtype=np.float32)
+    depth = np.zeros((H, W, 2), dtype=np.float32)
+    pres = np.zeros((H, W, 4), dtype=np.float32)
+    pl = np.ascontiguousarray(prev_light, dtype=np.float32) if prev_light is not None else None
+    pd = np.ascontiguousarray(prev_depth, dtype=np.float32) if prev_depth is not None else None
+    rc = lib().ca3d_oracle_render_frame(cp, C.c_uint32(G), u.ctypes.data_as(fp), C.c_uint32(W), C.c_uint32(H),
+                                        pl.ctypes.data_as(fp) if pl is not None else None,
+                                        pd.ctypes.data_as(fp) if pd is not None else None,
+                                        light.ctypes.data_as(fp), depth.ctypes.data_as(fp), pres.ctypes.data_as(fp))
+    assert rc == 0, rc
+    return light, depth, pres

@@ -127,3 +127,38 @@ def test_render_errors(eng):
         eng.render(u, 0, 64, 1)
     with pytest.raises(ValueError):
         eng.render(u[:100], 64, 64, 1)
+
+
+def test_literal_frame_mode_tracks_the_oracle(eng):
+    """N3: the reference's per-frame process (jittered marches, history reads, EMA) — GPU and oracle run in lock-step,
+    each feeding on its own history, and must stay together."""
+    G, W, H = 32, 160, 90
+    cells = host.random_fill(host.words_per_buffer(G), seed=11, and_rounds=4)
+    vm = host.orbit_camera(1.3, (1.0, 0.4, 0.0), 0.7)
+    eng.configure(G)
+    set_rules(eng, rules("default"))
+    eng.upload_state(cells)
+    eng.set_render_mode(True)
+    try:
+        eng.render(host.uniform_block(W, H, vm), W, H, 1)  # allocates the targets
+        eng.reset_render_history()
+        pl = pd = None
+        for f in range(12):
+            u = host.uniform_block(W, H, vm, elapsed_time=0.1 + 0.137 * f, prev_view_mat=vm if f else None)
+            pres, light, depth = eng.render(u, W, H, 1)
+            ol_light, ol_depth, ol_pres = ol.render_frame(cells, G, u, W, H, pl, pd)
+            pl, pd = ol_light.astype(np.float16).astype(np.float32), ol_depth.astype(np.float16).astype(np.float32)
+            ok = (np.abs(light.astype(np.float32)[..., :3] - pl[..., :3]).max(-1) <= 4e-3) & \
+                 (np.abs(depth.astype(np.float32)[..., 0] - pd[..., 0]) <= 2e-3)
+            assert ok.mean() >= 0.99, (f, ok.mean())
+        want8 = np.rint(np.clip(ol_pres, 0, 1) * 255.0)
+        assert (np.abs(pres.astype(np.float32) - want8).max(-1) <= 2).mean() >= 0.99
+        # and the accumulated frame sits on the converged one
+        eng.set_render_mode(False)
+        _, limit, _ = eng.render(host.uniform_block(W, H, vm), W, H, 1)
+        assert np.abs(light.astype(np.float32)[..., :3] - limit.astype(np.float32)[..., :3]).mean() < 0.01
+        with pytest.raises(Exception):
+            eng.set_render_mode(True)
+            eng.render(u, W, H, 4)
+    finally:
+        eng.set_render_mode(False)

@@ -102,3 +102,30 @@ def test_spp4_is_mean_of_subsamples_and_gamma():
     mean = light1[..., :3].reshape(H, 2, W, 2, 3).mean(axis=(1, 3))
     np.testing.assert_allclose(light4[..., :3], mean, rtol=0, atol=1e-6)
     np.testing.assert_allclose(pres4[..., :3], np.power(light4[..., :3], 0.5), rtol=0, atol=1e-6)
+
+
+def _static_camera_block(W, H, vm, t):
+    return host.uniform_block(W, H, vm, elapsed_time=t, prev_view_mat=vm)
+
+
+def test_literal_frames_converge_to_the_exact_walk_frame():
+    """R-par: under a static camera the reference's per-frame process (jittered marches + EMA, restated literally)
+    approaches the deterministic frame the engine renders by default."""
+    G, W, H = 32, 96, 54
+    cells = _scene(G, seed=11, rounds=4)
+    vm = host.orbit_camera(1.3, (1.0, 0.4, 0.0), 0.7)
+    limit, limit_depth, _, _ = ol.render(cells, G, host.uniform_block(W, H, vm), W, H, 1)
+    pl = pd = None
+    errs = []
+    for f in range(60):
+        u = _static_camera_block(W, H, vm, 0.1 + 0.137 * f)
+        light, depth, _ = ol.render_frame(cells, G, u, W, H, pl, pd)
+        pl, pd = light.astype(np.float16).astype(np.float32), depth.astype(np.float16).astype(np.float32)
+        errs.append(float(np.abs(light[..., :3] - limit[..., :3]).mean()))
+    lit = limit[..., :3].sum(-1) > 0.05
+    assert lit.mean() > 0.03
+    assert errs[-1] < 0.5 * errs[0] and errs[-1] < 0.004  # EMA pulls the noisy frames onto the limit
+    close = np.abs(light[..., :3] - limit[..., :3]).max(-1) < 0.15
+    assert close[lit].mean() > 0.85
+    hit = limit_depth[..., 0] > 0
+    assert (np.abs(depth[..., 0] - limit_depth[..., 0])[hit] < 2.0 / G).mean() > 0.9

@@ -606,7 +606,8 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 {
 	if (!h) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL engine handle");
 	if (!h->configured || !h->has_state) return fail(CA3D_ERR_NOT_CONFIGURED, "no state to render: configure and upload first");
-	if (h->slab || h->layout != CA3D_LAYOUT_PACKED32) return fail(CA3D_ERR_UNSUPPORTED, "the renderer reads the packed full grid (pathtraced_fragment_clustered.wgsl)");
+	if (h->slab) return fail(CA3D_ERR_UNSUPPORTED, "the renderer reads a full grid, not a slab");
+	if (h->layout == CA3D_LAYOUT_UNPACKED && h->render_mode != 0) return fail(CA3D_ERR_UNSUPPORTED, "the literal frame mode is implemented for the packed layout only");
 	if (!uniforms) return fail(CA3D_ERR_INVALID_ARGUMENT, "uniforms is NULL");
 	if (width == 0 || height == 0 || width > 16384u || height > 16384u) return fail(CA3D_ERR_INVALID_ARGUMENT, "bad target size %ux%u", width, height);
 	if (spp != 1 && spp != 4) return fail(CA3D_ERR_INVALID_ARGUMENT, "spp must be 1 or 4");
@@ -645,6 +646,7 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 	l.depth = h->r_depth[h->r_swap];
 	l.counters = h->r_counters;
 	l.mode = h->render_mode;
+	l.legacy = h->layout == CA3D_LAYOUT_UNPACKED; // legacy volume -> legacy shader (pathtraced_fragment.wgsl)
 	l.prev_light = h->r_light[h->r_swap ^ 1]; // group 1 of the render pass: last frame's targets (1519-1555, 1787)
 	l.prev_depth = h->r_depth[h->r_swap ^ 1];
 	HIP_TRY(hipEventRecord(h->rev_start, h->stream));

@@ -119,6 +119,7 @@ struct RenderLaunch
 	void *light;            // device RGBA16F or null
 	uint32_t *depth;        // device RG16F or null
 	unsigned long long *counters; // device, 3 counters, or null
+	bool legacy;                  // unpacked volume + legacy shading (shaders/pathtraced_fragment.wgsl)
 	int mode;                     // 0 converged frame (exact walk), 1 one literal reference frame with history
 	const void *prev_light;       // previous frame's RGBA16F (mode 1)
 	const uint32_t *prev_depth;   // previous frame's RG16F (mode 1)

@@ -50,6 +50,7 @@ struct RenderParams
 	uint2 *light;              // RGBA16F
 	u32 *depth;                // RG16F
 	unsigned long long *counters; // [0] shadow rays, [1] primary cell visits, [2] shadow cell visits
+	u32 legacy; // 1: one-u32-per-cell volume + the shading of shaders/pathtraced_fragment.wgsl (R-legacy)
 };
 
 constexpr float kPi = 3.14159265359f;
@@ -58,6 +59,14 @@ constexpr float kOcclusion = 0.0095f;
 
 __device__ __forceinline__ u32 cell_state(const RenderParams &P, u32 x, u32 y, u32 z)
 {
+	// legacy: cellStates[x + y*G + z*G*G], no wrap (pathtraced_fragment.wgsl:157-168). A point on the volume's
+	// boundary can floor to G or -1: the reference then indexes outside its buffer, which WebGPU's robust buffer
+	// access turns into a harmless read; here such a cell is simply dead.
+	if (P.legacy)
+	{
+		if (x >= P.G || y >= P.G || z >= P.G) return 0u;
+		return P.cells[(size_t)x + (size_t)y * P.G + (size_t)z * P.G * P.G] == 1u ? 1u : 0u;
+	}
 	// :268-290 — every coordinate wraps modulo the grid
 	const u32 idx = ((x >> 5) % P.cols) + (y % P.G) * P.cols + (z % P.G) * P.cols * P.G;
 	return (P.cells[idx] >> (x & 31u)) & 1u;
@@ -152,9 +161,15 @@ __device__ bool walk(const RenderParams &P, v3 start, v3 dir, float t0, float tm
 	{
 		if (t >= tmax) return false;
 		visits++;
-		const int key = (ix >> 5) + (iy + iz * G) * (int)P.cols;
-		if (key != wkey) { word = P.cells[key]; wkey = key; }
-		if ((word >> (ix & 31)) & 1u)
+		bool alive;
+		if (P.legacy) alive = P.cells[(size_t)ix + ((size_t)iy + (size_t)iz * G) * G] == 1u; // `== 1` (pathtraced_fragment.wgsl:530)
+		else
+		{
+			const int key = (ix >> 5) + (iy + iz * G) * (int)P.cols;
+			if (key != wkey) { word = P.cells[key]; wkey = key; }
+			alive = (word >> (ix & 31)) & 1u;
+		}
+		if (alive)
 		{
 			if (!(SHADOW && ix == sx0 && iy == sy0 && iz == sz0)) // any(cell != startCell) :664
 			{
@@ -229,7 +244,29 @@ __device__ Sample shade_sample(const RenderParams &P, float vu, float vv, u32 &p
 			const float slen = len3(sseg);
 			float dummy = 0.0f;
 			const bool occluded = walk<true>(P, p, sdir, 0.0025f, slen, vhalf, cx, cy, cz, dummy, svis);
-			const float occ = occluded ? kOcclusion : 1.0f;
+			const float occ = occluded ? (P.legacy ? 0.095f : kOcclusion) : 1.0f; // pathtraced_fragment.wgsl:67 / clustered :72
+			if (P.legacy)
+			{
+				// calculateLigtingAt (pathtraced_fragment.wgsl:338-365): mirror-reflection term + flat term, 1/d^2 to light and eye
+				const v3 N = face_normal(p, origin);
+				const float Gf = (float)P.G;
+				const v3 colr = V(f.x / Gf, f.y / Gf, 1.0f - f.x / Gf);
+				const v3 view_dir = norm3(p - cam);
+				const float dl = len3(light_pos - p), dc = len3(cam - p);
+				const float fl = fmaxf(1.0f, powf(dl, 2.0f)), fc = fmaxf(1.0f, powf(dc, 2.0f));
+				const float incident = u[U_LIGHT + 3] / fl;
+				const v3 inc_dir = norm3(p - light_pos);
+				const float ndi = dot3(N, inc_dir);
+				const v3 refl = V(inc_dir.x - 2.0f * ndi * N.x, inc_dir.y - 2.0f * ndi * N.y, inc_dir.z - 2.0f * ndi * N.z);
+				const float reflected = incident * dot3(refl, V(-view_dir.x, -view_dir.y, -view_dir.z));
+				s.r = occ * ((colr.x * reflected + incident * colr.x) / fc);
+				s.g = occ * ((colr.y * reflected + incident * colr.y) / fc);
+				s.b = occ * ((colr.z * reflected + incident * colr.z) / fc);
+				s.a = occ; // the vec4 colour (alpha 1) is scaled as a whole (:226)
+				s.shadow_ray = 1u;
+			}
+			else
+			{
 			// calculateLightingAt :594-633
 			const v3 N = face_normal(p, origin);
 			const float Gf = (float)P.G;
@@ -247,11 +284,13 @@ __device__ Sample shade_sample(const RenderParams &P, float vu, float vv, u32 &p
 			s.g = occ * fmaxf(0.0f, brdf.y * mag * LoN);
 			s.b = occ * fmaxf(0.0f, brdf.z * mag * LoN);
 			s.shadow_ray = 1u;
+			}
 		}
 		// fixed point of clamp(mix(prev, cur, alpha), 0, 1) under a static camera :468
 		s.r = fminf(fmaxf(s.r, 0.0f), 1.0f);
 		s.g = fminf(fmaxf(s.g, 0.0f), 1.0f);
 		s.b = fminf(fmaxf(s.b, 0.0f), 1.0f);
+		s.a = fminf(fmaxf(s.a, 0.0f), 1.0f);
 	}
 	{
 		// light gizmo :866-874
@@ -301,7 +340,7 @@ __global__ __launch_bounds__(256) void ca_render_packed(RenderParams P)
 	}
 	if (P.presentation)
 	{
-		const float ig = 1.0f / P.u[U_GAMMA];
+		const float ig = P.legacy ? 1.0f / 2.2f : 1.0f / P.u[U_GAMMA]; // legacy gamma is the constant 2.2 (:704)
 		P.presentation[i] = unorm8(powf(r, ig)) | (unorm8(powf(g, ig)) << 8) | (unorm8(powf(b, ig)) << 16) | (unorm8(a) << 24);
 	}
 	if (P.counters)
@@ -590,6 +629,7 @@ hipError_t launch_render(const RenderLaunch &l, hipStream_t stream)
 	P.light = reinterpret_cast<uint2 *>(l.light);
 	P.depth = l.depth;
 	P.counters = l.counters;
+	P.legacy = l.legacy ? 1u : 0u;
 	const dim3 grid((l.W + 15u) / 16u, (l.H + 15u) / 16u);
 	if (l.mode == 1)
 	{

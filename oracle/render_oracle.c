@@ -56,12 +56,15 @@ typedef struct
 	uint32_t G;
 	const float *u;
 	float cot_half_fov;
+	int legacy; /* one u32 per cell + shaders/pathtraced_fragment.wgsl shading */
 } Ctx;
 
 /* :268-290 (modulo wrap of every coordinate) */
 static inline uint32_t cell_state(const Ctx *c, uint32_t x, uint32_t y, uint32_t z)
 {
 	const uint32_t G = c->G, cols = G / 32u;
+	if (c->legacy) /* pathtraced_fragment.wgsl:157-168, 201: no wrap; out-of-range coordinates read as dead */
+		return (x >= G || y >= G || z >= G) ? 0u : (c->cells[(size_t)x + (size_t)y * G + (size_t)z * G * G] == 1u ? 1u : 0u);
 	const uint32_t idx = ((x / 32u) % cols) + (y % G) * cols + (z % G) * cols * G;
 	return (c->cells[idx] >> (x % 32u)) & 1u;
 }
@@ -277,13 +280,36 @@ static Sample shade_sample(const Ctx *c, float vu, float vv)
 			const float slen = length3(sseg);
 			ShadowUD su = { c, p, sdir, V(vis, vis, vis), cell.cx, cell.cy, cell.cz, 0 };
 			walk_cells(c, p, sdir, 0.0025f, slen, shadow_visit, &su);
-			const float occ = su.occluded ? OCCLUSION_FACTOR : 1.0f;
-			const v3 lit = lighting_at(c, p, cell, cam);
-			s.r = occ * lit.x; s.g = occ * lit.y; s.b = occ * lit.z;
+			const float occ = su.occluded ? (c->legacy ? 0.095f : OCCLUSION_FACTOR) : 1.0f;
+			if (c->legacy)
+			{
+				/* calculateLigtingAt, pathtraced_fragment.wgsl:338-365 */
+				const v3 N = face_normal(p, cell.origin);
+				const float Gf = (float)c->G;
+				const float fx = floorf((p.x + HALF_CUBE_SIZE) / cs), fy = floorf((p.y + HALF_CUBE_SIZE) / cs);
+				const v3 colr = V(fx / Gf, fy / Gf, 1.0f - fx / Gf);
+				const v3 view_dir = normalize3(sub(p, cam));
+				const float dl = length3(sub(lightPos, p)), dc = length3(sub(cam, p));
+				const float fl = maxf(1.0f, powf(dl, 2.0f)), fc = maxf(1.0f, powf(dc, 2.0f));
+				const float incident = u[U_LIGHT + 3] / fl;
+				const v3 inc_dir = normalize3(sub(p, lightPos));
+				const float ndi = dot(N, inc_dir);
+				const v3 refl = V(inc_dir.x - 2.0f * ndi * N.x, inc_dir.y - 2.0f * ndi * N.y, inc_dir.z - 2.0f * ndi * N.z);
+				const float reflected = incident * dot(refl, V(-view_dir.x, -view_dir.y, -view_dir.z));
+				s.r = occ * ((colr.x * reflected + incident * colr.x) / fc);
+				s.g = occ * ((colr.y * reflected + incident * colr.y) / fc);
+				s.b = occ * ((colr.z * reflected + incident * colr.z) / fc);
+				s.a = occ;
+			}
+			else
+			{
+				const v3 lit = lighting_at(c, p, cell, cam);
+				s.r = occ * lit.x; s.g = occ * lit.y; s.b = occ * lit.z;
+			}
 			s.shadow_ray = 1;
 		}
 		/* temporal limit of clamp(mix(prev, cur, alpha), 0, 1) :468 */
-		s.r = clampf(s.r, 0.0f, 1.0f); s.g = clampf(s.g, 0.0f, 1.0f); s.b = clampf(s.b, 0.0f, 1.0f);
+		s.r = clampf(s.r, 0.0f, 1.0f); s.g = clampf(s.g, 0.0f, 1.0f); s.b = clampf(s.b, 0.0f, 1.0f); s.a = clampf(s.a, 0.0f, 1.0f);
 	}
 	/* light gizmo :866-874 */
 	{
@@ -300,11 +326,11 @@ static const float kSub4[4][2] = { { 0.25f, 0.25f }, { 0.75f, 0.25f }, { 0.25f, 
 
 /* Outputs as float: light[W*H*4] (linear rgb, a), depth[W*H*2] (depth of sub-sample 0, 1), presentation[W*H*4]
  * (pow(rgb, 1/gamma), a). spp is 1 (pixel centre) or 4 (2x2 stratified). Returns shadow rays traced, or <0. */
-int64_t ca3d_oracle_render(const uint32_t *cells, uint32_t G, const float *uniforms, uint32_t W, uint32_t H, uint32_t spp,
-                           float *light, float *depth, float *presentation, uint32_t y_begin, uint32_t y_end)
+static int64_t render_impl(const uint32_t *cells, uint32_t G, const float *uniforms, uint32_t W, uint32_t H, uint32_t spp,
+                           float *light, float *depth, float *presentation, uint32_t y_begin, uint32_t y_end, int legacy)
 {
-	if (!cells || !uniforms || G == 0 || (G % 32u) || (spp != 1 && spp != 4)) return -1;
-	Ctx c = { cells, G, uniforms, (float)(1.0 / tan(37.5 * 3.14159265359 / 180.0)) };
+	if (!cells || !uniforms || G == 0 || (!legacy && (G % 32u)) || (spp != 1 && spp != 4)) return -1;
+	Ctx c = { cells, G, uniforms, (float)(1.0 / tan(37.5 * 3.14159265359 / 180.0)), legacy };
 	int64_t shadow = 0;
 	if (y_end > H) y_end = H;
 #ifdef _OPENMP
@@ -330,12 +356,26 @@ int64_t ca3d_oracle_render(const uint32_t *cells, uint32_t G, const float *unifo
 			if (depth) { depth[2 * i] = d0; depth[2 * i + 1] = 1.0f; }
 			if (presentation)
 			{
-				const float ig = 1.0f / uniforms[U_GAMMA];
+				const float ig = legacy ? 1.0f / 2.2f : 1.0f / uniforms[U_GAMMA]; /* legacy: constant 2.2 (:704) */
 				presentation[4 * i] = powf(r, ig); presentation[4 * i + 1] = powf(g, ig); presentation[4 * i + 2] = powf(b, ig);
 				presentation[4 * i + 3] = a;
 			}
 		}
 	return shadow;
+}
+
+int64_t ca3d_oracle_render(const uint32_t *cells, uint32_t G, const float *uniforms, uint32_t W, uint32_t H, uint32_t spp,
+                           float *light, float *depth, float *presentation, uint32_t y_begin, uint32_t y_end)
+{
+	return render_impl(cells, G, uniforms, W, H, spp, light, depth, presentation, y_begin, y_end, 0);
+}
+
+/* The legacy renderer (shaders/pathtraced_fragment.wgsl): same converged-frame definition over the one-u32-per-cell
+ * volume with its own shading, OCCLUSION_FACTOR 0.095 and gamma 2.2. */
+int64_t ca3d_oracle_render_legacy(const uint32_t *cells, uint32_t G, const float *uniforms, uint32_t W, uint32_t H, uint32_t spp,
+                                  float *light, float *depth, float *presentation, uint32_t y_begin, uint32_t y_end)
+{
+	return render_impl(cells, G, uniforms, W, H, spp, light, depth, presentation, y_begin, y_end, 1);
 }
 
 /* Independent visibility check for small grids: nearest passing visible cube among ALL alive cells. Returns the
@@ -344,7 +384,7 @@ int64_t ca3d_oracle_render(const uint32_t *cells, uint32_t G, const float *unifo
 float ca3d_oracle_primary_bruteforce(const uint32_t *cells, uint32_t G, const float *uniforms, uint32_t W, uint32_t H,
                                      uint32_t px, uint32_t py, int64_t *hit_cell)
 {
-	Ctx c = { cells, G, uniforms, (float)(1.0 / tan(37.5 * 3.14159265359 / 180.0)) };
+	Ctx c = { cells, G, uniforms, (float)(1.0 / tan(37.5 * 3.14159265359 / 180.0)), 0 };
 	const float *view = uniforms + U_VIEW;
 	const v3 cam = V(view[12], view[13], view[14]);
 	const float vu = ((float)px + 0.5f) / (float)W, vv = 1.0f - ((float)py + 0.5f) / (float)H;
@@ -596,7 +636,7 @@ int ca3d_oracle_render_frame(const uint32_t *cells, uint32_t G, const float *uni
                              const float *prev_light, const float *prev_depth, float *light, float *depth, float *presentation)
 {
 	if (!cells || !uniforms || G == 0 || (G % 32u)) return -1;
-	Ctx c = { cells, G, uniforms, (float)(1.0 / tan(37.5 * 3.14159265359 / 180.0)) };
+	Ctx c = { cells, G, uniforms, (float)(1.0 / tan(37.5 * 3.14159265359 / 180.0)), 0 };
 #ifdef _OPENMP
 #pragma omp parallel for schedule(dynamic, 4)
 #endif

@@ -55,3 +55,18 @@ def test_js_engine_on_gpu(tmp_path):
     ok = (np.abs(light[..., :3] - olight[..., :3]).max(-1) <= 2e-3) & \
          (np.abs(pres.astype(np.float32) - np.rint(np.clip(opres, 0, 1) * 255)).max(-1) <= 1)
     assert ok.mean() >= 0.999
+
+
+def test_facade_runs_the_unmodified_reference_host_with_a_mock_engine():
+    """SURVEY 8(f) N2 (build container only): main_pathtraced.js + ui.js + MemoryManager.js, unmodified, drive the
+    navigator.gpu facade through init and five frames; a recording mock stands in for the engine."""
+    if not os.path.isdir("/root/reference"):
+        pytest.skip("the reference sources are not mounted here")
+    r = _node("tests/js/facade_reference_mock.js", "/root/reference")
+    assert r.returncode == 0 and '"ok":true' in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
+@pytest.mark.gpu
+def test_facade_call_sequence_on_the_real_engine():
+    r = _node("tests/js/facade_gpu_check.js")
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout + r.stderr)[-3000:]

@@ -154,8 +154,14 @@ int ca3d_get_stats(ca3d_t *h, ca3d_stats *out);
  *   presentation_rgba8  width*height*4 bytes   pow(rgb, 1/gamma), alpha  -> the canvas attachment
  *   light_rgba16f       width*height*4 halfs   linear rgb, 1              -> light history attachment
  *   depth_rg16f         width*height*2 halfs   distance from camera, 1    -> depth history attachment
- * The engine keeps the device-side targets and swaps its two history surfaces per call (1793). Packed layout,
- * full grid only. Synchronous only when an output pointer is given.
+ * The engine keeps the device-side targets and swaps its two history surfaces per call (1793). Full grid only.
+ * Synchronous only when an output pointer is given.
+ *
+ * What a frame is: by default the frame the reference's jittered, temporally accumulated process converges to
+ * under a static camera (exact cell walk). ca3d_set_option("render_mode", 1) switches to ONE literal
+ * reference frame per call (jittered marches + history look-ups + temporal blend; spp must be 1; packed layout);
+ * "render_reset_history" clears the history surfaces. An engine configured with CA3D_LAYOUT_UNPACKED renders
+ * through the legacy shader model (shaders/pathtraced_fragment.wgsl).
  */
 int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t height, uint32_t spp,
                 uint8_t *presentation_rgba8, uint16_t *light_rgba16f, uint16_t *depth_rg16f);
@@ -169,7 +175,9 @@ typedef struct ca3d_render_stats
 } ca3d_render_stats;
 int ca3d_get_render_stats(ca3d_t *h, ca3d_render_stats *out);
 
-/* Tuning knobs (not part of the reference surface): "graph" 0/1 hipGraph batching, "variant" kernel override. */
+/* Options (not part of the reference surface): "graph" 0/1 hipGraph batching; "fused" 0/1 two-step fused kernel
+ * (bit-exact, off by default); "variant" 1 forces the generic / literal kernels; "render_mode" 0/1;
+ * "render_reset_history". */
 int ca3d_set_option(ca3d_t *h, const char *name, int64_t value);
 
 #ifdef __cplusplus

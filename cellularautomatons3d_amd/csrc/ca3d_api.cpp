@@ -3,6 +3,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <new>
 #include <string>
 
@@ -67,6 +68,7 @@ struct ca3d_engine
 	// hipGraph of an even number of full-grid steps starting from buffer 0 (invalidated on any change)
 	hipGraphExec_t graph_exec = nullptr;
 	uint32_t graph_steps = 0, graph_launches = 0;
+	std::map<uint64_t, hipGraphExec_t> slab_graphs; // (start buffer, sub-steps) -> captured slab batch
 
 	ca3d_stats stats{};
 	const char *kernel_name = "";
@@ -99,6 +101,8 @@ void drop_graph(ca3d_engine *h)
 		h->graph_exec = nullptr;
 		h->graph_steps = 0;
 	}
+	for (auto &kv : h->slab_graphs) hipGraphExecDestroy(kv.second);
+	h->slab_graphs.clear();
 }
 
 void free_render_targets(ca3d_engine *h)
@@ -478,26 +482,57 @@ int ca3d_slab_step(ca3d_t *h, uint32_t n_steps)
 	if (n_steps == 0) return CA3D_OK;
 	HIP_TRY(hipEventRecord(h->ev_start, h->stream));
 	const uint32_t L = h->nplanes, K = h->ghost;
-	double planes_done = 0;
-	for (uint32_t s = 1; s <= n_steps; s++)
+	// Valid region shrinks by one plane per side per sub-step. The packed kernel's bottom face is dead (z == -1 is
+	// dropped), so the slab that owns global plane 0 never needs its low ghost.
+	auto enqueue_all = [&](uint32_t start_buf) -> int {
+		uint32_t cur = start_buf;
+		for (uint32_t s = 1; s <= n_steps; s++, cur ^= 1u)
+		{
+			uint32_t lo = s, hi = L - s;
+			if (h->layout == CA3D_LAYOUT_PACKED32 && h->z0 == 0) lo = K;
+			int r2 = enqueue_step(h, (int)cur, lo, hi, h->stream);
+			if (r2) return r2;
+		}
+		return CA3D_OK;
+	};
+	const bool graphable = h->use_graph && h->stream != nullptr && n_steps > 1 &&
+	                       !(h->layout == CA3D_LAYOUT_UNPACKED && !h->binary_state);
+	if (graphable)
 	{
-		// Valid region shrinks by one plane per side per sub-step. The packed kernel's bottom face is dead
-		// (z == -1 is dropped), so the slab that owns global plane 0 never needs its low ghost.
-		uint32_t lo = s, hi = L - s;
-		if (h->layout == CA3D_LAYOUT_PACKED32 && h->z0 == 0) lo = K;
-		rc = enqueue_step(h, (int)h->cur, lo, hi, h->stream);
-		if (rc) return rc;
-		h->step++;
-		h->cur ^= 1u;
-		planes_done += hi - lo;
+		// one graph launch per batch: the host cost of a K-step batch must stay below its GPU time for the ranks
+		// to scale (8 launches of ~7 us kernels would otherwise be host-bound)
+		const uint64_t key = ((uint64_t)h->cur << 32) | n_steps;
+		auto it = h->slab_graphs.find(key);
+		if (it == h->slab_graphs.end())
+		{
+			hipGraph_t graph = nullptr;
+			HIP_TRY(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+			rc = enqueue_all(h->cur);
+			hipError_t e = hipStreamEndCapture(h->stream, &graph);
+			if (rc != CA3D_OK) { if (graph) hipGraphDestroy(graph); return rc; }
+			if (e != hipSuccess) return fail(CA3D_ERR_DEVICE, "hipStreamEndCapture: %s", hipGetErrorString(e));
+			hipGraphExec_t exec = nullptr;
+			e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+			hipGraphDestroy(graph);
+			if (e != hipSuccess) return fail(CA3D_ERR_DEVICE, "hipGraphInstantiate: %s", hipGetErrorString(e));
+			it = h->slab_graphs.emplace(key, exec).first;
+		}
+		HIP_TRY(hipGraphLaunch(it->second, h->stream));
 	}
+	else
+	{
+		rc = enqueue_all(h->cur);
+		if (rc) return rc;
+	}
+	h->step += n_steps;
+	h->cur = (h->cur + n_steps) & 1u;
+	if (h->layout == CA3D_LAYOUT_UNPACKED) h->binary_state = true;
 	HIP_TRY(hipEventRecord(h->ev_stop, h->stream));
 	h->ev_valid = true;
 	h->stats.steps = n_steps;
 	h->stats.kernel_launches = n_steps;
 	h->stats.cell_steps = (double)n_steps * h->cells_per_plane() * h->nz; // owned cells only: ghost recompute is overhead
 	h->stats.algorithmic_bytes = h->stats.cell_steps * h->bytes_per_cell_step();
-	(void)planes_done;
 	return CA3D_OK;
 }
 

@@ -117,8 +117,10 @@ def device_tensor(ptr: int, nbytes: int, device: int):
 class SlabEngine:
     """One rank's slab on one GPU: an `Engine` in slab mode plus the halo exchange.
 
-    The engine runs on torch's current HIP stream so that RCCL operations posted through torch.distributed are
-    ordered with the step kernels by torch's own stream/event bookkeeping.
+    Engine kernels and RCCL operations are ordered on one dedicated HIP stream: the engine is bound to it
+    (`ca3d_set_stream`) and the torch.distributed calls are issued with it as torch's current stream, so torch's
+    own event bookkeeping serialises "exchange -> K sub-steps -> exchange". A K-step batch is one hipGraph launch
+    (`ca3d_slab_step`), so the host cost per batch is one graph launch plus one grouped send/recv.
     """
 
     def __init__(self, grid_size: int, rank: int, world: int, ghost: int, layout: int = LAYOUT_PACKED32,
@@ -134,21 +136,30 @@ class SlabEngine:
         self.device = device
         self.host_staging = host_staging
         torch.cuda.set_device(device)
+        self.stream = torch.cuda.Stream(device=device)
         self.engine = engine or Engine(device)
         self.engine.configure_slab(grid_size, self.z0, self.nz, ghost, layout)
-        self.engine.set_stream(torch.cuda.current_stream().cuda_stream)
+        self.engine.set_stream(self.stream.cuda_stream)
         self._regions = [None, None]
+        self._parity = 0  # mirrors the engine's current buffer without a round trip per batch
+
+    def upload_state(self, owned_words) -> None:
+        self.engine.upload_state(owned_words)
+        self._parity = 0
 
     def _current_regions(self):
-        parity = self.engine.info().current_buffer
-        if self._regions[parity] is None:
+        if self._regions[self._parity] is None:
+            assert self.engine.info().current_buffer == self._parity
             names = {"send_low": SLAB_SEND_LOW, "send_high": SLAB_SEND_HIGH, "recv_low": SLAB_RECV_LOW,
                      "recv_high": SLAB_RECV_HIGH, "owned": SLAB_OWNED}
-            self._regions[parity] = {k: device_tensor(*self.engine.slab_region(v), self.device) for k, v in names.items()}
-        return self._regions[parity]
+            self._regions[self._parity] = {k: device_tensor(*self.engine.slab_region(v), self.device) for k, v in names.items()}
+        return self._regions[self._parity]
 
     def exchange(self) -> None:
-        exchange_halos(self._current_regions(), self.plan, self.rank, self.group, self.host_staging)
+        import torch
+
+        with torch.cuda.stream(self.stream):
+            exchange_halos(self._current_regions(), self.plan, self.rank, self.group, self.host_staging)
 
     def run(self, n_steps: int) -> None:
         """n CA steps: [exchange ghosts, up to `ghost` sub-steps] repeated. Asynchronous on the GPU."""
@@ -157,6 +168,7 @@ class SlabEngine:
             k = min(self.ghost, left)
             self.exchange()
             self.engine.slab_step(k)
+            self._parity = (self._parity + k) & 1
             left -= k
 
     def close(self) -> None:

@@ -74,7 +74,7 @@ def test_slab_engine_single_rank_uses_product_exchange():
     full = host.random_fill(host.words_per_buffer(G), seed=2)
     se = slab.SlabEngine(G, 0, 1, ghost=4)
     set_rules(se.engine, r)
-    se.engine.upload_state(full)
+    se.upload_state(full)
     se.run(10)
     got = se.engine.read_state()
     se.close()

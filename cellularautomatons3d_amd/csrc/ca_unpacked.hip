@@ -63,10 +63,10 @@ __global__ __launch_bounds__(256) void ca_unpacked_literal(const u32 *__restrict
 	out[idx] = o;
 }
 
-constexpr int kBTY = 32, kBTZ = 16; // tile rows x planes (interior)
+constexpr int kBTY = 32; // tile rows; planes per tile (kBTZ) is a template parameter: 16, or 8 on grids with few tiles // tile rows x planes (interior)
 constexpr int kBThreads = 1024;     // 16 waves per workgroup: the pack / unpack phases are load-latency-bound
 
-template <int MAIN, bool FAST>
+template <int MAIN, bool FAST, int kBTZ>
 __global__ __launch_bounds__(kBThreads) void ca_unpacked_ballot(const u32 *__restrict__ in, u32 *__restrict__ out, PlaneRange pr,
                                                           u32 ny, u32 cv_shift, PackedRuleArgs rules_in)
 {
@@ -81,45 +81,55 @@ __global__ __launch_bounds__(kBThreads) void ca_unpacked_ballot(const u32 *__res
 	u32 *in_bits = lds;
 	u32 *out_bits = lds + RZ * RY * C;
 
-	// ---- phase 1: pack (tile + halo) into bits: one coalesced dword per lane, one ballot per 64 cells.
-	// A wave takes whole rows; the loads of a row (X64 of them, up to 8 at a time) are issued before the ballots.
-	constexpr u32 NW = kBThreads / 64u, RB = 1; // waves per workgroup, rows in flight per wave
-	for (u32 row0 = wave; row0 < RZ * RY; row0 += NW * RB)
+	// ---- phase 1: pack (tile + halo) into bits. Each lane loads 4 cells (one coalesced dwordx4: 1 KiB per wave),
+	// folds them into a nibble, and three lane exchanges gather 8 nibbles into the word the first lane of every
+	// octet writes to LDS. (One __ballot per 64 dword-loaded cells does the same with 4x the load instructions;
+	// the phase is load-latency-bound, so bytes in flight per wave are what counts.)
+	constexpr u32 NW = kBThreads / 64u;
+	const u32 X256 = G / 256u; // dwordx4 wave-loads per row (G >= 256), else the ballot path below
+	if (X256 > 0)
 	{
-		const u32 *src[RB];
-#pragma unroll
-		for (u32 q = 0; q < RB; q++)
+		for (u32 row = wave; row < RZ * RY; row += NW)
 		{
-			const u32 row = row0 + q * NW < RZ * RY ? row0 + q * NW : row0;
 			const u32 zz = row / RY, yy = row - zz * RY;
 			int gy = y0 + (int)yy - 1, gz = z0 + (int)zz - 1;
 			gy = gy < 0 ? gy + (int)G : (gy >= (int)G ? gy - (int)G : gy); // toroidal (power-of-two G)
 			if (pr.wrap_full) gz = gz < 0 ? gz + (int)G : (gz >= (int)G ? gz - (int)G : gz);
 			else gz = gz < 0 ? 0 : (gz >= (int)pr.nplanes ? (int)pr.nplanes - 1 : gz); // slab: ghosts are adjacent planes
-			src[q] = in + (size_t)gz * plane_cells + (size_t)gy * G + lane;
-		}
-		for (u32 x0 = 0; x0 < X64; x0 += 8u)
-		{
-			u32 vals[RB][8];
-#pragma unroll
-			for (u32 q = 0; q < RB; q++)
-#pragma unroll
-				for (int k = 0; k < 8; k++) vals[q][k] = x0 + (u32)k < X64 ? src[q][(x0 + (u32)k) * 64u] : 0u;
-#pragma unroll
-			for (u32 q = 0; q < RB; q++)
+			const uint4 *src = reinterpret_cast<const uint4 *>(in + (size_t)gz * plane_cells + (size_t)gy * G) + lane;
+			u32 *dst = in_bits + row * C + (lane >> 3);
+			for (u32 x0 = 0; x0 < X256; x0 += 4u)
 			{
-				const u32 row = row0 + q * NW;
-				u32 *dst = in_bits + row * C;
+				uint4 vals[4];
 #pragma unroll
-				for (int k = 0; k < 8; k++)
+				for (int k = 0; k < 4; k++) vals[k] = x0 + (u32)k < X256 ? src[(x0 + (u32)k) * 64u] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+				for (int k = 0; k < 4; k++)
 				{
-					const unsigned long long m = __ballot(vals[q][k] != 0u);
-					if (lane == 0 && x0 + (u32)k < X64 && row < RZ * RY)
-					{
-						dst[(x0 + (u32)k) * 2u] = (u32)m;
-						dst[(x0 + (u32)k) * 2u + 1u] = (u32)(m >> 32);
-					}
+					u32 n = (vals[k].x != 0u ? 1u : 0u) | (vals[k].y != 0u ? 2u : 0u) | (vals[k].z != 0u ? 4u : 0u) | (vals[k].w != 0u ? 8u : 0u);
+					n |= (u32)__shfl_down((int)n, 1) << 4;
+					n |= (u32)__shfl_down((int)n, 2) << 8;
+					n |= (u32)__shfl_down((int)n, 4) << 16;
+					if ((lane & 7u) == 0 && x0 + (u32)k < X256) dst[(x0 + (u32)k) * 8u] = n;
 				}
+			}
+		}
+	}
+	else
+	{
+		for (u32 row = wave; row < RZ * RY; row += NW)
+		{
+			const u32 zz = row / RY, yy = row - zz * RY;
+			int gy = y0 + (int)yy - 1, gz = z0 + (int)zz - 1;
+			gy = gy < 0 ? gy + (int)G : (gy >= (int)G ? gy - (int)G : gy);
+			if (pr.wrap_full) gz = gz < 0 ? gz + (int)G : (gz >= (int)G ? gz - (int)G : gz);
+			else gz = gz < 0 ? 0 : (gz >= (int)pr.nplanes ? (int)pr.nplanes - 1 : gz);
+			const u32 *src = in + (size_t)gz * plane_cells + (size_t)gy * G + lane;
+			u32 *dst = in_bits + row * C;
+			for (u32 xc = 0; xc < X64; xc++)
+			{
+				const unsigned long long m = __ballot(src[xc * 64u] != 0u);
+				if (lane == 0) { dst[xc * 2u] = (u32)m; dst[xc * 2u + 1u] = (u32)(m >> 32); }
 			}
 		}
 	}
@@ -161,26 +171,41 @@ __global__ __launch_bounds__(kBThreads) void ca_unpacked_ballot(const u32 *__res
 	}
 	__syncthreads();
 
-	// ---- phase 3: expand bits to one u32 per cell, coalesced dword stores, whole rows per wave
-	for (u32 row = wave; row < kBTZ * kBTY; row += kBThreads / 64u)
+	// ---- phase 3: expand bits to one u32 per cell: 4 cells per lane, coalesced dwordx4 stores, whole rows per wave
+	for (u32 row = wave; row < kBTZ * kBTY; row += NW)
 	{
 		const u32 rz = row / kBTY, ry = row - rz * kBTY;
 		const int gy = y0 + (int)ry, gz = z0 + (int)rz;
 		if (gy >= (int)G || gz >= (int)pr.hi) continue;
-		u32 *dstc = out + (size_t)gz * plane_cells + (size_t)gy * G + lane;
-		const u32 *srcb = out_bits + row * C + (lane >> 5);
-		for (u32 xc = 0; xc < X64; xc++) dstc[xc * 64u] = (srcb[xc * 2u] >> (lane & 31u)) & 1u;
+		u32 *drow = out + (size_t)gz * plane_cells + (size_t)gy * G;
+		if (X256 > 0)
+		{
+			const u32 *srcb = out_bits + row * C + (lane >> 3);
+			const u32 sh = (lane & 7u) * 4u;
+			for (u32 xc = 0; xc < X256; xc++)
+			{
+				const u32 w = srcb[xc * 8u] >> sh;
+				uint4 v;
+				v.x = w & 1u; v.y = (w >> 1) & 1u; v.z = (w >> 2) & 1u; v.w = (w >> 3) & 1u;
+				reinterpret_cast<uint4 *>(drow)[xc * 64u + lane] = v;
+			}
+		}
+		else
+		{
+			const u32 *srcb = out_bits + row * C + (lane >> 5);
+			for (u32 xc = 0; xc < X64; xc++) drow[xc * 64u + lane] = (srcb[xc * 2u] >> (lane & 31u)) & 1u;
+		}
 	}
 }
 
-template <int MAIN, bool FAST>
-hipError_t launch_ballot_f(const UnpackedLaunch &l, hipStream_t stream, const PackedRuleArgs &prog)
+template <int MAIN, bool FAST, int kBTZ>
+hipError_t launch_ballot_fz(const UnpackedLaunch &l, hipStream_t stream, const PackedRuleArgs &prog)
 {
 	const u32 G = l.pr.G, C = G / 32u;
 	const u32 ny = (G + kBTY - 1) / kBTY, nz = (l.pr.hi - l.pr.lo + kBTZ - 1) / kBTZ;
 	const size_t lds_bytes = ((size_t)(kBTZ + 2) * (kBTY + 2) + (size_t)kBTZ * kBTY) * C * sizeof(u32);
 	if (lds_bytes > 160u * 1024u) return hipErrorInvalidValue;
-	auto kern = ca_unpacked_ballot<MAIN, FAST>;
+	auto kern = ca_unpacked_ballot<MAIN, FAST, kBTZ>;
 	u32 cv_shift = 0;
 	while ((1u << cv_shift) < C / 4u) cv_shift++;
 	static bool attr_set = false;
@@ -192,6 +217,14 @@ hipError_t launch_ballot_f(const UnpackedLaunch &l, hipStream_t stream, const Pa
 	}
 	hipLaunchKernelGGL(kern, dim3(ny * nz), dim3(kBThreads), lds_bytes, stream, l.in, l.out, l.pr, ny, cv_shift, prog);
 	return hipGetLastError();
+}
+
+template <int MAIN, bool FAST>
+hipError_t launch_ballot_f(const UnpackedLaunch &l, hipStream_t stream, const PackedRuleArgs &prog)
+{
+	// 16-plane tiles re-read 1.2x (8-plane tiles 1.33x) but need >= 2 workgroups per CU to keep HBM busy
+	const u32 tiles16 = ((l.pr.G + kBTY - 1) / kBTY) * ((l.pr.hi - l.pr.lo + 15u) / 16u);
+	return tiles16 >= 512u ? launch_ballot_fz<MAIN, FAST, 16>(l, stream, prog) : launch_ballot_fz<MAIN, FAST, 8>(l, stream, prog);
 }
 
 template <int MAIN>
@@ -207,7 +240,7 @@ bool ballot_applies(const UnpackedLaunch &l)
 	const u32 G = l.pr.G;
 	if (!l.binary_state || !r.unpacked_fast) return false;
 	if (G < 128u || (G & (G - 1u))) return false; // torus only for power-of-two G; rows of >= 4 words
-	const size_t lds_bytes = ((size_t)(kBTZ + 2) * (kBTY + 2) + (size_t)kBTZ * kBTY) * (G / 32u) * sizeof(u32);
+	const size_t lds_bytes = ((size_t)(16 + 2) * (kBTY + 2) + (size_t)16 * kBTY) * (G / 32u) * sizeof(u32);
 	return lds_bytes <= 160u * 1024u;
 }
 

@@ -417,8 +417,7 @@ hipError_t launch_class(const PackedLaunch &l, hipStream_t stream)
 	g.use_shfl = (g.cv_shift >= 0 && g.CV <= 64u) ? 1u : 0u;
 	// Non-temporal stores (measured, MI355X): 6.9 vs 7.5 us per step at 512^3, but 58 vs 43 us at 1024^3 — they pay
 	// only while both ping-pong buffers sit in the 256 MiB Infinity Cache with room to spare.
-	static const int nt_env = [] { const char *e = getenv("CA3D_NT_STORE"); return e ? atoi(e) : -1; }();
-	const bool nt = nt_env >= 0 ? nt_env != 0 : (size_t)l.pr.nplanes * l.pr.G * C * sizeof(u32) <= (16u << 20); // per buffer, ghosts included
+	const bool nt = (size_t)l.pr.nplanes * l.pr.G * C * sizeof(u32) <= (16u << 20); // per buffer, ghosts included
 	if (nt) g.use_shfl |= 2u; // (sc1 / sc0 sc1 stores were tried too: no gain at either size)
 	const u32 planes = l.pr.hi - l.pr.lo;
 	// z-run of 4 planes per thread once that still leaves >= 4 workgroups per CU; small grids keep 1 plane per

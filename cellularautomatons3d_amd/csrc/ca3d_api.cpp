@@ -616,8 +616,11 @@ int ca3d_get_info(ca3d_t *h, ca3d_info *out)
 	out->device = h->device;
 	const char *name = "";
 	if (h->configured && h->rules.valid)
-		name = h->layout == CA3D_LAYOUT_PACKED32 ? packed_kernel_name(h->rules, h->G, h->variant)
-		                                          : (h->step > 0 && h->kernel_name[0] ? h->kernel_name : "ca_unpacked");
+	{
+		if (h->layout != CA3D_LAYOUT_PACKED32) name = h->step > 0 && h->kernel_name[0] ? h->kernel_name : "ca_unpacked";
+		else if (h->use_fused && !h->slab && packed_fused_steps(h->rules, h->G, h->variant) == 2) name = "ca_packed_fused+ca_packed_class";
+		else name = packed_kernel_name(h->rules, h->G, h->variant);
+	}
 	snprintf(out->kernel_name, sizeof out->kernel_name, "%s", name);
 	return CA3D_OK;
 }

@@ -1,0 +1,29 @@
+#!/bin/bash
+# Collect the per-round evidence on an MI355X box: bench lines, rocprofv3 kernel stats, and the two PMC passes.
+#   tools/profile_round.sh r1_d        (run from the repo root; writes gpurun_out/<tag>_*)
+set -e -o pipefail
+tag=${1:-rX}
+out=$PWD/gpurun_out
+mkdir -p "$out"
+export TMPDIR=/tmp
+B512="bench.py --no-cpu-baseline --no-render --steps 512 --warmup 64"
+B1024="bench.py --no-cpu-baseline --no-render --grid 1024 --steps 128 --warmup 32"
+
+python bench.py > "$out/${tag}_bench512_default.json"
+cat "$out/${tag}_bench512_default.json"
+
+rocprofv3 --output-format csv --kernel-trace --stats -d "$out/${tag}_stats512" -o s -- python $B512 > "$out/${tag}_bench512_under_rocprof.json"
+rocprofv3 --output-format csv --kernel-trace --stats -d "$out/${tag}_stats1024" -o s -- python $B1024 > "$out/${tag}_bench1024_under_rocprof.json"
+rocprofv3 --output-format csv --kernel-trace --stats -d "$out/${tag}_stats_render" -o s -- python bench.py --no-cpu-baseline --steps 64 --warmup 8 > "$out/${tag}_bench_render_under_rocprof.json"
+rocprofv3 --output-format csv --kernel-trace --stats -d "$out/${tag}_stats_clustered" -o s -- python $B512 --rule clustered > "$out/${tag}_bench512_clustered_under_rocprof.json"
+rocprofv3 --output-format csv --kernel-trace --stats -d "$out/${tag}_stats_unpacked" -o s -- python tools/run_unpacked.py > "$out/${tag}_unpacked.log"
+
+rocprofv3 --output-format csv --pmc FETCH_SIZE --kernel-trace -d "$out/${tag}_pmc_fetch512" -o p -- python $B512 > /dev/null
+rocprofv3 --output-format csv --pmc WRITE_SIZE --kernel-trace -d "$out/${tag}_pmc_write512" -o p -- python $B512 > /dev/null
+rocprofv3 --output-format csv --pmc FETCH_SIZE --kernel-trace -d "$out/${tag}_pmc_fetch1024" -o p -- python $B1024 > /dev/null
+rocprofv3 --output-format csv --pmc WRITE_SIZE --kernel-trace -d "$out/${tag}_pmc_write1024" -o p -- python $B1024 > /dev/null
+python tools/pmc_reduce.py "ca_packed_class<vn>@512" ca_packed_class "$out/${tag}_pmc_fetch512" "$out/${tag}_pmc_write512" "$out/${tag}_pmc_traffic.json"
+python tools/pmc_reduce.py "ca_packed_class<vn>@1024" ca_packed_class "$out/${tag}_pmc_fetch1024" "$out/${tag}_pmc_write1024" "$out/${tag}_pmc_traffic.json"
+# keep only summaries: the raw per-dispatch traces are large
+find "$out" -name "*kernel_trace.csv" -delete; find "$out" -name "*counter_collection.csv" -delete; find "$out" -name "*agent_info.csv" -delete
+echo done

@@ -64,6 +64,7 @@ struct CanonRules
 	bool fast = false;                    // the three lists are the named class unions -> class kernels
 	OffsetLists lists{};
 	PackedRuleArgs prog{};
+	uint32_t onset_survive[3]{}, onset_born[3]{}; // bit k: LUT slot k of the rule-set == 1
 	// unpacked layout: main list + slots 0..26 with `> 0`
 	uint32_t unpacked_survive = 0, unpacked_born = 0; // bit k = LUT[k] > 0
 	RuleSetProg unpacked_prog{};                        // the same as cube programs over the main list's count
@@ -131,6 +132,9 @@ hipError_t launch_render(const RenderLaunch &l, hipStream_t stream);
 // ca_packed.hip / ca_unpacked.hip
 hipError_t launch_packed_step(const PackedLaunch &l, hipStream_t stream, const char **kernel_name);
 const char *packed_kernel_name(const CanonRules &r, uint32_t G, int variant);
+// ca_packed_vn.hip: the specialised von Neumann kernel (truth-table rules, power-of-two grids)
+bool vn_kernel_applies(const CanonRules &r, uint32_t G, int variant);
+hipError_t launch_packed_vn(const PackedLaunch &l, hipStream_t stream);
 // Steps one fused launch advances for these rules / grid (0 = no fused kernel applies).
 int packed_fused_steps(const CanonRules &r, uint32_t G, int variant);
 hipError_t launch_packed_fused(const PackedLaunch &l, hipStream_t stream, const char **kernel_name);

@@ -26,7 +26,7 @@ namespace
 
 // Each thread owns one dwordx4 column position (y, cx0..cx0+3) and walks ZR consecutive z-planes with the three
 // planes it needs held in registers, so a plane's rows are fetched once per ZR outputs instead of three times.
-template <int MAIN, bool E, bool C_, int ZR, bool FAST>
+template <int MAIN, bool E, bool C_, int ZR, bool FAST, bool P2>
 __global__ __launch_bounds__(256) void ca_packed_class(const u32 *__restrict__ in, u32 *__restrict__ out,
                                                        PlaneRange pr, TileGeom g, PackedRuleArgs rules_in)
 {
@@ -43,13 +43,14 @@ __global__ __launch_bounds__(256) void ca_packed_class(const u32 *__restrict__ i
 	// eighth of the (z-run, tile) space so z-neighbour planes meet in one XCD's L2.
 	const u32 b = blockIdx.x, nb = gridDim.x;
 	const u32 v = (nb & 7u) == 0 ? (b & 7u) * (nb >> 3) + (b >> 3) : b;
-	u32 zr, tile;
-	if (g.tpp_shift >= 0) { zr = v >> g.tpp_shift; tile = v & (g.tiles_per_plane - 1u); }
+	// P2: power-of-two grid — shifts only, and a row (<= 64 uint4) sits inside one wave, so the words either
+	// side of a segment come from the neighbour lanes. Otherwise: divisions, and two extra dword loads per row.
+	u32 zr, tile, y, cxv;
+	if (P2) { zr = v >> g.tpp_shift; tile = v & (g.tiles_per_plane - 1u); }
 	else { zr = v / g.tiles_per_plane; tile = v - zr * g.tiles_per_plane; }
 	const u32 t = tile * 256u + threadIdx.x;
 	if (t >= pr.G * g.CV) return;
-	u32 y, cxv;
-	if (g.cv_shift >= 0) { y = t >> g.cv_shift; cxv = t & (g.CV - 1u); }
+	if (P2) { y = t >> g.cv_shift; cxv = t & (g.CV - 1u); }
 	else { y = t / g.CV; cxv = t - y * g.CV; }
 	const u32 C = g.CV * 4u, cx0 = cxv * 4u;
 	const u32 plane_words = C * pr.G;
@@ -65,15 +66,17 @@ __global__ __launch_bounds__(256) void ca_packed_class(const u32 *__restrict__ i
 		const int lane = (int)(threadIdx.x & 63u);
 		ps.src_lo = lane - 1;
 		ps.src_hi = cxv + 1 == g.CV ? lane - (int)(g.CV - 1u) : lane + 1;
-		ps.shfl = (g.use_shfl & 1u) != 0;
 	}
 
-	FastRules<MAIN, E, C_> frules;
-	if (FAST) frules = expand_rules<MAIN, E, C_>(rules_in);
-
-	const u32 j0 = pr.lo + zr * ZR;
-	// window plane q holds array plane j0 + q - 1 (q = 0 .. ZR+1); out-of-range ends are clamped / wrapped
-	PlaneRows win[ZR + 2];
+	// The last z-run of a range whose length is not a multiple of ZR is shifted down to end at `hi` (a few planes
+	// are computed twice with identical results) so that the body has no tail guard: any branch here lets the
+	// compiler sink loads behind it and turns one memory round trip into two. The launcher guarantees hi - lo >= ZR.
+	u32 j0 = pr.lo + zr * ZR;
+	if (j0 + ZR > pr.hi) j0 = pr.hi - ZR;
+	// Window plane q holds array plane j0 + q - 1 (q = 0 .. ZR+1); out-of-range ends are clamped / wrapped.
+	// Phase 1 issues EVERY load of the thread back to back with no control flow in between, so one memory round
+	// trip covers them all; phase 2 masks the rows and fetches the edge words from the neighbour lanes.
+	RawRows raw[ZR + 2];
 #pragma unroll
 	for (int q = 0; q < ZR + 2; q++)
 	{
@@ -83,28 +86,68 @@ __global__ __launch_bounds__(256) void ca_packed_class(const u32 *__restrict__ i
 		if (q == 0 && j0 == 0) jq = 0;                                     // only ever used masked (global z == 0)
 		if (jq >= pr.nplanes) jq = (jq == pr.nplanes && pr.wrap_full) ? 0u : pr.nplanes - 1u;
 		const u32 *plane = in + (size_t)jq * plane_words;
-		win[q].c = load_seg<kCenterLR>(plane, ps, 1, 0xFFFFFFFFu);
-		if (kYRows && (is_out || kZYRows))
+		const bool rows = kYRows && (is_out || kZYRows);
+		raw[q].c = *reinterpret_cast<const uint4 *>(plane + ps.off[1]);
+		if (rows)
 		{
-			win[q].ym = load_seg<kYLR>(plane, ps, 0, 0xFFFFFFFFu);
-			win[q].yp = load_seg<kYLR>(plane, ps, 2, 0xFFFFFFFFu);
+			raw[q].ym = *reinterpret_cast<const uint4 *>(plane + ps.off[0]);
+			raw[q].yp = *reinterpret_cast<const uint4 *>(plane + ps.off[2]);
+		}
+		if (!P2)
+		{
+			if (kCenterLR) { raw[q].e[1][0] = plane[ps.row0[1] + ps.lo_rel]; raw[q].e[1][1] = plane[ps.row0[1] + ps.hi_rel]; }
+			if (rows && kYLR)
+			{
+				raw[q].e[0][0] = plane[ps.row0[0] + ps.lo_rel]; raw[q].e[0][1] = plane[ps.row0[0] + ps.hi_rel];
+				raw[q].e[2][0] = plane[ps.row0[2] + ps.lo_rel]; raw[q].e[2][1] = plane[ps.row0[2] + ps.hi_rel];
+			}
 		}
 	}
 
+	FastRules<MAIN, E, C_> frules;
+	if (FAST) frules = expand_rules<MAIN, E, C_>(rules_in);
+
+	PlaneRows win[ZR + 2];
+#pragma unroll
+	for (int q = 0; q < ZR + 2; q++)
+	{
+		const bool is_out = q >= 1 && q <= ZR;
+		if (!kZNbr && !is_out) continue;
+		win[q].c = make_seg<kCenterLR, P2>(raw[q].c, raw[q].e[1], ps, 1);
+		if (kYRows && (is_out || kZYRows))
+		{
+			win[q].ym = make_seg<kYLR, P2>(raw[q].ym, raw[q].e[0], ps, 0);
+			win[q].yp = make_seg<kYLR, P2>(raw[q].yp, raw[q].e[2], ps, 2);
+		}
+	}
+
+	// All results first, then all stores: on gfx9-family targets loads and stores share one counter (vmcnt), so a
+	// store issued between two uses of loaded data makes the later use wait for the store to complete.
 	int zg = global_z(pr, j0);
+	uint4 res[ZR];
 #pragma unroll
 	for (int q = 1; q <= ZR; q++)
 	{
-		const u32 j = j0 + (u32)q - 1u;
-		if (j >= pr.hi) break;
 		const u32 zmask = zg == 0 ? 0u : 0xFFFFFFFFu; // z-1 == -1 is dropped (compute_clustered.wgsl:104)
 		zg = zg + 1 == (int)pr.G ? 0 : zg + 1;
-		uint4 r;
-		if (FAST) r = evolve4<MAIN, E, C_>(win[q - 1], win[q], win[q + 1], zmask, frules);
-		else r = evolve4<MAIN, E, C_>(win[q - 1], win[q], win[q + 1], zmask, rules_in);
-		typedef u32 u32x4 __attribute__((ext_vector_type(4)));
-		if (g.use_shfl & 2u) { u32x4 rv = {r.x, r.y, r.z, r.w}; __builtin_nontemporal_store(rv, reinterpret_cast<u32x4 *>(out + (size_t)j * plane_words + ps.off[1])); }
-		else *reinterpret_cast<uint4 *>(out + (size_t)j * plane_words + ps.off[1]) = r;
+		if (FAST) res[q - 1] = evolve4<MAIN, E, C_>(win[q - 1], win[q], win[q + 1], zmask, frules);
+		else res[q - 1] = evolve4<MAIN, E, C_>(win[q - 1], win[q], win[q + 1], zmask, rules_in);
+	}
+	typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+	u32 *dst = out + (size_t)j0 * plane_words + ps.off[1];
+	if (g.use_shfl & 2u)
+	{
+#pragma unroll
+		for (int q = 0; q < ZR; q++)
+		{
+			const u32x4 rv = {res[q].x, res[q].y, res[q].z, res[q].w};
+			__builtin_nontemporal_store(rv, reinterpret_cast<u32x4 *>(dst + (size_t)q * plane_words));
+		}
+	}
+	else
+	{
+#pragma unroll
+		for (int q = 0; q < ZR; q++) *reinterpret_cast<uint4 *>(dst + (size_t)q * plane_words) = res[q];
 	}
 }
 
@@ -427,13 +470,26 @@ hipError_t launch_class(const PackedLaunch &l, hipStream_t stream)
 	// kernels that need the diagonal rows re-read 9 rows per plane and amortise them over 4 planes (28 us vs 35 us).
 	constexpr bool kDiagonals = E || C_ || MAIN == MAIN_MOORE || MAIN == MAIN_EDGES || MAIN == MAIN_CORNERS;
 	constexpr int ZRUN = kDiagonals ? 4 : 2;
-	const bool deep = (size_t)g.tiles_per_plane * ((planes + ZRUN - 1u) / ZRUN) >= 1024u;
+	const bool deep = (size_t)g.tiles_per_plane * ((planes + ZRUN - 1u) / ZRUN) >= 1024u && planes >= (u32)ZRUN;
 	const bool fast = rules_fit_fast(*l.rules);
 	const dim3 grid_deep(g.tiles_per_plane * ((planes + ZRUN - 1u) / ZRUN)), grid_flat(g.tiles_per_plane * planes);
-	if (deep && fast) hipLaunchKernelGGL((ca_packed_class<MAIN, E, C_, ZRUN, true>), grid_deep, dim3(256), 0, stream, l.in, l.out, l.pr, g, l.rules->prog);
-	else if (deep) hipLaunchKernelGGL((ca_packed_class<MAIN, E, C_, ZRUN, false>), grid_deep, dim3(256), 0, stream, l.in, l.out, l.pr, g, l.rules->prog);
-	else if (fast) hipLaunchKernelGGL((ca_packed_class<MAIN, E, C_, 1, true>), grid_flat, dim3(256), 0, stream, l.in, l.out, l.pr, g, l.rules->prog);
-	else hipLaunchKernelGGL((ca_packed_class<MAIN, E, C_, 1, false>), grid_flat, dim3(256), 0, stream, l.in, l.out, l.pr, g, l.rules->prog);
+	const bool p2 = (g.use_shfl & 1u) != 0;
+#define CA3D_LAUNCH_CLASS(ZR_, FAST_, P2_, GRID_) \
+	hipLaunchKernelGGL((ca_packed_class<MAIN, E, C_, ZR_, FAST_, P2_>), GRID_, dim3(256), 0, stream, l.in, l.out, l.pr, g, l.rules->prog)
+	if (p2)
+	{
+		if (deep && fast) CA3D_LAUNCH_CLASS(ZRUN, true, true, grid_deep);
+		else if (deep) CA3D_LAUNCH_CLASS(ZRUN, false, true, grid_deep);
+		else if (fast) CA3D_LAUNCH_CLASS(1, true, true, grid_flat);
+		else CA3D_LAUNCH_CLASS(1, false, true, grid_flat);
+	}
+	else
+	{
+		// non-power-of-two grids (G = 384, 640, ...): one variant per rule shape is enough
+		if (fast) CA3D_LAUNCH_CLASS(1, true, false, grid_flat);
+		else CA3D_LAUNCH_CLASS(1, false, false, grid_flat);
+	}
+#undef CA3D_LAUNCH_CLASS
 	return hipGetLastError();
 }
 
@@ -456,6 +512,7 @@ bool use_class_kernel(const CanonRules &r, uint32_t G, int variant)
 
 const char *packed_kernel_name(const CanonRules &r, uint32_t G, int variant)
 {
+	if (vn_kernel_applies(r, G, variant)) return "ca_packed_vn";
 	if (!use_class_kernel(r, G, variant)) return "ca_packed_generic";
 	static const char *names[6][4] = {
 	    {"ca_packed_class<vn>", "ca_packed_class<vn,E>", "ca_packed_class<vn,C>", "ca_packed_class<vn,E,C>"},
@@ -494,6 +551,7 @@ hipError_t launch_packed_step(const PackedLaunch &l, hipStream_t stream, const c
 	const CanonRules &r = *l.rules;
 	if (kernel_name) *kernel_name = packed_kernel_name(r, l.pr.G, l.variant);
 	if (l.pr.hi <= l.pr.lo) return hipSuccess;
+	if (vn_kernel_applies(r, l.pr.G, l.variant)) return launch_packed_vn(l, stream);
 	if (use_class_kernel(r, l.pr.G, l.variant))
 	{
 		switch (r.main)

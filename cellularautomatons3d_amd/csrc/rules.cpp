@@ -176,6 +176,8 @@ int canonicalize_rules(const int32_t *main_offs, uint32_t n_main, const int32_t 
 			if (born[k + 27 * s] == 1u) b |= 1u << k;
 			if (survive[k + 27 * s] == 1u) v |= 1u << k;
 		}
+		r.onset_born[s] = b;
+		r.onset_survive[s] = v;
 		compile_rule_prog(b, r.lists.n[s], &r.prog.set[s].born);
 		compile_rule_prog(v, r.lists.n[s], &r.prog.set[s].survive);
 		r.need[s] = r.prog.set[s].born.n != 0 || r.prog.set[s].survive.n != 0;

@@ -13,6 +13,7 @@ RULESETS = {
     "corners_main": dict(neighbourhood="corners", born="1", survive="0-8", survive_edges="0", born_corners="8"),
     "moore_wide": dict(neighbourhood="moore", born="13-14,17-19", survive="13-26", born_edges="0", survive_corners="0"),
     "moore_b4s4": dict(neighbourhood="moore", born="4", survive="4"),
+    "vn_b24_s135": dict(neighbourhood="von neumann", born="2,4", survive="1,3,5"),
     "vn_edges_only": dict(neighbourhood="von neumann", born="2", survive="1-3", born_edges="3-4", survive_edges="2"),
     "vn_corners_only": dict(neighbourhood="von neumann", born="2", survive="1-3", born_corners="1", survive_corners="2,4"),
 }

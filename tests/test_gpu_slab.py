@@ -56,6 +56,17 @@ def test_packed_slabs_equal_full_grid(P, K, steps, name):
     np.testing.assert_array_equal(got, ol.packed_run(G, full, r, steps))
 
 
+@pytest.mark.parametrize("name", ["default", "vn_b24_s135", "clustered"])
+def test_packed_slabs_512_two_planes_per_thread(name):
+    """512^3 slabs run the kernels' 2 / 4-planes-per-thread variants over plane ranges of every parity (the
+    shrinking ghost zones): the shifted last z-run must reproduce the full grid."""
+    G, P, K, steps = 512, 4, 3, 7
+    r = rules(name)
+    full = host.random_fill(host.words_per_buffer(G), seed=5)
+    got = _run_slabs(G, P, K, steps, r, LAYOUT_PACKED32, full)
+    np.testing.assert_array_equal(got, ol.packed_run(G, full, r, steps))
+
+
 @pytest.mark.parametrize("G", [32, 128])
 def test_unpacked_slabs_equal_full_grid(G):
     P, K, steps = 2, 2, 5
@@ -123,4 +134,4 @@ def test_bench_two_ranks_on_one_gpu_gloo_rehearsal():
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["oracle_match"] is True and d["scaling"] == "strong"
-    assert d["roofline"]["kernel"].startswith("ca_packed_class")
+    assert d["roofline"]["kernel"] == "ca_packed_vn"

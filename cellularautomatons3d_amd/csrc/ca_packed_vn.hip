@@ -36,7 +36,7 @@ constexpr int kDppWaveShl1 = 0x130; // lane i <- lane i + 1
 constexpr int kDppWaveRol1 = 0x134; // lane i <- lane (i + 1) % 64
 constexpr int kDppWaveShr1 = 0x138; // lane i <- lane i - 1
 template <int CTRL>
-__device__ __forceinline__ u32 dpp_mov(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false); }
+__device__ __forceinline__ u32 dpp_mov(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true); }
 
 // Word 0 of the lane that starts this lane's row (CV lanes per row), valid in the row's last lane.
 template <int CVL>
@@ -83,39 +83,36 @@ __global__ __launch_bounds__(256) void ca_packed_vn(const u32 *__restrict__ in, 
 	const u32 v = (nb & 7u) == 0 ? (b & 7u) * (nb >> 3) + (b >> 3) : b;
 	const u32 zr = v / TPP, tile = v % TPP;
 	const u32 t = tile * 256u + threadIdx.x; // uint4 index inside a plane = y * CV + cxv
-	u32 j0 = a.lo + zr * ZR;
-	if (j0 + ZR > a.hi) j0 = a.hi - ZR; // last run of an odd range overlaps the one before (same results twice)
+	// first output plane of this thread; the last run of an odd range is shifted down to end at `hi` (the overlap
+	// is computed twice with identical results) so that the body has no tail guard
+	const u32 j0 = min(a.lo + zr * ZR, a.hi - ZR);
+
+	// Scalar plane bases. Own planes j0 .. j0+ZR-1 are always inside the array; only the plane below the run
+	// (clamped at plane 0, where it is only ever read masked: global z == 0) and the plane above it (wraps to
+	// plane 0 on the full grid, clamps on the last plane of a slab, whose top ghost is never a valid output) need care.
+	const char *own = reinterpret_cast<const char *>(in) + (size_t)j0 * PLANE_BYTES;
+	const char *below = own - (j0 != 0 ? PLANE_BYTES : 0u);
+	const char *above = j0 + ZR < a.nplanes ? own + (size_t)ZR * PLANE_BYTES
+	                                        : (a.wrap_full ? reinterpret_cast<const char *>(in) : own + (size_t)(ZR - 1) * PLANE_BYTES);
+	const u32 zg0 = (u32)(a.zbase + (int)j0) & (G - 1u); // global z of plane j0
 
 	// row offsets in bytes: y-1 (clamped: masked when y == 0), y, y+1 (wraps to row 0)
 	const u32 oc = t * 16u;
-	const u32 om = (t < CV ? t : t - CV) * 16u;
-	const u32 op = ((t + CV) & (PLANE - 1u)) * 16u;
+	const u32 om = (u32)max((int)oc - (int)(CV * 16u), 0);
+	const u32 op = (oc + CV * 16u) & (PLANE_BYTES - 1u);
 
 	// every load of the thread, back to back, in the order the planes are consumed
 	uint4 c[ZR + 2], m[ZR], p[ZR];
-	int zg0;
-	{
-		zg0 = a.zbase + (int)j0;
-		if (zg0 < 0) zg0 += (int)G;
-		if (zg0 >= (int)G) zg0 -= (int)G;
-	}
-	const char *plane[ZR + 2];
-#pragma unroll
-	for (int q = 0; q < ZR + 2; q++)
-	{
-		u32 jq = j0 + (u32)q - 1u;
-		if (q == 0 && j0 == 0) jq = 0; // only ever used masked (global z == 0)
-		if (jq >= a.nplanes) jq = (jq == a.nplanes && a.wrap_full) ? 0u : a.nplanes - 1u;
-		plane[q] = reinterpret_cast<const char *>(in) + (size_t)jq * PLANE_BYTES;
-	}
-	c[0] = *reinterpret_cast<const uint4 *>(plane[0] + oc);
-	c[1] = *reinterpret_cast<const uint4 *>(plane[1] + oc);
+	c[0] = *reinterpret_cast<const uint4 *>(below + oc);
+	c[1] = *reinterpret_cast<const uint4 *>(own + oc);
 #pragma unroll
 	for (int q = 1; q <= ZR; q++)
 	{
-		m[q - 1] = *reinterpret_cast<const uint4 *>(plane[q] + om);
-		p[q - 1] = *reinterpret_cast<const uint4 *>(plane[q] + op);
-		c[q + 1] = *reinterpret_cast<const uint4 *>(plane[q + 1] + oc);
+		const char *pl = own + (size_t)(q - 1) * PLANE_BYTES;
+		m[q - 1] = *reinterpret_cast<const uint4 *>(pl + om);
+		p[q - 1] = *reinterpret_cast<const uint4 *>(pl + op);
+		c[q + 1] = *reinterpret_cast<const uint4 *>((q < ZR ? pl + PLANE_BYTES : above) + oc);
+		__builtin_amdgcn_sched_barrier(0); // keep the issue order: plane q's inputs land before plane q+1's
 	}
 
 	const int lane = (int)(threadIdx.x & 63u);
@@ -124,19 +121,33 @@ __global__ __launch_bounds__(256) void ca_packed_vn(const u32 *__restrict__ in, 
 	u32 lomask = cxv == 0 ? 0u : 0xFFFFFFFFu; // x-1 is dead at x == 0
 	asm volatile("" : "+v"(ymask), "+v"(lomask)); // keep them masks (v_and), not per-word selects
 	const bool last = cxv == CV - 1u;
+	// Only the wave that holds row 0 of a plane has a dead y-1 row and only plane z == 0 a dead z-1 plane: both
+	// are handled under wave-uniform branches (the empty asm keeps the compiler from turning them back into
+	// per-word selects), so all other waves spend no VALU on boundary masks.
+	const bool wave_has_row0 = __builtin_amdgcn_readfirstlane((int)t) < 64;
 
 	u32 cnt[ZR * 4][3], self[ZR * 4];
-	int zg = zg0;
 #pragma unroll
 	for (int q = 1; q <= ZR; q++)
 	{
-		const u32 zmask = zg == 0 ? 0u : 0xFFFFFFFFu; // z-1 == -1 is dropped (compute_clustered.wgsl:104)
-		zg = zg + 1 == (int)G ? 0 : zg + 1;
+		const bool below_dead = ((zg0 + (u32)q - 1u) & (G - 1u)) == 0u; // z-1 == -1 is dropped (compute_clustered.wgsl:104)
 		const u32 w[4] = {c[q].x, c[q].y, c[q].z, c[q].w};
-		const u32 wm[4] = {m[q - 1].x, m[q - 1].y, m[q - 1].z, m[q - 1].w};
+		u32 wm[4] = {m[q - 1].x, m[q - 1].y, m[q - 1].z, m[q - 1].w};
 		const u32 wp[4] = {p[q - 1].x, p[q - 1].y, p[q - 1].z, p[q - 1].w};
-		const u32 wb[4] = {c[q - 1].x, c[q - 1].y, c[q - 1].z, c[q - 1].w};
+		u32 wb[4] = {c[q - 1].x, c[q - 1].y, c[q - 1].z, c[q - 1].w};
 		const u32 wa[4] = {c[q + 1].x, c[q + 1].y, c[q + 1].z, c[q + 1].w};
+		if (__builtin_expect(wave_has_row0, 0))
+		{
+			asm volatile("");
+#pragma unroll
+			for (int i = 0; i < 4; i++) wm[i] &= ymask;
+		}
+		if (__builtin_expect(below_dead, 0))
+		{
+			asm volatile("");
+#pragma unroll
+			for (int i = 0; i < 4; i++) wb[i] = 0u;
+		}
 		const u32 lo = dpp_mov<kDppWaveShr1>(w[3]) & lomask;
 		const u32 nxt = dpp_mov<kDppWaveShl1>(w[0]);
 		// both sources are taken with every lane active (a DPP move cannot read a lane that EXEC has switched
@@ -148,7 +159,7 @@ __global__ __launch_bounds__(256) void ca_packed_vn(const u32 *__restrict__ in, 
 		{
 			const u32 l = from_left(w[i], i ? w[i > 0 ? i - 1 : 0] : lo);
 			const u32 r = from_right(i < 3 ? w[i < 3 ? i + 1 : 0] : hi, w[i]);
-			sum6(l, r, wp[i], wm[i] & ymask, wa[i], wb[i] & zmask, cnt[(q - 1) * 4 + i]);
+			sum6(l, r, wp[i], wm[i], wa[i], wb[i], cnt[(q - 1) * 4 + i]);
 			self[(q - 1) * 4 + i] = w[i];
 		}
 	}
@@ -190,7 +201,7 @@ __global__ __launch_bounds__(256) void ca_packed_vn(const u32 *__restrict__ in, 
 
 // Tables with a pre-built specialisation: the reference UI's start-up rule, von Neumann B1,3 / S0-6
 // (survive slots 0..6, born slots 1 and 3 of the main rule-set).
-constexpr int kDefaultS = 0x7F, kDefaultB = 0x0A;
+constexpr int kDefaultS = 0xFF, kDefaultB = 0x0A; // canonical form: see launch_packed_vn
 
 template <int CVL, int ZR>
 hipError_t launch(const PackedLaunch &l, const VnArgs &a, hipStream_t stream)
@@ -235,8 +246,12 @@ hipError_t launch_packed_vn(const PackedLaunch &l, hipStream_t stream)
 	const int cvl = log2_exact(G / 128u);
 	VnArgs a;
 	a.lo = l.pr.lo; a.hi = l.pr.hi; a.nplanes = l.pr.nplanes; a.wrap_full = l.pr.wrap_full; a.zbase = l.pr.zbase;
+	// Entry 7 of a table is never read (a cell has at most 6 von Neumann neighbours): give it the value that makes
+	// the table constant when the other seven agree, so the specialised kernels can drop the evaluation.
 	a.lut_s = r.onset_survive[0] & 0x7Fu;
 	a.lut_b = r.onset_born[0] & 0x7Fu;
+	if (a.lut_s == 0x7Fu) a.lut_s = 0xFFu;
+	if (a.lut_b == 0x7Fu) a.lut_b = 0xFFu;
 	// Non-temporal stores pay only while both ping-pong buffers sit in the 256 MiB Infinity Cache with room to
 	// spare (measured: 6.9 vs 7.5 us per step at 512^3, 58 vs 43 us at 1024^3).
 	a.nt = (size_t)l.pr.nplanes * G * (G / 32u) * sizeof(u32) <= (16u << 20) ? 1u : 0u;

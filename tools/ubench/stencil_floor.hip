@@ -18,7 +18,7 @@ __device__ __forceinline__ void ST(uint4 *p, uint4 v, int nt)
 	if (nt) { u32x4 r = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(r, reinterpret_cast<u32x4 *>(p)); }
 	else *p = v;
 }
-template <int ZR, int YM, int ZH, int NTH>
+template <int ZR, int YM, int ZH, int NTH, int NV = 0>
 __global__ __launch_bounds__(NTH) void k(const uint4 *__restrict__ in, uint4 *__restrict__ out, const uint4 *__restrict__ extra, u32 G, int nt, int nostore)
 {
 	const u32 CV = G / 128, rows_per_block = NTH / CV;
@@ -49,6 +49,20 @@ __global__ __launch_bounds__(NTH) void k(const uint4 *__restrict__ in, uint4 *__
 		if (YM == 2) r[q] = X(r[q], X(DP<0x114>(c[q]), DP<0x104>(c[q]))); // row_shr:4, row_shl:4
 		if (ZH || ZR > 1) r[q] = X(r[q], X(q ? c[q > 0 ? q - 1 : 0] : (ZH ? lo : c[0]), q + 1 < ZR ? c[q + 1 < ZR ? q + 1 : 0] : (ZH ? hi : c[0])));
 	}
+	if (NV > 0)
+	{
+		// NV dependent-in-pairs VALU ops per output word, like the adder trees of the real kernel
+#pragma unroll
+		for (int q = 0; q < ZR; q++)
+		{
+			u32 w[4] = {r[q].x, r[q].y, r[q].z, r[q].w};
+#pragma unroll
+			for (int n = 0; n < NV; n++)
+#pragma unroll
+				for (int i = 0; i < 4; i++) w[i] = __builtin_amdgcn_bitop3_b32(w[i], w[(i + 1) & 3], c[q].x, 0x96);
+			r[q] = make_uint4(w[0], w[1], w[2], w[3]);
+		}
+	}
 	if (nostore)
 	{
 		u32 acc = 0;
@@ -59,7 +73,7 @@ __global__ __launch_bounds__(NTH) void k(const uint4 *__restrict__ in, uint4 *__
 #pragma unroll
 	for (int q = 0; q < ZR; q++) ST(out + (z + q) * plane + y * CV + cx, r[q], nt);
 }
-template <int ZR, int YM, int ZH, int NTH> void run(u32 G, int nt, int nostore)
+template <int ZR, int YM, int ZH, int NTH, int NV = 0> void run(u32 G, int nt, int nostore)
 {
 	const size_t bytes = (size_t)G * G * G / 8;
 	uint4 *a, *b, *c;
@@ -70,7 +84,7 @@ template <int ZR, int YM, int ZH, int NTH> void run(u32 G, int nt, int nostore)
 	const int blocks = (int)(threads / NTH);
 	hipGraph_t g; hipGraphExec_t ge;
 	hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
-	for (int i = 0; i < 64; i++) hipLaunchKernelGGL((k<ZR, YM, ZH, NTH>), dim3(blocks), dim3(NTH), 0, s, (i & 1) ? b : a, (i & 1) ? a : b, c, G, nt, nostore);
+	for (int i = 0; i < 64; i++) hipLaunchKernelGGL((k<ZR, YM, ZH, NTH, NV>), dim3(blocks), dim3(NTH), 0, s, (i & 1) ? b : a, (i & 1) ? a : b, c, G, nt, nostore);
 	hipStreamEndCapture(s, &g);
 	hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
 	for (int w = 0; w < 4; w++) hipGraphLaunch(ge, s);
@@ -83,7 +97,7 @@ template <int ZR, int YM, int ZH, int NTH> void run(u32 G, int nt, int nostore)
 	float ms; hipEventElapsedTime(&ms, e0, e1);
 	static const char *ymn[] = {"y rows loaded", "y by bpermute", "y by DPP", "no y"};
 	const int loads = ZR * (YM == 0 ? 3 : 1) + (ZH ? 2 : 0);
-	printf("G %4u ZR %d %-14s zhalo %d block %4d (%2d loads / %d outputs) nostore %d: %6.2f us\n", G, ZR, ymn[YM], ZH, NTH, loads, ZR, nostore, ms * 1e3 / (16 * 64));
+	printf("G %4u ZR %d %-14s zhalo %d block %4d (%2d loads / %d outputs) valu/word %3d nostore %d: %6.2f us\n", G, ZR, ymn[YM], ZH, NTH, loads, ZR, NV, nostore, ms * 1e3 / (16 * 64));
 	hipFree(a); hipFree(b); hipFree(c); hipStreamDestroy(s);
 }
 template <int ZR, int NTH> void family(u32 G, int nt, int nostore)
@@ -96,10 +110,30 @@ template <int ZR, int NTH> void family(u32 G, int nt, int nostore)
 	run<ZR, 1, 0, NTH>(G, nt, nostore);
 	run<ZR, 3, 0, NTH>(G, nt, nostore);
 }
+template <int NTH> void valu_family(u32 G, int nt)
+{
+	run<2, 0, 1, NTH, 0>(G, nt, 0);
+	run<2, 0, 1, NTH, 4>(G, nt, 0);
+	run<2, 0, 1, NTH, 8>(G, nt, 0);
+	run<2, 0, 1, NTH, 12>(G, nt, 0);
+	run<2, 0, 1, NTH, 16>(G, nt, 0);
+	run<2, 0, 1, NTH, 24>(G, nt, 0);
+}
 int main(int argc, char **argv)
 {
 	const u32 G = argc > 1 ? (u32)atoi(argv[1]) : 512u;
 	const int nt = G <= 512;
+	if (argc > 2)
+	{
+		valu_family<64>(G, nt);
+		valu_family<128>(G, nt);
+		valu_family<256>(G, nt);
+		valu_family<512>(G, nt);
+		run<1, 0, 1, 256, 16>(G, nt, 0);
+		run<4, 0, 1, 256, 16>(G, nt, 0);
+		return 0;
+	}
+
 	for (int nostore = 0; nostore < 2; nostore++)
 	{
 		for (int rep = 0; rep < 2; rep++)

@@ -13,6 +13,7 @@ LAYOUT_UNPACKED = 1
 LUT_LEN = 81
 
 SLAB_SEND_LOW, SLAB_SEND_HIGH, SLAB_RECV_LOW, SLAB_RECV_HIGH, SLAB_OWNED = range(5)
+SLAB_PHASE_ALL, SLAB_PHASE_EDGES, SLAB_PHASE_INTERIOR = range(3)
 
 
 class Ca3dError(RuntimeError):
@@ -61,6 +62,7 @@ SYMBOLS = [
     ("ca3d_read_state", C.c_int, [_H, _u32p, C.c_size_t]),
     ("ca3d_step", C.c_int, [_H, C.c_uint32]),
     ("ca3d_slab_step", C.c_int, [_H, C.c_uint32]),
+    ("ca3d_slab_step_phase", C.c_int, [_H, C.c_uint32, C.c_int]),
     ("ca3d_slab_region", C.c_int, [_H, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     ("ca3d_synchronize", C.c_int, [_H]),
     ("ca3d_set_stream", C.c_int, [_H, C.c_void_p]),

@@ -68,7 +68,8 @@ struct ca3d_engine
 	// hipGraph of an even number of full-grid steps starting from buffer 0 (invalidated on any change)
 	hipGraphExec_t graph_exec = nullptr;
 	uint32_t graph_steps = 0, graph_launches = 0;
-	std::map<uint64_t, hipGraphExec_t> slab_graphs; // (start buffer, sub-steps) -> captured slab batch
+	std::map<uint64_t, hipGraphExec_t> slab_graphs; // (phase, start buffer, sub-steps) -> captured slab batch
+	uint32_t pending_edges = 0;                     // sub-steps of an edge phase awaiting its interior phase
 
 	ca3d_stats stats{};
 	const char *kernel_name = "";
@@ -157,8 +158,9 @@ int allocate(ca3d_engine *h)
 	return CA3D_OK;
 }
 
-// One launch reading buffer `src` over output planes [lo, hi): a single step, or a fused multi-step pass.
-int enqueue_step(ca3d_engine *h, int src, uint32_t lo, uint32_t hi, hipStream_t s, bool fused = false)
+// One launch reading buffer `src` over output planes [lo, hi) (plus [lo2, hi2) when given: the packed class kernels
+// take both ranges in one launch): a single step, or a fused multi-step pass.
+int enqueue_step(ca3d_engine *h, int src, uint32_t lo, uint32_t hi, hipStream_t s, bool fused = false, uint32_t lo2 = 0, uint32_t hi2 = 0)
 {
 	PlaneRange pr;
 	pr.G = h->G;
@@ -170,6 +172,8 @@ int enqueue_step(ca3d_engine *h, int src, uint32_t lo, uint32_t hi, hipStream_t 
 	hipError_t e;
 	if (h->layout == CA3D_LAYOUT_PACKED32)
 	{
+		pr.lo2 = lo2;
+		pr.hi2 = hi2;
 		PackedLaunch l{h->buf[src], h->buf[src ^ 1], pr, &h->rules, h->variant};
 		e = fused ? launch_packed_fused(l, s, &h->kernel_name) : launch_packed_step(l, s, &h->kernel_name);
 	}
@@ -177,6 +181,12 @@ int enqueue_step(ca3d_engine *h, int src, uint32_t lo, uint32_t hi, hipStream_t 
 	{
 		UnpackedLaunch l{h->buf[src], h->buf[src ^ 1], pr, &h->rules, h->binary_state && h->variant == 0};
 		e = launch_unpacked_step(l, s, &h->kernel_name);
+		if (e == hipSuccess && hi2 > lo2)
+		{
+			l.pr.lo = lo2;
+			l.pr.hi = hi2;
+			e = launch_unpacked_step(l, s, &h->kernel_name);
+		}
 		h->binary_state = true; // the kernel writes only 0 / 1 (compute.wgsl:160-174)
 	}
 	if (e != hipSuccess) return fail(CA3D_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(e));
@@ -471,37 +481,61 @@ int ca3d_step(ca3d_t *h, uint32_t n_steps)
 	return CA3D_OK;
 }
 
-int ca3d_slab_step(ca3d_t *h, uint32_t n_steps)
+// Slab batch of n sub-steps, whole or in two phases (include/ca3d.h). Array planes: ghost [0,K), owned [K,K+nz),
+// ghost [K+nz, L). Sub-step s (1..n) of the whole batch updates [s, L-s). The phased form splits that range:
+//   low edge   [s, 2K+n-s)          ends at s = n as [n, 2K): covers the planes sent down, [K, 2K)
+//   high edge  [L-2K-n+s, L-s)      ends as [L-2K, L-n): covers the planes sent up, [nz, nz+K)
+//   interior   [2K+n-s, L-2K-n+s)   grows by one plane per side per sub-step
+// Each edge chain reads only its own previous sub-step; both zones go into ONE launch per sub-step (the packed
+// class kernels take two output ranges: a second stream with fork / join events inside the captured graph cost
+// ~40 us of host time per graph launch). The interior reads one plane of each edge per sub-step, which the edge
+// chains — finished first — never overwrite afterwards (their ranges shrink).
+int slab_batch(ca3d_engine *h, uint32_t n_steps, int phase)
 {
 	int rc = check_ready(h);
 	if (rc) return rc;
 	if (!h->slab) return fail(CA3D_ERR_INVALID_ARGUMENT, "engine is not a slab: use ca3d_step");
 	if (n_steps > h->ghost) return fail(CA3D_ERR_INVALID_ARGUMENT, "%u sub-steps exceed the ghost depth %u", n_steps, h->ghost);
+	if (phase == CA3D_SLAB_PHASE_EDGES && h->pending_edges) return fail(CA3D_ERR_INVALID_ARGUMENT, "edge phase issued twice: the interior phase must follow");
+	if (phase == CA3D_SLAB_PHASE_INTERIOR && h->pending_edges != n_steps) return fail(CA3D_ERR_INVALID_ARGUMENT, "interior phase of %u sub-steps does not follow an edge phase of the same length", n_steps);
+	if (phase == CA3D_SLAB_PHASE_ALL && h->pending_edges) return fail(CA3D_ERR_INVALID_ARGUMENT, "an edge phase is pending: finish it with the interior phase");
 	rc = bind_device(h);
 	if (rc) return rc;
 	if (n_steps == 0) return CA3D_OK;
-	HIP_TRY(hipEventRecord(h->ev_start, h->stream));
-	const uint32_t L = h->nplanes, K = h->ghost;
-	// Valid region shrinks by one plane per side per sub-step. The packed kernel's bottom face is dead (z == -1 is
-	// dropped), so the slab that owns global plane 0 never needs its low ghost.
+	const uint32_t L = h->nplanes, K = h->ghost, n = n_steps;
+	// The packed kernel's bottom face is dead (z == -1 is dropped): the slab that owns global plane 0 never needs
+	// its low ghost.
+	const uint32_t lo_floor = (h->layout == CA3D_LAYOUT_PACKED32 && h->z0 == 0) ? K : 0u;
+	const bool splittable = h->nz + 2u > 2u * K + 2u * n; // interior non-empty in every sub-step
+	if (phase != CA3D_SLAB_PHASE_INTERIOR) HIP_TRY(hipEventRecord(h->ev_start, h->stream));
+	int what = phase; // what this call enqueues
+	if (!splittable)
+	{
+		// thin slab: the edge phase does the whole batch, the interior phase only commits it
+		what = phase == CA3D_SLAB_PHASE_INTERIOR ? -1 : CA3D_SLAB_PHASE_ALL;
+	}
 	auto enqueue_all = [&](uint32_t start_buf) -> int {
 		uint32_t cur = start_buf;
-		for (uint32_t s = 1; s <= n_steps; s++, cur ^= 1u)
+		for (uint32_t s = 1; s <= n; s++, cur ^= 1u)
 		{
-			uint32_t lo = s, hi = L - s;
-			if (h->layout == CA3D_LAYOUT_PACKED32 && h->z0 == 0) lo = K;
-			int r2 = enqueue_step(h, (int)cur, lo, hi, h->stream);
+			const uint32_t lo = s > lo_floor ? s : lo_floor, hi = L - s;
+			const uint32_t e_lo = 2u * K + n - s, e_hi = L - 2u * K - n + s;
+			int r2 = CA3D_OK;
+			if (what == CA3D_SLAB_PHASE_ALL) r2 = enqueue_step(h, (int)cur, lo, hi, h->stream);
+			else if (what == CA3D_SLAB_PHASE_INTERIOR) r2 = enqueue_step(h, (int)cur, e_lo, e_hi, h->stream);
+			else r2 = enqueue_step(h, (int)cur, lo, e_lo, h->stream, false, e_hi, hi); // both edge zones, one launch
 			if (r2) return r2;
 		}
 		return CA3D_OK;
 	};
-	const bool graphable = h->use_graph && h->stream != nullptr && n_steps > 1 &&
+	const bool graphable = h->use_graph && h->stream != nullptr && n > 1 &&
 	                       !(h->layout == CA3D_LAYOUT_UNPACKED && !h->binary_state);
-	if (graphable)
+	if (what < 0) { /* nothing to enqueue */ }
+	else if (graphable)
 	{
 		// one graph launch per batch: the host cost of a K-step batch must stay below its GPU time for the ranks
 		// to scale (8 launches of ~7 us kernels would otherwise be host-bound)
-		const uint64_t key = ((uint64_t)h->cur << 32) | n_steps;
+		const uint64_t key = ((uint64_t)what << 40) | ((uint64_t)h->cur << 32) | n;
 		auto it = h->slab_graphs.find(key);
 		if (it == h->slab_graphs.end())
 		{
@@ -524,23 +558,38 @@ int ca3d_slab_step(ca3d_t *h, uint32_t n_steps)
 		rc = enqueue_all(h->cur);
 		if (rc) return rc;
 	}
-	h->step += n_steps;
-	h->cur = (h->cur + n_steps) & 1u;
 	if (h->layout == CA3D_LAYOUT_UNPACKED) h->binary_state = true;
+	if (phase == CA3D_SLAB_PHASE_EDGES)
+	{
+		h->pending_edges = n; // ca3d_slab_region now refers to the buffer the batch ends in
+		return CA3D_OK;
+	}
+	h->pending_edges = 0;
+	h->step += n;
+	h->cur = (h->cur + n) & 1u;
 	HIP_TRY(hipEventRecord(h->ev_stop, h->stream));
 	h->ev_valid = true;
-	h->stats.steps = n_steps;
-	h->stats.kernel_launches = n_steps;
-	h->stats.cell_steps = (double)n_steps * h->cells_per_plane() * h->nz; // owned cells only: ghost recompute is overhead
+	h->stats.steps = n;
+	h->stats.kernel_launches = phase == CA3D_SLAB_PHASE_ALL || !splittable ? n : 2u * n;
+	h->stats.cell_steps = (double)n * h->cells_per_plane() * h->nz; // owned cells only: ghost recompute is overhead
 	h->stats.algorithmic_bytes = h->stats.cell_steps * h->bytes_per_cell_step();
 	return CA3D_OK;
+}
+
+int ca3d_slab_step(ca3d_t *h, uint32_t n_steps) { return slab_batch(h, n_steps, CA3D_SLAB_PHASE_ALL); }
+
+int ca3d_slab_step_phase(ca3d_t *h, uint32_t n_steps, int phase)
+{
+	if (phase != CA3D_SLAB_PHASE_ALL && phase != CA3D_SLAB_PHASE_EDGES && phase != CA3D_SLAB_PHASE_INTERIOR)
+		return fail(CA3D_ERR_INVALID_ARGUMENT, "unknown slab phase %d", phase);
+	return slab_batch(h, n_steps, phase);
 }
 
 int ca3d_slab_region(ca3d_t *h, int region, void **device_ptr, size_t *n_bytes)
 {
 	if (!h || !device_ptr || !n_bytes) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL argument");
 	if (!h->configured || !h->slab) return fail(CA3D_ERR_NOT_CONFIGURED, "engine is not configured as a slab");
-	uint32_t *base = h->buf[h->cur];
+	uint32_t *base = h->buf[(h->cur + h->pending_edges) & 1u]; // after an edge phase: the buffer its results are in
 	const size_t pw = h->plane_words;
 	const uint32_t K = h->ghost, nz = h->nz;
 	size_t first = 0, count = K;

@@ -82,7 +82,7 @@ void compile_rule_prog(uint32_t onset_mask, uint32_t max_count, RuleProg *out);
 
 // ---------------------------------------------------------------------------------------------- launch params
 
-// A step over output planes [lo, hi) of an array of `nplanes` z-planes; plane j holds global z = zbase + j
+// A step over output planes [lo, hi) (and optionally [lo2, hi2)) of an array of `nplanes` z-planes; plane j holds global z = zbase + j
 // (mod G). Full grid: zbase 0, nplanes G, wrap_full 1. See oracle/ca_oracle.c for the same convention.
 struct PlaneRange
 {
@@ -91,6 +91,7 @@ struct PlaneRange
 	int32_t zbase;
 	uint32_t lo, hi;
 	uint32_t wrap_full;
+	uint32_t lo2 = 0, hi2 = 0; // optional second output range (the two edge zones of a slab batch in one launch)
 };
 
 struct PackedLaunch

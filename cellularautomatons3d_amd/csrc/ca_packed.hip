@@ -71,8 +71,9 @@ __global__ __launch_bounds__(256) void ca_packed_class(const u32 *__restrict__ i
 	// The last z-run of a range whose length is not a multiple of ZR is shifted down to end at `hi` (a few planes
 	// are computed twice with identical results) so that the body has no tail guard: any branch here lets the
 	// compiler sink loads behind it and turns one memory round trip into two. The launcher guarantees hi - lo >= ZR.
-	u32 j0 = pr.lo + zr * ZR;
-	if (j0 + ZR > pr.hi) j0 = pr.hi - ZR;
+	u32 j0;
+	if (zr >= g.runs1) { j0 = pr.lo2 + (zr - g.runs1) * ZR; if (j0 + ZR > pr.hi2) j0 = pr.hi2 - ZR; } // second range
+	else { j0 = pr.lo + zr * ZR; if (j0 + ZR > pr.hi) j0 = pr.hi - ZR; }
 	// Window plane q holds array plane j0 + q - 1 (q = 0 .. ZR+1); out-of-range ends are clamped / wrapped.
 	// Phase 1 issues EVERY load of the thread back to back with no control flow in between, so one memory round
 	// trip covers them all; phase 2 masks the rows and fetches the edge words from the neighbour lanes.
@@ -462,7 +463,9 @@ hipError_t launch_class(const PackedLaunch &l, hipStream_t stream)
 	// only while both ping-pong buffers sit in the 256 MiB Infinity Cache with room to spare.
 	const bool nt = (size_t)l.pr.nplanes * l.pr.G * C * sizeof(u32) <= (16u << 20); // per buffer, ghosts included
 	if (nt) g.use_shfl |= 2u; // (sc1 / sc0 sc1 stores were tried too: no gain at either size)
-	const u32 planes = l.pr.hi - l.pr.lo;
+	const bool two = l.pr.hi2 > l.pr.lo2;
+	const u32 planes1 = l.pr.hi - l.pr.lo, planes2 = two ? l.pr.hi2 - l.pr.lo2 : 0u, planes = planes1 + planes2;
+	const u32 shortest = two && planes2 < planes1 ? planes2 : planes1;
 	// z-run of 4 planes per thread once that still leaves >= 4 workgroups per CU; small grids keep 1 plane per
 	// thread so all 256 CUs get work.
 	// Planes per thread (measured on MI355X, 512^3 / 1024^3): kernels that read only face neighbours are
@@ -470,10 +473,13 @@ hipError_t launch_class(const PackedLaunch &l, hipStream_t stream)
 	// kernels that need the diagonal rows re-read 9 rows per plane and amortise them over 4 planes (28 us vs 35 us).
 	constexpr bool kDiagonals = E || C_ || MAIN == MAIN_MOORE || MAIN == MAIN_EDGES || MAIN == MAIN_CORNERS;
 	constexpr int ZRUN = kDiagonals ? 4 : 2;
-	const bool deep = (size_t)g.tiles_per_plane * ((planes + ZRUN - 1u) / ZRUN) >= 1024u && planes >= (u32)ZRUN;
+	const bool deep = (size_t)g.tiles_per_plane * ((planes + ZRUN - 1u) / ZRUN) >= 1024u && shortest >= (u32)ZRUN;
 	const bool fast = rules_fit_fast(*l.rules);
-	const dim3 grid_deep(g.tiles_per_plane * ((planes + ZRUN - 1u) / ZRUN)), grid_flat(g.tiles_per_plane * planes);
 	const bool p2 = (g.use_shfl & 1u) != 0;
+	const u32 zr_used = (deep && p2) ? (u32)ZRUN : 1u;
+	g.runs1 = (planes1 + zr_used - 1u) / zr_used;
+	const u32 runs = g.runs1 + (planes2 + zr_used - 1u) / zr_used;
+	const dim3 grid_deep(g.tiles_per_plane * runs), grid_flat(g.tiles_per_plane * runs);
 #define CA3D_LAUNCH_CLASS(ZR_, FAST_, P2_, GRID_) \
 	hipLaunchKernelGGL((ca_packed_class<MAIN, E, C_, ZR_, FAST_, P2_>), GRID_, dim3(256), 0, stream, l.in, l.out, l.pr, g, l.rules->prog)
 	if (p2)
@@ -550,8 +556,23 @@ hipError_t launch_packed_step(const PackedLaunch &l, hipStream_t stream, const c
 {
 	const CanonRules &r = *l.rules;
 	if (kernel_name) *kernel_name = packed_kernel_name(r, l.pr.G, l.variant);
-	if (l.pr.hi <= l.pr.lo) return hipSuccess;
+	if (l.pr.hi <= l.pr.lo)
+	{
+		if (l.pr.hi2 <= l.pr.lo2) return hipSuccess;
+		PackedLaunch only = l; // only the second range has planes
+		only.pr.lo = l.pr.lo2; only.pr.hi = l.pr.hi2; only.pr.lo2 = only.pr.hi2 = 0;
+		return launch_packed_step(only, stream, nullptr);
+	}
 	if (vn_kernel_applies(r, l.pr.G, l.variant)) return launch_packed_vn(l, stream);
+	if (l.pr.hi2 > l.pr.lo2 && !use_class_kernel(r, l.pr.G, l.variant))
+	{
+		// the generic kernel takes one range per launch
+		PackedLaunch a = l, b = l;
+		a.pr.lo2 = a.pr.hi2 = 0;
+		b.pr.lo = l.pr.lo2; b.pr.hi = l.pr.hi2; b.pr.lo2 = b.pr.hi2 = 0;
+		hipError_t e = launch_packed_step(a, stream, nullptr);
+		return e != hipSuccess ? e : launch_packed_step(b, stream, nullptr);
+	}
 	if (use_class_kernel(r, l.pr.G, l.variant))
 	{
 		switch (r.main)

@@ -26,6 +26,7 @@ namespace
 struct VnArgs
 {
 	u32 lo, hi, nplanes, wrap_full; // PlaneRange without G
+	u32 lo2, hi2, runs1;            // second output range; z-runs of the first one
 	int zbase;
 	u32 lut_s, lut_b; // bit k: a cell with k live von Neumann neighbours survives / is born (k = 0 .. 6)
 	u32 nt;           // non-temporal stores
@@ -85,7 +86,8 @@ __global__ __launch_bounds__(256) void ca_packed_vn(const u32 *__restrict__ in, 
 	const u32 t = tile * 256u + threadIdx.x; // uint4 index inside a plane = y * CV + cxv
 	// first output plane of this thread; the last run of an odd range is shifted down to end at `hi` (the overlap
 	// is computed twice with identical results) so that the body has no tail guard
-	const u32 j0 = min(a.lo + zr * ZR, a.hi - ZR);
+	const bool second = zr >= a.runs1; // wave-uniform
+	const u32 j0 = second ? min(a.lo2 + (zr - a.runs1) * ZR, a.hi2 - ZR) : min(a.lo + zr * ZR, a.hi - ZR);
 
 	// Scalar plane bases. Own planes j0 .. j0+ZR-1 are always inside the array; only the plane below the run
 	// (clamped at plane 0, where it is only ever read masked: global z == 0) and the plane above it (wraps to
@@ -204,11 +206,11 @@ __global__ __launch_bounds__(256) void ca_packed_vn(const u32 *__restrict__ in, 
 constexpr int kDefaultS = 0xFF, kDefaultB = 0x0A; // canonical form: see launch_packed_vn
 
 template <int CVL, int ZR>
-hipError_t launch(const PackedLaunch &l, const VnArgs &a, hipStream_t stream)
+hipError_t launch(const PackedLaunch &l, VnArgs a, hipStream_t stream)
 {
+	a.runs1 = (l.pr.hi - l.pr.lo + ZR - 1u) / ZR;
 	constexpr u32 CV = 1u << CVL, TPP = 128u * CV * CV / 256u;
-	const u32 planes = l.pr.hi - l.pr.lo;
-	const u32 blocks = TPP * ((planes + ZR - 1u) / ZR);
+	const u32 blocks = TPP * (a.runs1 + (l.pr.hi2 > l.pr.lo2 ? (l.pr.hi2 - l.pr.lo2 + ZR - 1u) / ZR : 0u));
 	if (a.lut_s == (u32)kDefaultS && a.lut_b == (u32)kDefaultB)
 		hipLaunchKernelGGL((ca_packed_vn<CVL, ZR, kDefaultS, kDefaultB>), dim3(blocks), dim3(256), 0, stream, l.in, l.out, a);
 	else
@@ -242,10 +244,13 @@ bool vn_kernel_applies(const CanonRules &r, uint32_t G, int variant)
 hipError_t launch_packed_vn(const PackedLaunch &l, hipStream_t stream)
 {
 	const CanonRules &r = *l.rules;
-	const u32 G = l.pr.G, planes = l.pr.hi - l.pr.lo;
+	const bool two = l.pr.hi2 > l.pr.lo2;
+	const u32 G = l.pr.G, planes = l.pr.hi - l.pr.lo + (two ? l.pr.hi2 - l.pr.lo2 : 0u);
+	const u32 shortest = two ? (l.pr.hi - l.pr.lo < l.pr.hi2 - l.pr.lo2 ? l.pr.hi - l.pr.lo : l.pr.hi2 - l.pr.lo2) : l.pr.hi - l.pr.lo;
 	const int cvl = log2_exact(G / 128u);
 	VnArgs a;
 	a.lo = l.pr.lo; a.hi = l.pr.hi; a.nplanes = l.pr.nplanes; a.wrap_full = l.pr.wrap_full; a.zbase = l.pr.zbase;
+	a.lo2 = l.pr.lo2; a.hi2 = two ? l.pr.hi2 : l.pr.lo2; a.runs1 = 0;
 	// Entry 7 of a table is never read (a cell has at most 6 von Neumann neighbours): give it the value that makes
 	// the table constant when the other seven agree, so the specialised kernels can drop the evaluation.
 	a.lut_s = r.onset_survive[0] & 0x7Fu;
@@ -257,7 +262,7 @@ hipError_t launch_packed_vn(const PackedLaunch &l, hipStream_t stream)
 	a.nt = (size_t)l.pr.nplanes * G * (G / 32u) * sizeof(u32) <= (16u << 20) ? 1u : 0u;
 	// 2 planes per thread once that still fills the chip (>= 1024 workgroups), else 1
 	const u32 tpp = G / 128u * G / 256u;
-	const bool deep = planes >= 2u && (size_t)tpp * ((planes + 1u) / 2u) >= 1024u;
+	const bool deep = shortest >= 2u && (size_t)tpp * ((planes + 1u) / 2u) >= 1024u;
 	switch (cvl)
 	{
 	case 1: return launch<1, 1>(l, a, stream);

@@ -120,6 +120,11 @@ class Engine:
     def slab_step(self, n_steps: int) -> None:
         _capi.check(self._lib.ca3d_slab_step(self._h, n_steps))
 
+    def slab_step_phase(self, n_steps: int, phase: int) -> None:
+        """`slab_step` in two phases (SLAB_PHASE_EDGES, then SLAB_PHASE_INTERIOR) so the halo exchange can run
+        between them, overlapped with the interior."""
+        _capi.check(self._lib.ca3d_slab_step_phase(self._h, n_steps, phase))
+
     def slab_region(self, region: int):
         p, n = C.c_void_p(), C.c_size_t()
         _capi.check(self._lib.ca3d_slab_region(self._h, region, C.byref(p), C.byref(n)))

@@ -235,6 +235,17 @@ static napi_value js_slab_step(napi_env env, napi_callback_info info)
 	return rc ? throw_ca3d(env, rc) : undefined(env);
 }
 
+static napi_value js_slab_step_phase(napi_env env, napi_callback_info info)
+{
+	napi_value argv[3];
+	if (!get_args(env, info, 3, argv)) return NULL;
+	ca3d_t *h = get_handle(env, argv[0]);
+	uint32_t n, phase;
+	if (!h || !get_u32(env, argv[1], &n) || !get_u32(env, argv[2], &phase)) return NULL;
+	int rc = ca3d_slab_step_phase(h, n, (int)phase);
+	return rc ? throw_ca3d(env, rc) : undefined(env);
+}
+
 static napi_value js_synchronize(napi_env env, napi_callback_info info)
 {
 	napi_value argv[1];
@@ -366,7 +377,7 @@ static napi_value init(napi_env env, napi_value exports)
 	static const struct { const char *name; napi_callback fn; } fns[] = {
 	    {"abiVersion", js_abi_version}, {"deviceCount", js_device_count}, {"create", js_create}, {"destroy", js_destroy},
 	    {"configure", js_configure}, {"configureSlab", js_configure_slab}, {"setRules", js_set_rules},
-	    {"uploadState", js_upload_state}, {"readState", js_read_state}, {"step", js_step}, {"slabStep", js_slab_step},
+	    {"uploadState", js_upload_state}, {"readState", js_read_state}, {"step", js_step}, {"slabStep", js_slab_step}, {"slabStepPhase", js_slab_step_phase},
 	    {"synchronize", js_synchronize}, {"info", js_info}, {"stats", js_stats}, {"render", js_render},
 	    {"renderStats", js_render_stats}, {"setOption", js_set_option}};
 	for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++)

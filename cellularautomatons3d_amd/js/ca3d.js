@@ -211,6 +211,11 @@ class Engine
 	// _computePass (1796-1809), n times
 	step(n) { this._a.step(this._h, n === undefined ? 1 : n); }
 
+	// Z-slab mode (multi-GPU hosts; SURVEY 8(e)): see include/ca3d.h. phase: 0 whole batch, 1 edge zones, 2 interior.
+	configureSlab(gridSize, z0, nz, ghost, layout) { this._a.configureSlab(this._h, gridSize, layout === undefined ? LAYOUT_PACKED32 : layout, z0, nz, ghost); }
+	slabStep(n) { this._a.slabStep(this._h, n); }
+	slabStepPhase(n, phase) { this._a.slabStepPhase(this._h, n, phase); }
+
 	synchronize() { this._a.synchronize(this._h); }
 
 	// _renderPass (1775-1794) with the reference's 128-float block (MemoryManager.bufferf32)

@@ -11,7 +11,10 @@ A plane of the packed layout is contiguous (z is the slowest index), so a halo i
 * UNPACKED (compute.wgsl, toroidal): a true ring in both directions.
 
 With `ghost` = K planes the ranks exchange once per K steps and recompute the overlap (K sub-steps on a
-shrinking plane range), because one RCCL send/recv round costs more than one slab step.
+shrinking plane range), because one RCCL send/recv round costs more than one slab step. The exchange is
+overlapped with compute: a batch runs its edge zones first (`SLAB_PHASE_EDGES`: afterwards the planes the
+neighbours need are final), the sends / receives are posted, and the interior — which reads no ghost plane —
+runs while they are in flight (`SLAB_PHASE_INTERIOR`); the next batch waits for the receives.
 
 The transport is torch.distributed point-to-point (backend "nccl" = RCCL over xGMI on GPU tensors, "gloo" on
 CPU tensors in the tests), posted as one batch so RCCL groups the sends and receives.
@@ -21,7 +24,8 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Tuple
 
-from ._capi import LAYOUT_PACKED32, LAYOUT_UNPACKED, SLAB_OWNED, SLAB_RECV_HIGH, SLAB_RECV_LOW, SLAB_SEND_HIGH, SLAB_SEND_LOW
+from ._capi import (LAYOUT_PACKED32, LAYOUT_UNPACKED, SLAB_OWNED, SLAB_PHASE_EDGES, SLAB_PHASE_INTERIOR, SLAB_RECV_HIGH,
+                    SLAB_RECV_LOW, SLAB_SEND_HIGH, SLAB_SEND_LOW)
 
 TAG_TO_HIGH_GHOST = 0  # a rank's first owned planes travelling down to its lower neighbour's high ghost
 TAG_TO_LOW_GHOST = 1   # a rank's last owned planes travelling up to its upper neighbour's low ghost
@@ -63,11 +67,28 @@ def halo_plan(rank: int, world: int, layout: int = LAYOUT_PACKED32) -> HaloPlan:
     )
 
 
-def exchange_halos(regions: Dict[str, "object"], plan: HaloPlan, rank: int, group=None, host_staging: bool = False) -> None:
+def batch_ranges(nz: int, ghost: int, n: int, s: int, dead_bottom: bool) -> Dict[str, Tuple[int, int]]:
+    """Array-plane ranges [lo, hi) that sub-step s (1..n) of an n-sub-step batch updates (array = `ghost` low ghost
+    planes, nz owned planes, `ghost` high ghost planes) — the same split `ca3d_slab_step_phase` makes: 'all' is
+    the whole shrinking range; 'low' / 'high' are the edge zones that end on the planes the neighbours need;
+    'interior' is what lies between and grows as they shrink. `dead_bottom`: the slab owns global plane 0 of a
+    packed grid, whose -z face is dead, so its low ghost is never computed. Thin slabs cannot be split: then
+    'low' is 'all' and the other two are empty."""
+    L, K = nz + 2 * ghost, ghost
+    lo, hi = max(s, K if dead_bottom else 0), L - s
+    if nz + 2 <= 2 * K + 2 * n:
+        return {"all": (lo, hi), "low": (lo, hi), "high": (hi, hi), "interior": (hi, hi)}
+    e_lo, e_hi = 2 * K + n - s, L - 2 * K - n + s
+    return {"all": (lo, hi), "low": (lo, e_lo), "high": (e_hi, hi), "interior": (e_lo, e_hi)}
+
+
+def exchange_halos(regions: Dict[str, "object"], plan: HaloPlan, rank: int, group=None, host_staging: bool = False,
+                   wait: bool = True) -> List:
     """Refresh the ghost planes. `regions` maps 'send_low', 'send_high', 'recv_low', 'recv_high' to torch tensors
     (views of the current state buffer). Sends are posted low-then-high and receives high-then-low so that the
     two messages a pair of ranks may exchange in one direction (world == 2) match in order under RCCL, which
-    ignores tags; gloo uses the tags."""
+    ignores tags; gloo uses the tags. With wait=False the posted requests are returned instead of waited for
+    (RCCL: `wait()` later makes the then-current stream wait for the transfer, the host never blocks)."""
     import torch.distributed as dist
 
     if host_staging:
@@ -80,7 +101,7 @@ def exchange_halos(regions: Dict[str, "object"], plan: HaloPlan, rank: int, grou
             regions["recv_high"].copy_(staged["recv_high"])
         if plan.recv_low_from is not None:
             regions["recv_low"].copy_(staged["recv_low"])
-        return
+        return []
     ops: List = []
     if plan.send_low_to is not None:
         if plan.send_low_to == rank:
@@ -96,9 +117,14 @@ def exchange_halos(regions: Dict[str, "object"], plan: HaloPlan, rank: int, grou
         ops.append(dist.P2POp(dist.irecv, regions["recv_high"], plan.recv_high_from, group, TAG_TO_HIGH_GHOST))
     if plan.recv_low_from is not None and plan.recv_low_from != rank:
         ops.append(dist.P2POp(dist.irecv, regions["recv_low"], plan.recv_low_from, group, TAG_TO_LOW_GHOST))
-    if ops:
-        for req in dist.batch_isend_irecv(ops):
+    if not ops:
+        return []
+    reqs = dist.batch_isend_irecv(ops)
+    if wait:
+        for req in reqs:
             req.wait()
+        return []
+    return reqs
 
 
 class _DevicePtr:
@@ -124,7 +150,7 @@ class SlabEngine:
     """
 
     def __init__(self, grid_size: int, rank: int, world: int, ghost: int, layout: int = LAYOUT_PACKED32,
-                 device: int = 0, group=None, engine=None, host_staging: bool = False):
+                 device: int = 0, group=None, engine=None, host_staging: bool = False, overlap: bool = True):
         import torch
 
         from .engine import Engine
@@ -140,35 +166,53 @@ class SlabEngine:
         self.engine = engine or Engine(device)
         self.engine.configure_slab(grid_size, self.z0, self.nz, ghost, layout)
         self.engine.set_stream(self.stream.cuda_stream)
+        self.overlap = overlap
         self._regions = [None, None]
-        self._parity = 0  # mirrors the engine's current buffer without a round trip per batch
+        self._parity = 0  # buffer `slab_region` refers to, mirrored here to save a round trip per batch
+        self._ghosts_valid = False
 
     def upload_state(self, owned_words) -> None:
         self.engine.upload_state(owned_words)
         self._parity = 0
+        self._ghosts_valid = False
 
     def _current_regions(self):
         if self._regions[self._parity] is None:
-            assert self.engine.info().current_buffer == self._parity
             names = {"send_low": SLAB_SEND_LOW, "send_high": SLAB_SEND_HIGH, "recv_low": SLAB_RECV_LOW,
                      "recv_high": SLAB_RECV_HIGH, "owned": SLAB_OWNED}
             self._regions[self._parity] = {k: device_tensor(*self.engine.slab_region(v), self.device) for k, v in names.items()}
         return self._regions[self._parity]
 
-    def exchange(self) -> None:
+    def exchange(self, wait: bool = True) -> List:
         import torch
 
         with torch.cuda.stream(self.stream):
-            exchange_halos(self._current_regions(), self.plan, self.rank, self.group, self.host_staging)
+            return exchange_halos(self._current_regions(), self.plan, self.rank, self.group, self.host_staging, wait=wait)
 
     def run(self, n_steps: int) -> None:
-        """n CA steps: [exchange ghosts, up to `ghost` sub-steps] repeated. Asynchronous on the GPU."""
+        """n CA steps in batches of up to `ghost` sub-steps. Asynchronous on the GPU. Per batch: edge zones ->
+        post the exchange of the fresh edge planes -> interior (overlaps the transfer) -> the stream waits for the
+        receives. Ghosts are valid for the current step on entry (first call: one blocking exchange) and on exit."""
+        import torch
+
+        if not self._ghosts_valid:
+            self.exchange()
+            self._ghosts_valid = True
         left = n_steps
         while left > 0:
             k = min(self.ghost, left)
-            self.exchange()
-            self.engine.slab_step(k)
-            self._parity = (self._parity + k) & 1
+            if self.overlap:
+                self.engine.slab_step_phase(k, SLAB_PHASE_EDGES)
+                self._parity = (self._parity + k) & 1  # slab_region now refers to the buffer the batch ends in
+                reqs = self.exchange(wait=False)
+                self.engine.slab_step_phase(k, SLAB_PHASE_INTERIOR)
+                with torch.cuda.stream(self.stream):
+                    for req in reqs:
+                        req.wait()
+            else:
+                self.engine.slab_step(k)
+                self._parity = (self._parity + k) & 1
+                self.exchange()
             left -= k
 
     def close(self) -> None:

@@ -101,6 +101,26 @@ int ca3d_step(ca3d_t *h, uint32_t n_steps);
 /* Slab mode: n_steps <= ghost sub-steps on a shrinking plane range; then the ghosts must be refreshed. */
 int ca3d_slab_step(ca3d_t *h, uint32_t n_steps);
 
+/*
+ * The same batch in two phases, so that the halo exchange overlaps the bulk of the compute (BASELINE configs[4]:
+ * "halo overlapped with compute"):
+ *   CA3D_SLAB_PHASE_EDGES     all n sub-steps on the two edge zones only — afterwards the planes the neighbours
+ *                             need (SEND_LOW / SEND_HIGH of ca3d_slab_region) hold their final values of this batch;
+ *   (the caller starts the exchange of those planes into the neighbours' ghosts here)
+ *   CA3D_SLAB_PHASE_INTERIOR  all n sub-steps on the planes in between, commits the batch (step counter, current
+ *                             buffer). It reads no ghost plane, so the exchange may run concurrently with it.
+ * EDGES then INTERIOR with the same n equals one ca3d_slab_step(n). Slabs too thin to split (nz + 2 <= 2*ghost + 2*n)
+ * run the whole batch in the edge phase. Between the two phases ca3d_slab_region refers to the buffer the batch
+ * ends in (where the edge results are, and where the incoming ghosts belong).
+ */
+enum ca3d_slab_phase
+{
+	CA3D_SLAB_PHASE_ALL = 0,
+	CA3D_SLAB_PHASE_EDGES = 1,
+	CA3D_SLAB_PHASE_INTERIOR = 2
+};
+int ca3d_slab_step_phase(ca3d_t *h, uint32_t n_steps, int phase);
+
 enum ca3d_slab_region_id
 {
 	CA3D_SLAB_SEND_LOW = 0,  /* first `ghost` owned planes  -> lower neighbour's high ghost */
@@ -109,7 +129,8 @@ enum ca3d_slab_region_id
 	CA3D_SLAB_RECV_HIGH = 3, /* this engine's high ghost planes */
 	CA3D_SLAB_OWNED = 4      /* all owned planes */
 };
-/* Device pointer + byte size of a region of the CURRENT buffer (changes with step parity). */
+/* Device pointer + byte size of a region of the CURRENT buffer (changes with step parity; after an edge phase: of
+ * the buffer that batch ends in). */
 int ca3d_slab_region(ca3d_t *h, int region, void **device_ptr, size_t *n_bytes);
 
 int ca3d_synchronize(ca3d_t *h);

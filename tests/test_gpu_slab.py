@@ -10,6 +10,57 @@ from gpu_common import rules, set_rules
 pytestmark = pytest.mark.gpu
 
 
+def _run_slabs_overlapped(G, P, K, steps, r, layout, full):
+    """The overlapped schedule on one GPU: every engine runs its edge phase, then ALL interior phases are enqueued
+    and the ghost copies run on another stream at the same time — the interiors must neither read nor disturb the
+    ghost planes being written."""
+    import torch
+    from cellularautomatons3d_amd import SLAB_PHASE_EDGES, SLAB_PHASE_INTERIOR, Engine
+
+    pw = (G // 32) * G if layout == LAYOUT_PACKED32 else G * G
+    engs = []
+    for k in range(P):
+        e = Engine(0)
+        z0, nz = slab.slab_bounds(G, P, k)
+        e.configure_slab(G, z0, nz, K, layout)
+        set_rules(e, r)
+        e.upload_state(full[z0 * pw:(z0 + nz) * pw])
+        engs.append(e)
+    names = {"send_low": 0, "send_high": 1, "recv_low": 2, "recv_high": 3}
+    copy_stream = torch.cuda.Stream()
+
+    def exchange():
+        regs = [{n: slab.device_tensor(*e.slab_region(i), 0) for n, i in names.items()} for e in engs]
+        with torch.cuda.stream(copy_stream):
+            for rk in range(P):
+                plan = slab.halo_plan(rk, P, layout)
+                if plan.send_low_to is not None:
+                    regs[plan.send_low_to]["recv_high"].copy_(regs[rk]["send_low"])
+                if plan.send_high_to is not None:
+                    regs[plan.send_high_to]["recv_low"].copy_(regs[rk]["send_high"])
+
+    for e in engs:
+        e.synchronize()
+    exchange()
+    torch.cuda.synchronize()
+    left = steps
+    while left > 0:
+        k = min(K, left)
+        for e in engs:
+            e.slab_step_phase(k, SLAB_PHASE_EDGES)
+        for e in engs:
+            e.synchronize()
+        for e in engs:
+            e.slab_step_phase(k, SLAB_PHASE_INTERIOR)  # asynchronous: runs while the copies below are in flight
+        exchange()
+        torch.cuda.synchronize()
+        left -= k
+    out = np.concatenate([e.read_state() for e in engs])
+    for e in engs:
+        e.close()
+    return out
+
+
 def _run_slabs(G, P, K, steps, r, layout, full):
     import torch
     from cellularautomatons3d_amd import Engine
@@ -54,6 +105,49 @@ def test_packed_slabs_equal_full_grid(P, K, steps, name):
     full = host.random_fill(host.words_per_buffer(G), seed=31)
     got = _run_slabs(G, P, K, steps, r, LAYOUT_PACKED32, full)
     np.testing.assert_array_equal(got, ol.packed_run(G, full, r, steps))
+
+
+@pytest.mark.parametrize("G,P,K,steps,name", [(128, 2, 4, 9, "default"), (128, 4, 3, 7, "clustered"), (128, 8, 2, 5, "default"),
+                                                (128, 4, 8, 17, "default"), (512, 4, 6, 13, "default"), (512, 8, 16, 33, "vn_b24_s135")])
+def test_packed_slabs_overlapped_schedule(G, P, K, steps, name):
+    """Edge phase -> exchange concurrent with the interior phase: equals the full grid (the (128, 4, 8) case is too
+    thin to split: the edge phase then runs whole batches)."""
+    r = rules(name)
+    full = host.random_fill(host.words_per_buffer(G), seed=77)
+    got = _run_slabs_overlapped(G, P, K, steps, r, LAYOUT_PACKED32, full)
+    np.testing.assert_array_equal(got, ol.packed_run(G, full, r, steps))
+
+
+def test_unpacked_slabs_overlapped_schedule():
+    G, P, K, steps = 128, 2, 3, 7
+    r = rules("default")
+    full = (host.random_fill(G ** 3, seed=3) & 1).astype(np.uint32)
+    got = _run_slabs_overlapped(G, P, K, steps, r, LAYOUT_UNPACKED, full)
+    cur = full
+    for _ in range(steps):
+        cur = ol.unpacked_step(G, cur, r.main, r.survive, r.born)
+    np.testing.assert_array_equal(got, cur)
+
+
+def test_slab_phase_order_is_enforced():
+    from cellularautomatons3d_amd import SLAB_PHASE_EDGES, SLAB_PHASE_INTERIOR, Ca3dError, Engine
+
+    e = Engine(0)
+    try:
+        e.configure_slab(128, 0, 64, 2)
+        e.set_rule_strings()
+        e.upload_state(host.random_fill((128 // 32) * 128 * 64))
+        with pytest.raises(Ca3dError):
+            e.slab_step_phase(2, SLAB_PHASE_INTERIOR)  # no edge phase pending
+        e.slab_step_phase(2, SLAB_PHASE_EDGES)
+        with pytest.raises(Ca3dError):
+            e.slab_step(1)  # an edge phase is pending
+        with pytest.raises(Ca3dError):
+            e.slab_step_phase(1, SLAB_PHASE_INTERIOR)  # different length
+        e.slab_step_phase(2, SLAB_PHASE_INTERIOR)
+        assert e.info().step == 2
+    finally:
+        e.close()
 
 
 @pytest.mark.parametrize("name", ["default", "vn_b24_s135", "clustered"])

@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, G, ghost, steps, rule_kw, layout, out_dir):
+def _worker(rank, world, port, G, ghost, steps, rule_kw, layout, out_dir, overlap=False):
     import sys
 
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -38,7 +38,7 @@ def _worker(rank, world, port, G, ghost, steps, rule_kw, layout, out_dir):
         else:
             full = (host.random_fill(G ** 3, seed=1234) & 1).astype(np.uint32)
             pw = G * G
-        sl = OracleSlab(G, rank, world, ghost, rules, layout)
+        sl = OracleSlab(G, rank, world, ghost, rules, layout, overlap=overlap)
         sl.upload(full[sl.z0 * pw:(sl.z0 + sl.nz) * pw])
         sl.run(steps)
         np.save(os.path.join(out_dir, f"rank{rank}.npy"), sl.owned())
@@ -55,6 +55,51 @@ def test_packed_slabs_over_gloo(tmp_path, world, ghost, steps):
     got = np.concatenate([np.load(tmp_path / f"rank{r}.npy") for r in range(world)])
     want = ol.packed_run(G, host.random_fill(host.words_per_buffer(G), seed=1234), ol.Rules.from_strings(**rule_kw), steps)
     np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize("world,ghost,steps", [(2, 3, 8), (2, 8, 9)])
+def test_packed_slabs_over_gloo_overlapped_schedule(tmp_path, world, ghost, steps):
+    """Edge zones -> exchange -> interior (the schedule SlabEngine.run / ca3d_slab_step_phase use), world 2 over
+    gloo; ghost 8 on 32-plane slabs is too thin to split in the full batches and splits in the 1-step tail."""
+    G = 64
+    rule_kw = dict(neighbourhood="moore", born="5-7", survive="4-7", born_edges="4", survive_edges="3-5",
+                   born_corners="3", survive_corners="2-4")
+    mp.spawn(_worker, args=(world, _free_port(), G, ghost, steps, rule_kw, LAYOUT_PACKED32, str(tmp_path), True), nprocs=world, join=True)
+    got = np.concatenate([np.load(tmp_path / f"rank{r}.npy") for r in range(world)])
+    want = ol.packed_run(G, host.random_fill(host.words_per_buffer(G), seed=1234), ol.Rules.from_strings(**rule_kw), steps)
+    np.testing.assert_array_equal(got, want)
+
+
+def test_batch_ranges_partition_and_dependencies():
+    """The three zones tile the whole shrinking range; every zone's inputs at sub-step s were produced at s-1 by a
+    zone that is finished before it (edges before interior), and are not overwritten in between (ping-pong)."""
+    for nz, K in [(128, 16), (32, 3), (16, 4), (12, 5), (8, 1)]:
+        for dead in (False, True):
+            for n in range(1, K + 1):
+                prev = None
+                for s in range(1, n + 1):
+                    r = slab.batch_ranges(nz, K, n, s, dead)
+                    lo, hi = r["all"]
+                    assert (lo, hi) == (max(s, K if dead else 0), nz + 2 * K - s)
+                    assert r["low"][0] == lo and r["high"][1] == hi
+                    assert r["low"][1] == r["interior"][0] and r["interior"][1] == r["high"][0]
+                    if prev is not None:
+                        # an edge chain only needs its own previous range (one plane wider on the open side)
+                        assert r["low"][1] + 1 <= prev["low"][1] or r["low"] == r["all"]
+                        assert r["high"][0] - 1 >= prev["high"][0] or r["high"][0] == r["high"][1]
+                        # the interior needs one plane of each edge from sub-step s-1 ...
+                        if r["interior"][0] < r["interior"][1]:
+                            assert prev["low"][0] <= r["interior"][0] - 1 < prev["low"][1]
+                            assert prev["high"][0] <= r["interior"][1] < prev["high"][1]
+                    # ... which later edge sub-steps writing the same buffer (s+1, s+3, ...) leave alone
+                    for s2 in range(s + 2, n + 1, 2):
+                        r2 = slab.batch_ranges(nz, K, n, s2, dead)
+                        if r2["interior"][0] < r2["interior"][1]:
+                            assert r2["low"][1] <= r["low"][1] - 2 and r2["high"][0] >= r["high"][0] + 2
+                    prev = r
+                end = slab.batch_ranges(nz, K, n, n, dead)
+                assert end["low"][0] <= K and (end["low"][1] >= 2 * K or end["low"] == end["all"])  # planes sent down are final
+                assert end["all"][1] >= nz + K
 
 
 def test_unpacked_slabs_over_gloo(tmp_path):

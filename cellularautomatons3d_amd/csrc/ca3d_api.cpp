@@ -63,7 +63,7 @@ struct ca3d_engine
 	int variant = 0;
 	int use_graph = 1;
 	int render_mode = 0;
-	int use_fused = 0; // the two-step fused kernel is bit-exact but measured slower than two single steps (DESIGN.md 4.4)
+	int use_fused = 0; // the two-step fused kernel is bit-exact but measured slower than two single steps (DESIGN.md 4.5)
 
 	// hipGraph of an even number of full-grid steps starting from buffer 0 (invalidated on any change)
 	hipGraphExec_t graph_exec = nullptr;

@@ -17,13 +17,17 @@ rocprofv3 --output-format csv --kernel-trace --stats -d "$out/${tag}_stats1024" 
 rocprofv3 --output-format csv --kernel-trace --stats -d "$out/${tag}_stats_render" -o s -- python bench.py --no-cpu-baseline --steps 64 --warmup 8 > "$out/${tag}_bench_render_under_rocprof.json"
 rocprofv3 --output-format csv --kernel-trace --stats -d "$out/${tag}_stats_clustered" -o s -- python $B512 --rule clustered > "$out/${tag}_bench512_clustered_under_rocprof.json"
 rocprofv3 --output-format csv --kernel-trace --stats -d "$out/${tag}_stats_unpacked" -o s -- python tools/run_unpacked.py > "$out/${tag}_unpacked.log"
+rocprofv3 --output-format csv --kernel-trace --stats -d "$out/${tag}_stats_slab" -o s -- python tools/run_slab.py --ghost 16 --batches 50 > "$out/${tag}_slab.log"
+rocprofv3 --output-format csv --kernel-trace --stats -d "$out/${tag}_stats_slab_phased" -o s -- python tools/run_slab.py --ghost 16 --batches 50 --phased 1 > "$out/${tag}_slab_phased.log"
+for g in 256 1024; do python bench.py --no-cpu-baseline --no-render --grid $g --steps 1024 --warmup 128 >> "$out/${tag}_bench_matrix.jsonl"; done
+for g in 256 512 1024; do python bench.py --no-cpu-baseline --no-render --grid $g --rule clustered --steps 256 --warmup 64 >> "$out/${tag}_bench_matrix.jsonl"; done
 
 rocprofv3 --output-format csv --pmc FETCH_SIZE --kernel-trace -d "$out/${tag}_pmc_fetch512" -o p -- python $B512 > /dev/null
 rocprofv3 --output-format csv --pmc WRITE_SIZE --kernel-trace -d "$out/${tag}_pmc_write512" -o p -- python $B512 > /dev/null
 rocprofv3 --output-format csv --pmc FETCH_SIZE --kernel-trace -d "$out/${tag}_pmc_fetch1024" -o p -- python $B1024 > /dev/null
 rocprofv3 --output-format csv --pmc WRITE_SIZE --kernel-trace -d "$out/${tag}_pmc_write1024" -o p -- python $B1024 > /dev/null
-python tools/pmc_reduce.py "ca_packed_class<vn>@512" ca_packed_class "$out/${tag}_pmc_fetch512" "$out/${tag}_pmc_write512" "$out/${tag}_pmc_traffic.json"
-python tools/pmc_reduce.py "ca_packed_class<vn>@1024" ca_packed_class "$out/${tag}_pmc_fetch1024" "$out/${tag}_pmc_write1024" "$out/${tag}_pmc_traffic.json"
+python tools/pmc_reduce.py "ca_packed_vn@512" ca_packed_vn "$out/${tag}_pmc_fetch512" "$out/${tag}_pmc_write512" "$out/${tag}_pmc_traffic.json"
+python tools/pmc_reduce.py "ca_packed_vn@1024" ca_packed_vn "$out/${tag}_pmc_fetch1024" "$out/${tag}_pmc_write1024" "$out/${tag}_pmc_traffic.json"
 # keep only summaries: the raw per-dispatch traces are large
 find "$out" -name "*kernel_trace.csv" -delete; find "$out" -name "*counter_collection.csv" -delete; find "$out" -name "*agent_info.csv" -delete
 echo done

@@ -70,6 +70,9 @@ struct ca3d_engine
 	uint32_t graph_steps = 0, graph_launches = 0;
 	std::map<uint64_t, hipGraphExec_t> slab_graphs; // (phase, start buffer, sub-steps) -> captured slab batch
 	uint32_t pending_edges = 0;                     // sub-steps of an edge phase awaiting its interior phase
+	int use_jit = 1;      // specialise kernels for the rule at run time (hiprtc) where a specialisation exists
+	VnJit vn_jit;         // valid when vn_jit.cvl >= 0
+	std::string jit_log;  // why the last specialisation attempt failed (empty: none failed)
 
 	ca3d_stats stats{};
 	const char *kernel_name = "";
@@ -174,7 +177,7 @@ int enqueue_step(ca3d_engine *h, int src, uint32_t lo, uint32_t hi, hipStream_t 
 	{
 		pr.lo2 = lo2;
 		pr.hi2 = hi2;
-		PackedLaunch l{h->buf[src], h->buf[src ^ 1], pr, &h->rules, h->variant};
+		PackedLaunch l{h->buf[src], h->buf[src ^ 1], pr, &h->rules, h->variant, h->vn_jit.cvl >= 0 ? &h->vn_jit : nullptr};
 		e = fused ? launch_packed_fused(l, s, &h->kernel_name) : launch_packed_step(l, s, &h->kernel_name);
 	}
 	else
@@ -191,6 +194,29 @@ int enqueue_step(ca3d_engine *h, int src, uint32_t lo, uint32_t hi, hipStream_t 
 	}
 	if (e != hipSuccess) return fail(CA3D_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString(e));
 	return CA3D_OK;
+}
+
+// (Re)select the kernels for the current rules and grid; compiles the rule's specialisation when one applies. Called
+// whenever rules, grid or the relevant options change — never from the step path (the WebGPU analogue is pipeline
+// creation). A failed compile leaves the ahead-of-time kernels in charge.
+void refresh_kernels(ca3d_engine *h)
+{
+	h->vn_jit = VnJit{};
+	h->jit_log.clear();
+	if (!h->configured || !h->rules.valid) return;
+	if (h->layout != CA3D_LAYOUT_PACKED32) { h->kernel_name = "ca_unpacked_literal"; return; }
+	h->kernel_name = packed_kernel_name(h->rules, h->G, h->variant);
+	if (!h->use_jit || !vn_kernel_applies(h->rules, h->G, h->variant)) return;
+	uint32_t ls = 0, lb = 0;
+	vn_tables(h->rules, &ls, &lb);
+	if (vn_tables_prebuilt(ls, lb)) return;
+	if (hipSetDevice(h->device) != hipSuccess) return;
+	VnJit j;
+	if (jit_vn_kernels(h->device, vn_grid_log2(h->G), ls, lb, &j, &h->jit_log) == CA3D_OK)
+	{
+		h->vn_jit = j;
+		h->kernel_name = "ca_packed_vn(jit)";
+	}
 }
 
 int check_ready(ca3d_engine *h)
@@ -355,7 +381,9 @@ int ca3d_configure(ca3d_t *h, uint32_t gx, uint32_t gy, uint32_t gz, int layout)
 	h->nz = gx;
 	h->ghost = 0;
 	h->nplanes = gx;
-	return allocate(h);
+	rc = allocate(h);
+	if (rc == CA3D_OK) refresh_kernels(h);
+	return rc;
 }
 
 int ca3d_configure_slab(ca3d_t *h, uint32_t g, int layout, uint32_t z0, uint32_t nz, uint32_t ghost)
@@ -370,7 +398,9 @@ int ca3d_configure_slab(ca3d_t *h, uint32_t g, int layout, uint32_t z0, uint32_t
 	h->nz = nz;
 	h->ghost = ghost;
 	h->nplanes = nz + 2u * ghost;
-	return allocate(h);
+	rc = allocate(h);
+	if (rc == CA3D_OK) refresh_kernels(h);
+	return rc;
 }
 
 int ca3d_set_rules(ca3d_t *h, const int32_t *main_offsets, uint32_t n_main, const int32_t *edges_offsets, uint32_t n_edges,
@@ -386,8 +416,7 @@ int ca3d_set_rules(ca3d_t *h, const int32_t *main_offsets, uint32_t n_main, cons
 	if (rc) return rc;
 	drop_graph(h);
 	h->rules = r;
-	if (h->configured)
-		h->kernel_name = h->layout == CA3D_LAYOUT_PACKED32 ? packed_kernel_name(h->rules, h->G, h->variant) : "ca_unpacked_literal";
+	refresh_kernels(h);
 	return CA3D_OK;
 }
 
@@ -668,7 +697,7 @@ int ca3d_get_info(ca3d_t *h, ca3d_info *out)
 	{
 		if (h->layout != CA3D_LAYOUT_PACKED32) name = h->step > 0 && h->kernel_name[0] ? h->kernel_name : "ca_unpacked";
 		else if (h->use_fused && !h->slab && packed_fused_steps(h->rules, h->G, h->variant) == 2) name = "ca_packed_fused+ca_packed_class";
-		else name = packed_kernel_name(h->rules, h->G, h->variant);
+		else name = h->vn_jit.cvl >= 0 ? "ca_packed_vn(jit)" : packed_kernel_name(h->rules, h->G, h->variant);
 	}
 	snprintf(out->kernel_name, sizeof out->kernel_name, "%s", name);
 	return CA3D_OK;
@@ -798,6 +827,14 @@ int ca3d_set_option(ca3d_t *h, const char *name, int64_t value)
 		if (value < 0 || value > 0x2FF) return fail(CA3D_ERR_INVALID_ARGUMENT, "variant must be 0 (auto) or 1 (generic kernel)");
 		drop_graph(h);
 		h->variant = (int)value;
+		refresh_kernels(h);
+		return CA3D_OK;
+	}
+	if (!strcmp(name, "jit"))
+	{
+		drop_graph(h);
+		h->use_jit = value ? 1 : 0;
+		refresh_kernels(h);
 		return CA3D_OK;
 	}
 	return fail(CA3D_ERR_INVALID_ARGUMENT, "unknown option '%s'", name);

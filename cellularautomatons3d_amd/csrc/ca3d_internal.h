@@ -94,6 +94,14 @@ struct PlaneRange
 	uint32_t lo2 = 0, hi2 = 0; // optional second output range (the two edge zones of a slab batch in one launch)
 };
 
+// Run-time compiled (hiprtc) von Neumann kernels for one (grid, survive table, born table): ca_jit.cpp
+struct VnJit
+{
+	void *zr1 = nullptr, *zr2 = nullptr; // hipFunction_t of the 1- and 2-planes-per-thread entry points
+	int cvl = -1;
+	uint32_t lut_s = 0, lut_b = 0;
+};
+
 struct PackedLaunch
 {
 	const uint32_t *in;
@@ -101,6 +109,7 @@ struct PackedLaunch
 	PlaneRange pr;
 	const CanonRules *rules;
 	int variant; // -1 auto
+	const VnJit *vn_jit = nullptr; // specialised kernels for exactly these rules and this grid, or null
 };
 
 struct UnpackedLaunch
@@ -136,6 +145,13 @@ const char *packed_kernel_name(const CanonRules &r, uint32_t G, int variant);
 // ca_packed_vn.hip: the specialised von Neumann kernel (truth-table rules, power-of-two grids)
 bool vn_kernel_applies(const CanonRules &r, uint32_t G, int variant);
 hipError_t launch_packed_vn(const PackedLaunch &l, hipStream_t stream);
+// Canonical truth tables of the von Neumann kernel for these rules (entry 7 is a don't-care: see ca_packed_vn.hip)
+void vn_tables(const CanonRules &r, uint32_t *lut_s, uint32_t *lut_b);
+// Whether ca_packed_vn.hip carries an ahead-of-time specialisation for these tables (then no JIT is needed)
+bool vn_tables_prebuilt(uint32_t lut_s, uint32_t lut_b);
+int vn_grid_log2(uint32_t G); // log2(G / 128)
+// ca_jit.cpp: compile (or fetch from the cache) the kernels specialised for (grid 128 << cvl, tables)
+int jit_vn_kernels(int device, int cvl, uint32_t lut_s, uint32_t lut_b, VnJit *out, std::string *log);
 // Steps one fused launch advances for these rules / grid (0 = no fused kernel applies).
 int packed_fused_steps(const CanonRules &r, uint32_t G, int variant);
 hipError_t launch_packed_fused(const PackedLaunch &l, hipStream_t stream, const char **kernel_name);

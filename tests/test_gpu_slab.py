@@ -228,4 +228,4 @@ def test_bench_two_ranks_on_one_gpu_gloo_rehearsal():
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["oracle_match"] is True and d["scaling"] == "strong"
-    assert d["roofline"]["kernel"] == "ca_packed_vn"
+    assert d["roofline"]["kernel"].startswith("ca_packed_vn")

@@ -72,6 +72,7 @@ struct ca3d_engine
 	uint32_t pending_edges = 0;                     // sub-steps of an edge phase awaiting its interior phase
 	int use_jit = 1;      // specialise kernels for the rule at run time (hiprtc) where a specialisation exists
 	VnJit vn_jit;         // valid when vn_jit.cvl >= 0
+	ClassJit class_jit;   // valid when class_jit.main >= 0
 	std::string jit_log;  // why the last specialisation attempt failed (empty: none failed)
 
 	ca3d_stats stats{};
@@ -177,7 +178,7 @@ int enqueue_step(ca3d_engine *h, int src, uint32_t lo, uint32_t hi, hipStream_t 
 	{
 		pr.lo2 = lo2;
 		pr.hi2 = hi2;
-		PackedLaunch l{h->buf[src], h->buf[src ^ 1], pr, &h->rules, h->variant, h->vn_jit.cvl >= 0 ? &h->vn_jit : nullptr};
+		PackedLaunch l{h->buf[src], h->buf[src ^ 1], pr, &h->rules, h->variant, h->vn_jit.cvl >= 0 ? &h->vn_jit : nullptr, h->class_jit.main >= 0 ? &h->class_jit : nullptr};
 		e = fused ? launch_packed_fused(l, s, &h->kernel_name) : launch_packed_step(l, s, &h->kernel_name);
 	}
 	else
@@ -202,11 +203,22 @@ int enqueue_step(ca3d_engine *h, int src, uint32_t lo, uint32_t hi, hipStream_t 
 void refresh_kernels(ca3d_engine *h)
 {
 	h->vn_jit = VnJit{};
+	h->class_jit = ClassJit{};
 	h->jit_log.clear();
 	if (!h->configured || !h->rules.valid) return;
 	if (h->layout != CA3D_LAYOUT_PACKED32) { h->kernel_name = "ca_unpacked_literal"; return; }
 	h->kernel_name = packed_kernel_name(h->rules, h->G, h->variant);
-	if (!h->use_jit || !vn_kernel_applies(h->rules, h->G, h->variant)) return;
+	if (!h->use_jit) return;
+	if (!vn_kernel_applies(h->rules, h->G, h->variant))
+	{
+		// class kernels on power-of-two grids: the rule's truth tables become compile-time constants
+		const uint32_t cv = h->G / 128u;
+		if (!use_class_kernel(h->rules, h->G, h->variant) || h->G % 128u || (cv & (cv - 1u)) || cv > 64u) return;
+		if (hipSetDevice(h->device) != hipSuccess) return;
+		ClassJit cj;
+		if (jit_class_kernels(h->device, h->rules, &cj, &h->jit_log) == CA3D_OK) h->class_jit = cj;
+		return;
+	}
 	uint32_t ls = 0, lb = 0;
 	vn_tables(h->rules, &ls, &lb);
 	if (vn_tables_prebuilt(ls, lb)) return;
@@ -699,7 +711,9 @@ int ca3d_get_info(ca3d_t *h, ca3d_info *out)
 		else if (h->use_fused && !h->slab && packed_fused_steps(h->rules, h->G, h->variant) == 2) name = "ca_packed_fused+ca_packed_class";
 		else name = h->vn_jit.cvl >= 0 ? "ca_packed_vn(jit)" : packed_kernel_name(h->rules, h->G, h->variant);
 	}
-	snprintf(out->kernel_name, sizeof out->kernel_name, "%s", name);
+	const bool class_jit = h->configured && h->rules.valid && h->layout == CA3D_LAYOUT_PACKED32 && h->class_jit.main >= 0 &&
+	                       !(h->use_fused && !h->slab && packed_fused_steps(h->rules, h->G, h->variant) == 2);
+	snprintf(out->kernel_name, sizeof out->kernel_name, "%s%s", name, class_jit ? "(jit)" : "");
 	return CA3D_OK;
 }
 

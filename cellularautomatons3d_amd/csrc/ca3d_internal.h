@@ -7,45 +7,10 @@
 #include <string>
 
 #include "ca3d.h"
+#include "ca_device_types.h"
 
 namespace ca3d
 {
-
-// ---------------------------------------------------------------------------------------------- rule programs
-//
-// A born/survive LUT slice (27 slots of one rule-set) is a boolean function of the bit-sliced neighbour count.
-// The host compiles it (Quine-McCluskey with the unreachable counts as don't-cares) into a short OR-of-cubes
-// program which the kernels interpret with wave-uniform control flow: the LUT never reaches the GPU.
-constexpr int kMaxCubes = 16;
-
-struct RuleProg
-{
-	uint32_t n;      // cubes used
-	uint32_t invert; // 0 or 0xFFFFFFFF: the cubes cover the complement
-	// bits 0-4: care mask over count planes, bits 8-12: required plane value where cared
-	uint32_t cubes[kMaxCubes];
-};
-
-struct RuleSetProg
-{
-	RuleProg born, survive;
-};
-
-struct PackedRuleArgs
-{
-	RuleSetProg set[3]; // main, edges, corners
-};
-
-enum MainKind : int
-{
-	MAIN_VN = 0,
-	MAIN_VN2D = 1,
-	MAIN_MOORE = 2,
-	MAIN_MOORE2D = 3,
-	MAIN_EDGES = 4,
-	MAIN_CORNERS = 5,
-	MAIN_GENERIC = 6
-};
 
 constexpr int kMaxOffsets = 26; // per list; a count must stay inside its 27-slot LUT slice
 
@@ -82,24 +47,21 @@ void compile_rule_prog(uint32_t onset_mask, uint32_t max_count, RuleProg *out);
 
 // ---------------------------------------------------------------------------------------------- launch params
 
-// A step over output planes [lo, hi) (and optionally [lo2, hi2)) of an array of `nplanes` z-planes; plane j holds global z = zbase + j
-// (mod G). Full grid: zbase 0, nplanes G, wrap_full 1. See oracle/ca_oracle.c for the same convention.
-struct PlaneRange
-{
-	uint32_t G;
-	uint32_t nplanes;
-	int32_t zbase;
-	uint32_t lo, hi;
-	uint32_t wrap_full;
-	uint32_t lo2 = 0, hi2 = 0; // optional second output range (the two edge zones of a slab batch in one launch)
-};
-
 // Run-time compiled (hiprtc) von Neumann kernels for one (grid, survive table, born table): ca_jit.cpp
 struct VnJit
 {
 	void *zr1 = nullptr, *zr2 = nullptr; // hipFunction_t of the 1- and 2-planes-per-thread entry points
 	int cvl = -1;
 	uint32_t lut_s = 0, lut_b = 0;
+};
+
+// Run-time compiled class kernels (rule as compile-time truth tables) for one (main table, live rule-sets, rule)
+struct ClassJit
+{
+	void *deep = nullptr, *flat = nullptr; // hipFunction_t: ZRUN planes per thread / 1 plane per thread
+	int main = -1;
+	bool e = false, c = false;
+	uint32_t tables[6] = {0, 0, 0, 0, 0, 0}; // survive / born of main, edges, corners (bit k = value at count k)
 };
 
 struct PackedLaunch
@@ -110,6 +72,7 @@ struct PackedLaunch
 	const CanonRules *rules;
 	int variant; // -1 auto
 	const VnJit *vn_jit = nullptr; // specialised kernels for exactly these rules and this grid, or null
+	const ClassJit *class_jit = nullptr;
 };
 
 struct UnpackedLaunch
@@ -152,6 +115,11 @@ bool vn_tables_prebuilt(uint32_t lut_s, uint32_t lut_b);
 int vn_grid_log2(uint32_t G); // log2(G / 128)
 // ca_jit.cpp: compile (or fetch from the cache) the kernels specialised for (grid 128 << cvl, tables)
 int jit_vn_kernels(int device, int cvl, uint32_t lut_s, uint32_t lut_b, VnJit *out, std::string *log);
+// Truth tables of the three rule-sets over their count planes, unreachable counts filled (class kernels, JIT)
+void class_tables(const CanonRules &r, uint32_t tables[6]);
+int class_zrun(const CanonRules &r); // planes per thread of the deep variant for these rules
+bool use_class_kernel(const CanonRules &r, uint32_t G, int variant);
+int jit_class_kernels(int device, const CanonRules &r, ClassJit *out, std::string *log);
 // Steps one fused launch advances for these rules / grid (0 = no fused kernel applies).
 int packed_fused_steps(const CanonRules &r, uint32_t G, int variant);
 hipError_t launch_packed_fused(const PackedLaunch &l, hipStream_t stream, const char **kernel_name);

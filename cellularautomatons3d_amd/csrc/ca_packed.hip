@@ -24,133 +24,7 @@ namespace
 
 #include "ca_bitslice.inc"
 
-// Each thread owns one dwordx4 column position (y, cx0..cx0+3) and walks ZR consecutive z-planes with the three
-// planes it needs held in registers, so a plane's rows are fetched once per ZR outputs instead of three times.
-template <int MAIN, bool E, bool C_, int ZR, bool FAST, bool P2>
-__global__ __launch_bounds__(256) void ca_packed_class(const u32 *__restrict__ in, u32 *__restrict__ out,
-                                                       PlaneRange pr, TileGeom g, PackedRuleArgs rules_in)
-{
-	constexpr bool kMainVN = MAIN == MAIN_VN || MAIN == MAIN_MOORE;
-	constexpr bool kNeedEdges = E || MAIN == MAIN_MOORE || MAIN == MAIN_EDGES;
-	constexpr bool kNeedCorners = C_ || MAIN == MAIN_MOORE || MAIN == MAIN_CORNERS;
-	constexpr bool kCenterLR = kMainVN || MAIN == MAIN_VN2D || MAIN == MAIN_MOORE2D || kNeedEdges; // own plane or z+-1 planes
-	constexpr bool kYRows = kMainVN || MAIN == MAIN_VN2D || MAIN == MAIN_MOORE2D || kNeedEdges || kNeedCorners;
-	constexpr bool kYLR = kNeedEdges || kNeedCorners || MAIN == MAIN_MOORE2D;
-	constexpr bool kZNbr = kMainVN || kNeedEdges || kNeedCorners;  // z+-1 planes needed at all
-	constexpr bool kZYRows = kNeedEdges || kNeedCorners;           // y+-1 rows of the z+-1 planes (diagonals)
-
-	// XCD-aware block order: hardware deals blocks round-robin over the 8 XCDs; give XCD k the k-th contiguous
-	// eighth of the (z-run, tile) space so z-neighbour planes meet in one XCD's L2.
-	const u32 b = blockIdx.x, nb = gridDim.x;
-	const u32 v = (nb & 7u) == 0 ? (b & 7u) * (nb >> 3) + (b >> 3) : b;
-	// P2: power-of-two grid — shifts only, and a row (<= 64 uint4) sits inside one wave, so the words either
-	// side of a segment come from the neighbour lanes. Otherwise: divisions, and two extra dword loads per row.
-	u32 zr, tile, y, cxv;
-	if (P2) { zr = v >> g.tpp_shift; tile = v & (g.tiles_per_plane - 1u); }
-	else { zr = v / g.tiles_per_plane; tile = v - zr * g.tiles_per_plane; }
-	const u32 t = tile * 256u + threadIdx.x;
-	if (t >= pr.G * g.CV) return;
-	if (P2) { y = t >> g.cv_shift; cxv = t & (g.CV - 1u); }
-	else { y = t / g.CV; cxv = t - y * g.CV; }
-	const u32 C = g.CV * 4u, cx0 = cxv * 4u;
-	const u32 plane_words = C * pr.G;
-
-	Pos ps;
-	{
-		const u32 yr[3] = {y == 0 ? 0u : y - 1, y, (y + 1 == pr.G) ? 0u : y + 1};
-		for (int r = 0; r < 3; r++) { ps.row0[r] = yr[r] * C; ps.off[r] = ps.row0[r] + cx0; ps.ymask[r] = 0xFFFFFFFFu; }
-		ps.ymask[0] = y == 0 ? 0u : 0xFFFFFFFFu;
-		ps.lo_rel = cx0 == 0 ? 0u : cx0 - 1;
-		ps.hi_rel = cx0 + 4 == C ? 0u : cx0 + 4;
-		ps.lo_mask = cx0 == 0 ? 0u : 0xFFFFFFFFu;
-		const int lane = (int)(threadIdx.x & 63u);
-		ps.src_lo = lane - 1;
-		ps.src_hi = cxv + 1 == g.CV ? lane - (int)(g.CV - 1u) : lane + 1;
-	}
-
-	// The last z-run of a range whose length is not a multiple of ZR is shifted down to end at `hi` (a few planes
-	// are computed twice with identical results) so that the body has no tail guard: any branch here lets the
-	// compiler sink loads behind it and turns one memory round trip into two. The launcher guarantees hi - lo >= ZR.
-	u32 j0;
-	if (zr >= g.runs1) { j0 = pr.lo2 + (zr - g.runs1) * ZR; if (j0 + ZR > pr.hi2) j0 = pr.hi2 - ZR; } // second range
-	else { j0 = pr.lo + zr * ZR; if (j0 + ZR > pr.hi) j0 = pr.hi - ZR; }
-	// Window plane q holds array plane j0 + q - 1 (q = 0 .. ZR+1); out-of-range ends are clamped / wrapped.
-	// Phase 1 issues EVERY load of the thread back to back with no control flow in between, so one memory round
-	// trip covers them all; phase 2 masks the rows and fetches the edge words from the neighbour lanes.
-	RawRows raw[ZR + 2];
-#pragma unroll
-	for (int q = 0; q < ZR + 2; q++)
-	{
-		const bool is_out = q >= 1 && q <= ZR; // planes that are themselves outputs of this thread
-		if (!kZNbr && !is_out) continue;
-		u32 jq = j0 + (u32)q - 1u;
-		if (q == 0 && j0 == 0) jq = 0;                                     // only ever used masked (global z == 0)
-		if (jq >= pr.nplanes) jq = (jq == pr.nplanes && pr.wrap_full) ? 0u : pr.nplanes - 1u;
-		const u32 *plane = in + (size_t)jq * plane_words;
-		const bool rows = kYRows && (is_out || kZYRows);
-		raw[q].c = *reinterpret_cast<const uint4 *>(plane + ps.off[1]);
-		if (rows)
-		{
-			raw[q].ym = *reinterpret_cast<const uint4 *>(plane + ps.off[0]);
-			raw[q].yp = *reinterpret_cast<const uint4 *>(plane + ps.off[2]);
-		}
-		if (!P2)
-		{
-			if (kCenterLR) { raw[q].e[1][0] = plane[ps.row0[1] + ps.lo_rel]; raw[q].e[1][1] = plane[ps.row0[1] + ps.hi_rel]; }
-			if (rows && kYLR)
-			{
-				raw[q].e[0][0] = plane[ps.row0[0] + ps.lo_rel]; raw[q].e[0][1] = plane[ps.row0[0] + ps.hi_rel];
-				raw[q].e[2][0] = plane[ps.row0[2] + ps.lo_rel]; raw[q].e[2][1] = plane[ps.row0[2] + ps.hi_rel];
-			}
-		}
-	}
-
-	FastRules<MAIN, E, C_> frules;
-	if (FAST) frules = expand_rules<MAIN, E, C_>(rules_in);
-
-	PlaneRows win[ZR + 2];
-#pragma unroll
-	for (int q = 0; q < ZR + 2; q++)
-	{
-		const bool is_out = q >= 1 && q <= ZR;
-		if (!kZNbr && !is_out) continue;
-		win[q].c = make_seg<kCenterLR, P2>(raw[q].c, raw[q].e[1], ps, 1);
-		if (kYRows && (is_out || kZYRows))
-		{
-			win[q].ym = make_seg<kYLR, P2>(raw[q].ym, raw[q].e[0], ps, 0);
-			win[q].yp = make_seg<kYLR, P2>(raw[q].yp, raw[q].e[2], ps, 2);
-		}
-	}
-
-	// All results first, then all stores: on gfx9-family targets loads and stores share one counter (vmcnt), so a
-	// store issued between two uses of loaded data makes the later use wait for the store to complete.
-	int zg = global_z(pr, j0);
-	uint4 res[ZR];
-#pragma unroll
-	for (int q = 1; q <= ZR; q++)
-	{
-		const u32 zmask = zg == 0 ? 0u : 0xFFFFFFFFu; // z-1 == -1 is dropped (compute_clustered.wgsl:104)
-		zg = zg + 1 == (int)pr.G ? 0 : zg + 1;
-		if (FAST) res[q - 1] = evolve4<MAIN, E, C_>(win[q - 1], win[q], win[q + 1], zmask, frules);
-		else res[q - 1] = evolve4<MAIN, E, C_>(win[q - 1], win[q], win[q + 1], zmask, rules_in);
-	}
-	typedef u32 u32x4 __attribute__((ext_vector_type(4)));
-	u32 *dst = out + (size_t)j0 * plane_words + ps.off[1];
-	if (g.use_shfl & 2u)
-	{
-#pragma unroll
-		for (int q = 0; q < ZR; q++)
-		{
-			const u32x4 rv = {res[q].x, res[q].y, res[q].z, res[q].w};
-			__builtin_nontemporal_store(rv, reinterpret_cast<u32x4 *>(dst + (size_t)q * plane_words));
-		}
-	}
-	else
-	{
-#pragma unroll
-		for (int q = 0; q < ZR; q++) *reinterpret_cast<uint4 *>(dst + (size_t)q * plane_words) = res[q];
-	}
-}
+#include "ca_packed_class_kernel.inc"
 
 // ---------------------------------------------------------------------------------------------- fused kernel
 // Two CA steps per launch (temporal blocking) with NO shared memory and NO barriers: every wavefront is an
@@ -482,6 +356,17 @@ hipError_t launch_class(const PackedLaunch &l, hipStream_t stream)
 	const dim3 grid_deep(g.tiles_per_plane * runs), grid_flat(g.tiles_per_plane * runs);
 #define CA3D_LAUNCH_CLASS(ZR_, FAST_, P2_, GRID_) \
 	hipLaunchKernelGGL((ca_packed_class<MAIN, E, C_, ZR_, FAST_, P2_>), GRID_, dim3(256), 0, stream, l.in, l.out, l.pr, g, l.rules->prog)
+	const ClassJit *jit = l.class_jit;
+	if (p2 && jit && jit->main == MAIN && jit->e == E && jit->c == C_ && (deep ? jit->deep : jit->flat))
+	{
+		// the run-time compiled kernel for exactly these rules (truth tables baked in: ca_jit.cpp)
+		const u32 *in = l.in;
+		u32 *out = l.out;
+		PlaneRange pr = l.pr;
+		PackedRuleArgs prog = l.rules->prog;
+		void *args[] = {(void *)&in, (void *)&out, (void *)&pr, (void *)&g, (void *)&prog};
+		return hipModuleLaunchKernel((hipFunction_t)(deep ? jit->deep : jit->flat), grid_deep.x, 1, 1, 256, 1, 1, 0, stream, args, nullptr);
+	}
 	if (p2)
 	{
 		if (deep && fast) CA3D_LAUNCH_CLASS(ZRUN, true, true, grid_deep);
@@ -509,12 +394,19 @@ hipError_t launch_class_ec(const PackedLaunch &l, hipStream_t stream)
 	return launch_class<MAIN, false, false>(l, stream);
 }
 
+} // namespace
+
+int class_zrun(const CanonRules &r)
+{
+	const bool diagonals = r.need[1] || r.need[2] || r.main == MAIN_MOORE || r.main == MAIN_EDGES || r.main == MAIN_CORNERS;
+	return diagonals ? 4 : 2; // must match ZRUN of launch_class
+}
+
 bool use_class_kernel(const CanonRules &r, uint32_t G, int variant)
 {
 	return (variant & 0xFF) != 1 && r.fast && ((G / 32u) % 4u) == 0;
 }
 
-} // namespace
 
 const char *packed_kernel_name(const CanonRules &r, uint32_t G, int variant)
 {

@@ -23,16 +23,21 @@ def eng():
 def test_one_and_many_steps_random_fill(eng, G, name):
     r = rules(name)
     eng.configure(G)
-    set_rules(eng, r)
-    for rounds in (0, 3):
-        st = host.random_fill(host.words_per_buffer(G), seed=0xCA3D0001 + G, and_rounds=rounds)
-        eng.upload_state(st)
-        eng.step(1)
-        want1 = ol.packed_step(G, st, r)
-        np.testing.assert_array_equal(eng.read_state(), want1)
-        eng.step(4)
-        np.testing.assert_array_equal(eng.read_state(), ol.packed_run(G, want1, r, 4))
-        assert eng.info().step == 5
+    for jit in (1, 0):  # run-time compiled rule specialisation (where one applies), then the pre-built kernels
+        eng.set_option("jit", jit)
+        set_rules(eng, r)
+        # power-of-two grids from 128 up have a specialisation; the start-up rule's is pre-built from 256 up
+        assert (b"(jit)" in eng.info().kernel_name) == (bool(jit) and G >= 128 and not (name == "default" and G >= 256))
+        for rounds in (0, 3):
+            st = host.random_fill(host.words_per_buffer(G), seed=0xCA3D0001 + G, and_rounds=rounds)
+            eng.upload_state(st)
+            eng.step(1)
+            want1 = ol.packed_step(G, st, r)
+            np.testing.assert_array_equal(eng.read_state(), want1)
+            eng.step(4)
+            np.testing.assert_array_equal(eng.read_state(), ol.packed_run(G, want1, r, 4))
+            assert eng.info().step == 5
+    eng.set_option("jit", 1)
 
 
 @pytest.mark.parametrize("G", [256, 512])

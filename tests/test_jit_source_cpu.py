@@ -27,17 +27,28 @@ def _hiprtc():
     pytest.skip("hiprtc is not installed")
 
 
-@pytest.mark.parametrize("cvl,lut_s,lut_b", [(2, 0x2A, 0x14), (1, 0xFF, 0x0A), (6, 0x00, 0x7E)])
-def test_vn_kernel_source_compiles_with_hiprtc(cvl, lut_s, lut_b):
-    rtc = _hiprtc()
-    names = [b"ca_bitops.inc", b"ca_packed_vn_kernel.inc"]
-    sources = [open(os.path.join(CSRC, n.decode()), "rb").read() for n in names]
+CLASS_PROGRAM = b"""
+#include "ca_device_types.h"
+namespace ca3d
+{
+namespace jit
+{
+#include "ca_bitslice.inc"
+#include "ca_packed_class_kernel.inc"
+}
+}
+"""
+
+HEADERS = [b"ca_bitops.inc", b"ca_packed_vn_kernel.inc", b"ca_device_types.h", b"ca_bitslice.inc", b"ca_packed_class_kernel.inc"]
+
+
+def _compile(rtc, program, name, defines):
+    sources = [open(os.path.join(CSRC, n.decode()), "rb").read() for n in HEADERS]
     prog = C.c_void_p()
-    hs = (C.c_char_p * 2)(*sources)
-    hn = (C.c_char_p * 2)(*names)
-    assert rtc.hiprtcCreateProgram(C.byref(prog), PROGRAM, b"ca3d_jit_vn.hip", 2, hs, hn) == 0
-    opts = [b"--offload-arch=gfx950", b"-O3", b"-std=c++17", b"-DCA3D_JIT=1", b"-DCA3D_JIT_CVL=%d" % cvl,
-            b"-DCA3D_JIT_LS=%d" % lut_s, b"-DCA3D_JIT_LB=%d" % lut_b]
+    hs = (C.c_char_p * len(HEADERS))(*sources)
+    hn = (C.c_char_p * len(HEADERS))(*HEADERS)
+    assert rtc.hiprtcCreateProgram(C.byref(prog), program, name, len(HEADERS), hs, hn) == 0
+    opts = [b"--offload-arch=gfx950", b"-O3", b"-std=c++17", b"-DCA3D_JIT=1"] + defines
     rc = rtc.hiprtcCompileProgram(prog, len(opts), (C.c_char_p * len(opts))(*opts))
     n = C.c_size_t()
     rtc.hiprtcGetProgramLogSize(prog, C.byref(n))
@@ -48,5 +59,25 @@ def test_vn_kernel_source_compiles_with_hiprtc(cvl, lut_s, lut_b):
     assert rtc.hiprtcGetCodeSize(prog, C.byref(size)) == 0 and size.value > 1000
     code = C.create_string_buffer(size.value)
     assert rtc.hiprtcGetCode(prog, code) == 0
-    assert b"ca3d_jit_vn_zr1" in code.raw and b"ca3d_jit_vn_zr2" in code.raw
     rtc.hiprtcDestroyProgram(C.byref(prog))
+    return code.raw
+
+
+@pytest.mark.parametrize("main,e,c,zr,tables", [
+    (2, "true", "true", 4, (0x000000F0, 0x000000E0, 0x0038, 0x0010, 0x0014, 0x0008)),   # the clustered rule's shape
+    (3, "false", "false", 2, (0x000C, 0x0008, 0, 0, 0, 0)),                              # Moore 2D, life
+    (4, "false", "true", 4, (0x0350, 0x0244, 0, 0, 0x0002, 0x0000)),                     # edges main + corners set
+])
+def test_class_kernel_source_compiles_with_hiprtc(main, e, c, zr, tables):
+    rtc = _hiprtc()
+    defines = [b"-DCA3D_JIT_MAIN=%d" % main, b"-DCA3D_JIT_E=" + e.encode(), b"-DCA3D_JIT_C=" + c.encode(), b"-DCA3D_JIT_ZR=%d" % zr]
+    defines += [b"-DCA3D_JIT_%s=%du" % (n, t) for n, t in zip([b"TS0", b"TB0", b"TS1", b"TB1", b"TS2", b"TB2"], tables)]
+    code = _compile(rtc, CLASS_PROGRAM, b"ca3d_jit_class.hip", defines)
+    assert b"ca3d_jit_class_deep" in code and b"ca3d_jit_class_flat" in code
+
+
+@pytest.mark.parametrize("cvl,lut_s,lut_b", [(2, 0x2A, 0x14), (1, 0xFF, 0x0A), (6, 0x00, 0x7E)])
+def test_vn_kernel_source_compiles_with_hiprtc(cvl, lut_s, lut_b):
+    rtc = _hiprtc()
+    code = _compile(rtc, PROGRAM, b"ca3d_jit_vn.hip", [b"-DCA3D_JIT_CVL=%d" % cvl, b"-DCA3D_JIT_LS=%d" % lut_s, b"-DCA3D_JIT_LB=%d" % lut_b])
+    assert b"ca3d_jit_vn_zr1" in code and b"ca3d_jit_vn_zr2" in code

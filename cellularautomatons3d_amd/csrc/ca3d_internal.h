@@ -58,7 +58,8 @@ struct VnJit
 // Run-time compiled class kernels (rule as compile-time truth tables) for one (main table, live rule-sets, rule)
 struct ClassJit
 {
-	void *deep = nullptr, *flat = nullptr; // hipFunction_t: ZRUN planes per thread / 1 plane per thread
+	void *deep = nullptr, *deep_za = nullptr, *flat = nullptr; // hipFunction_t: ZRUN planes per thread (general /
+	                                                           // z-aligned ranges) / 1 plane per thread
 	int main = -1;
 	bool e = false, c = false;
 	uint32_t tables[6] = {0, 0, 0, 0, 0, 0}; // survive / born of main, edges, corners (bit k = value at count k)

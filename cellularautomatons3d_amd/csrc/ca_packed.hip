@@ -357,15 +357,22 @@ hipError_t launch_class(const PackedLaunch &l, hipStream_t stream)
 #define CA3D_LAUNCH_CLASS(ZR_, FAST_, P2_, GRID_) \
 	hipLaunchKernelGGL((ca_packed_class<MAIN, E, C_, ZR_, FAST_, P2_>), GRID_, dim3(256), 0, stream, l.in, l.out, l.pr, g, l.rules->prog)
 	const ClassJit *jit = l.class_jit;
-	if (p2 && jit && jit->main == MAIN && jit->e == E && jit->c == C_ && (deep ? jit->deep : jit->flat))
+	if (p2 && jit && jit->main == MAIN && jit->e == E && jit->c == C_ && jit->deep && jit->deep_za && jit->flat)
 	{
-		// the run-time compiled kernel for exactly these rules (truth tables baked in: ca_jit.cpp)
+		// the run-time compiled kernel for exactly these rules (truth tables baked in: ca_jit.cpp). z-aligned: every
+		// z-run starts on a global plane that is a multiple of ZRUN, so plane 0 is never in the middle of a run.
+		auto aligned = [&](u32 lo, u32 hi) {
+			const u32 zg = (u32)((l.pr.zbase + (int)lo) % (int)l.pr.G + (int)l.pr.G) % l.pr.G;
+			return zg % (u32)ZRUN == 0 && (hi - lo) % (u32)ZRUN == 0;
+		};
+		const bool za = l.pr.G % (u32)ZRUN == 0 && aligned(l.pr.lo, l.pr.hi) && (!two || aligned(l.pr.lo2, l.pr.hi2));
 		const u32 *in = l.in;
 		u32 *out = l.out;
 		PlaneRange pr = l.pr;
 		PackedRuleArgs prog = l.rules->prog;
 		void *args[] = {(void *)&in, (void *)&out, (void *)&pr, (void *)&g, (void *)&prog};
-		return hipModuleLaunchKernel((hipFunction_t)(deep ? jit->deep : jit->flat), grid_deep.x, 1, 1, 256, 1, 1, 0, stream, args, nullptr);
+		void *fn = deep ? (za ? jit->deep_za : jit->deep) : jit->flat;
+		return hipModuleLaunchKernel((hipFunction_t)fn, grid_deep.x, 1, 1, 256, 1, 1, 0, stream, args, nullptr);
 	}
 	if (p2)
 	{

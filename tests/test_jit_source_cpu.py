@@ -73,7 +73,7 @@ def test_class_kernel_source_compiles_with_hiprtc(main, e, c, zr, tables):
     defines = [b"-DCA3D_JIT_MAIN=%d" % main, b"-DCA3D_JIT_E=" + e.encode(), b"-DCA3D_JIT_C=" + c.encode(), b"-DCA3D_JIT_ZR=%d" % zr]
     defines += [b"-DCA3D_JIT_%s=%du" % (n, t) for n, t in zip([b"TS0", b"TB0", b"TS1", b"TB1", b"TS2", b"TB2"], tables)]
     code = _compile(rtc, CLASS_PROGRAM, b"ca3d_jit_class.hip", defines)
-    assert b"ca3d_jit_class_deep" in code and b"ca3d_jit_class_flat" in code
+    assert b"ca3d_jit_class_deep" in code and b"ca3d_jit_class_deep_za" in code and b"ca3d_jit_class_flat" in code
 
 
 @pytest.mark.parametrize("cvl,lut_s,lut_b", [(2, 0x2A, 0x14), (1, 0xFF, 0x0A), (6, 0x00, 0x7E)])

@@ -46,7 +46,8 @@ def parse():
     ap.add_argument("--render-size", default="1920x1080")
     ap.add_argument("--render-spp", type=int, default=4)
     ap.add_argument("--render-frames", type=int, default=10)
-    ap.add_argument("--no-overlap", action="store_true", help="N>1: exchange halos between batches instead of under the interior phase")
+    ap.add_argument("--overlap", choices=["auto", "on", "off"], default="auto",
+                    help="N>1: run the halo exchange under the interior phase of each batch (auto: by slab size, see slab.py)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="gloo = rehearsal transport through host memory")
     ap.add_argument("--device-map", default="", help="comma list: GPU index per rank (default: LOCAL_RANK)")
     ap.add_argument("--check", action="store_true", help="verify the final state against the oracle (small grids)")
@@ -183,7 +184,7 @@ def main():
         run = eng.step
         core = eng
     else:
-        se = slab.SlabEngine(G, rank, world, ghost=a.ghost, device=local_rank, host_staging=a.backend == "gloo", overlap=not a.no_overlap)
+        se = slab.SlabEngine(G, rank, world, ghost=a.ghost, device=local_rank, host_staging=a.backend == "gloo", overlap={"auto": "auto", "on": True, "off": False}[a.overlap])
         se.engine.set_rules(*offs, s, b)
         se.upload_state(full[se.z0 * pw:(se.z0 + se.nz) * pw])
         run = se.run
@@ -236,7 +237,7 @@ def main():
             "config": {"workload": f"{G}^3 uint32-packed grid, rule '{a.rule}' ({rule_kw['neighbourhood']} B{rule_kw['born']}/S{rule_kw['survive']}), "
                                    f"hashed fill seed 0xCA3D0001 density {2.0 ** -(1 + a.density_rounds):g}, one CA step per bench step",
                        "grid": G, "layout": "packed32", "rule": a.rule,
-                       "parallelism": "1 GPU" if world == 1 else f"z-slab x{world}, ghost {a.ghost} planes, RCCL send/recv every {a.ghost} steps" + ("" if a.no_overlap else " overlapped with the interior phase")},
+                       "parallelism": "1 GPU" if world == 1 else f"z-slab x{world}, ghost {a.ghost} planes, RCCL send/recv every {a.ghost} steps" + (" overlapped with the interior phase" if se.overlap else "")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(kernel, G),
                          "kernel": kernel, "launch_us": round(launch_ms * 1e3, 3),

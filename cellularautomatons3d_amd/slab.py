@@ -83,12 +83,14 @@ def batch_ranges(nz: int, ghost: int, n: int, s: int, dead_bottom: bool) -> Dict
 
 
 def exchange_halos(regions: Dict[str, "object"], plan: HaloPlan, rank: int, group=None, host_staging: bool = False,
-                   wait: bool = True) -> List:
+                   wait: bool = True, loopback: bool = False) -> List:
     """Refresh the ghost planes. `regions` maps 'send_low', 'send_high', 'recv_low', 'recv_high' to torch tensors
     (views of the current state buffer). Sends are posted low-then-high and receives high-then-low so that the
     two messages a pair of ranks may exchange in one direction (world == 2) match in order under RCCL, which
     ignores tags; gloo uses the tags. With wait=False the posted requests are returned instead of waited for
-    (RCCL: `wait()` later makes the then-current stream wait for the transfer, the host never blocks)."""
+    (RCCL: `wait()` later makes the then-current stream wait for the transfer, the host never blocks). A message
+    to oneself (world == 1, or the wrap of a one-rank chain) is a device copy unless `loopback` sends it through the
+    transport as well — the single-GPU rehearsal of the RCCL path."""
     import torch.distributed as dist
 
     if host_staging:
@@ -96,7 +98,7 @@ def exchange_halos(regions: Dict[str, "object"], plan: HaloPlan, rank: int, grou
         # rehearsal path only; RCCL moves the device buffers directly.
         staged = {k: v.cpu() for k, v in regions.items() if k.startswith("send")}
         staged.update({k: regions[k].new_empty(regions[k].shape, device="cpu") for k in ("recv_low", "recv_high")})
-        exchange_halos(staged, plan, rank, group, host_staging=False)
+        exchange_halos(staged, plan, rank, group, host_staging=False, loopback=loopback)
         if plan.recv_high_from is not None:
             regions["recv_high"].copy_(staged["recv_high"])
         if plan.recv_low_from is not None:
@@ -104,18 +106,18 @@ def exchange_halos(regions: Dict[str, "object"], plan: HaloPlan, rank: int, grou
         return []
     ops: List = []
     if plan.send_low_to is not None:
-        if plan.send_low_to == rank:
+        if plan.send_low_to == rank and not loopback:
             regions["recv_high"].copy_(regions["send_low"])
         else:
             ops.append(dist.P2POp(dist.isend, regions["send_low"], plan.send_low_to, group, TAG_TO_HIGH_GHOST))
     if plan.send_high_to is not None:
-        if plan.send_high_to == rank:
+        if plan.send_high_to == rank and not loopback:
             regions["recv_low"].copy_(regions["send_high"])
         else:
             ops.append(dist.P2POp(dist.isend, regions["send_high"], plan.send_high_to, group, TAG_TO_LOW_GHOST))
-    if plan.recv_high_from is not None and plan.recv_high_from != rank:
+    if plan.recv_high_from is not None and (plan.recv_high_from != rank or loopback):
         ops.append(dist.P2POp(dist.irecv, regions["recv_high"], plan.recv_high_from, group, TAG_TO_HIGH_GHOST))
-    if plan.recv_low_from is not None and plan.recv_low_from != rank:
+    if plan.recv_low_from is not None and (plan.recv_low_from != rank or loopback):
         ops.append(dist.P2POp(dist.irecv, regions["recv_low"], plan.recv_low_from, group, TAG_TO_LOW_GHOST))
     if not ops:
         return []
@@ -150,7 +152,8 @@ class SlabEngine:
     """
 
     def __init__(self, grid_size: int, rank: int, world: int, ghost: int, layout: int = LAYOUT_PACKED32,
-                 device: int = 0, group=None, engine=None, host_staging: bool = False, overlap: bool = True):
+                 device: int = 0, group=None, engine=None, host_staging: bool = False, overlap="auto",
+                 loopback: bool = False):
         import torch
 
         from .engine import Engine
@@ -166,7 +169,15 @@ class SlabEngine:
         self.engine = engine or Engine(device)
         self.engine.configure_slab(grid_size, self.z0, self.nz, ghost, layout)
         self.engine.set_stream(self.stream.cuda_stream)
-        self.overlap = overlap
+        # Overlapping the exchange costs two smaller launches per sub-step instead of one. Measured on one MI355X
+        # with the exchange through RCCL (tools/run_slab_rccl.py): it loses on slabs of 1024^2 planes (128 owned
+        # planes: 12.9 vs 10.9 us per step; 512 planes: 26.4 vs 24.7) and wins once a slab is a 1024^3-sized
+        # problem (256 planes of 2048^2: 47.7 vs 60.8 us per step). "auto" draws the line at 96 MiB of owned state.
+        if overlap == "auto":
+            info = self.engine.info()
+            overlap = info.state_words * 4 >= (96 << 20)
+        self.overlap = bool(overlap)
+        self.loopback = loopback
         self._regions = [None, None]
         self._parity = 0  # buffer `slab_region` refers to, mirrored here to save a round trip per batch
         self._ghosts_valid = False
@@ -187,7 +198,8 @@ class SlabEngine:
         import torch
 
         with torch.cuda.stream(self.stream):
-            return exchange_halos(self._current_regions(), self.plan, self.rank, self.group, self.host_staging, wait=wait)
+            return exchange_halos(self._current_regions(), self.plan, self.rank, self.group, self.host_staging, wait=wait,
+                                  loopback=self.loopback)
 
     def run(self, n_steps: int) -> None:
         """n CA steps in batches of up to `ghost` sub-steps. Asynchronous on the GPU. Per batch: edge zones ->

@@ -129,6 +129,37 @@ def test_unpacked_slabs_overlapped_schedule():
     np.testing.assert_array_equal(got, cur)
 
 
+@pytest.mark.parametrize("overlap", [True, False])
+def test_slab_engine_over_rccl_loopback(overlap):
+    """The product's exchange through the real transport on one GPU: a one-rank RCCL group, the wrap message (rank
+    0's first planes -> its own high ghost) sent to itself with ncclSend / ncclRecv on the engine's device memory,
+    posted between the edge and interior phases and waited for on the engine's stream."""
+    import socket
+
+    import torch
+    import torch.distributed as dist
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        G, K, steps = 256, 4, 14
+        r = rules("default")
+        full = host.random_fill(host.words_per_buffer(G), seed=91)
+        se = slab.SlabEngine(G, 0, 1, ghost=K, device=0, overlap=overlap, loopback=True)
+        set_rules(se.engine, r)
+        se.upload_state(full)
+        se.run(steps)
+        se.engine.synchronize()
+        got = se.engine.read_state()
+        se.close()
+        np.testing.assert_array_equal(got, ol.packed_run(G, full, r, steps))
+    finally:
+        dist.destroy_process_group()
+
+
 def test_slab_phase_order_is_enforced():
     from cellularautomatons3d_amd import SLAB_PHASE_EDGES, SLAB_PHASE_INTERIOR, Ca3dError, Engine
 
@@ -206,7 +237,8 @@ def test_slab_step_limits():
         e.close()
 
 
-def test_bench_two_ranks_on_one_gpu_gloo_rehearsal():
+@pytest.mark.parametrize("overlap", ["on", "off"])
+def test_bench_two_ranks_on_one_gpu_gloo_rehearsal(overlap):
     """bench.py's N > 1 path end to end with two processes sharing GPU 0 and gloo as a stand-in transport:
     slab engines, product halo plan, exchange every `ghost` steps, final state checked against the oracle."""
     import json
@@ -222,7 +254,7 @@ def test_bench_two_ranks_on_one_gpu_gloo_rehearsal():
     s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "21", "--warmup", "5",
-           "--grid", "256", "--ghost", "4", "--backend", "gloo", "--device-map", "0,0", "--check", "--no-cpu-baseline"]
+           "--grid", "256", "--ghost", "4", "--backend", "gloo", "--device-map", "0,0", "--check", "--no-cpu-baseline", "--overlap", overlap]
     r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]

@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--grid", type=int, default=0, help="grid edge (default: 512 at N=1, 1024 at N>1)")
     ap.add_argument("--rule", choices=sorted(RULES), default="default")
     ap.add_argument("--density-rounds", type=int, default=0, help="AND rounds of the hashed fill: density 2^-(1+r)")
-    ap.add_argument("--ghost", type=int, default=16, help="ghost planes per side = steps between halo exchanges (N>1)")
+    ap.add_argument("--ghost", type=int, default=32, help="ghost planes per side = steps between halo exchanges (N>1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-render", action="store_true", help="skip the renderer leg (N=1 only)")

@@ -63,6 +63,7 @@ struct ca3d_engine
 	int variant = 0;
 	int use_graph = 1;
 	int render_mode = 0;
+	int render_sched = 1; // dynamic ray scheduling in the converged-frame renderer (render.hip); 0: one pixel per lane, in order
 	int use_fused = 0; // the two-step fused kernel is bit-exact but measured slower than two single steps
 
 	// hipGraph of an even number of full-grid steps starting from buffer 0 (invalidated on any change)
@@ -776,6 +777,7 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 	l.depth = h->r_depth[h->r_swap];
 	l.counters = h->r_counters;
 	l.mode = h->render_mode;
+	l.sched = h->render_sched;
 	l.legacy = h->layout == CA3D_LAYOUT_UNPACKED; // legacy volume -> legacy shader (pathtraced_fragment.wgsl)
 	l.prev_light = h->r_light[h->r_swap ^ 1]; // group 1 of the render pass: last frame's targets (1519-1555, 1787)
 	l.prev_depth = h->r_depth[h->r_swap ^ 1];
@@ -816,6 +818,7 @@ int ca3d_set_option(ca3d_t *h, const char *name, int64_t value)
 {
 	if (!h || !name) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL argument");
 	if (!strcmp(name, "graph")) { h->use_graph = value ? 1 : 0; return CA3D_OK; }
+	if (!strcmp(name, "render_sched")) { h->render_sched = value ? 1 : 0; return CA3D_OK; }
 	if (!strcmp(name, "render_mode"))
 	{
 		if (value != 0 && value != 1) return fail(CA3D_ERR_INVALID_ARGUMENT, "render_mode must be 0 (converged frame) or 1 (one literal reference frame)");

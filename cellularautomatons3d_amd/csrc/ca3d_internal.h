@@ -98,6 +98,7 @@ struct RenderLaunch
 	int mode;                     // 0 converged frame (exact walk), 1 one literal reference frame with history
 	const void *prev_light;       // previous frame's RGBA16F (mode 1)
 	const uint32_t *prev_depth;   // previous frame's RG16F (mode 1)
+	int sched = 1;                // mode 0: dynamic ray scheduling inside each wave (same frame, bit for bit)
 };
 
 // render.hip

@@ -182,9 +182,17 @@ __device__ bool walk(const RenderParams &P, v3 start, v3 dir, float t0, float tm
 				}
 			}
 		}
-		if (tx <= ty && tx <= tz) { t = tx; tx += dx; ix += sx; if (ix < 0 || ix >= G) return false; }
-		else if (ty <= tz) { t = ty; ty += dy; iy += sy; if (iy < 0 || iy >= G) return false; }
-		else { t = tz; tz += dz; iz += sz; if (iz < 0 || iz >= G) return false; }
+		// advance along the axis whose boundary comes first — selects, not a three-way branch: the lanes of a wave
+		// step along different axes almost every time
+		const bool mx = tx <= ty && tx <= tz, my = !mx && ty <= tz, mz = !mx && !my;
+		t = mx ? tx : (my ? ty : tz);
+		tx += mx ? dx : 0.0f;
+		ty += my ? dy : 0.0f;
+		tz += mz ? dz : 0.0f;
+		ix += mx ? sx : 0;
+		iy += my ? sy : 0;
+		iz += mz ? sz : 0;
+		if ((u32)ix >= (u32)G || (u32)iy >= (u32)G || (u32)iz >= (u32)G) return false;
 	}
 	return false;
 }
@@ -341,6 +349,372 @@ __global__ __launch_bounds__(256) void ca_render_packed(RenderParams P)
 	if (P.presentation)
 	{
 		const float ig = P.legacy ? 1.0f / 2.2f : 1.0f / P.u[U_GAMMA]; // legacy gamma is the constant 2.2 (:704)
+		P.presentation[i] = unorm8(powf(r, ig)) | (unorm8(powf(g, ig)) << 8) | (unorm8(powf(b, ig)) << 16) | (unorm8(a) << 24);
+	}
+	if (P.counters)
+	{
+		atomicAdd(&P.counters[0], (unsigned long long)shadow);
+		atomicAdd(&P.counters[1], (unsigned long long)pvis);
+		atomicAdd(&P.counters[2], (unsigned long long)svis);
+	}
+}
+
+// ================================================================================================ scheduled form
+// The same frame as ca_render_packed, bit for bit, with the rays of a wave scheduled dynamically. In the plain
+// kernel a lane walks its pixel's samples one after the other and the wave waits for its longest walk every time:
+// walk lengths are roughly geometric, so only ~27 % of the lanes are doing work on average (PMC VALUUtilization on
+// the bench scene). Here a wave owns the 64 x spp sample jobs of its 64 pixels; a lane whose walk ends takes the next
+// job ("while-while" scheduling): the walk loop is left as soon as half of the walkers have finished (measured:
+// leaving at 1/4, 1/2, 3/4, 7/8 finished gives 1.94, 1.78, 1.85, 2.01 ms per 1080p 4 spp frame — the per-ray set-up
+// and shading code is as expensive as the walk itself, so it must not run with too few lanes either), finished
+// rays are shaded / turned into shadow rays / replaced by fresh primary rays, and everybody walks again. Primary and
+// shadow walks share one step function, so lanes in either phase step together. Results go to LDS per (sample,
+// pixel) and each lane then sums ITS pixel's samples in sample order, which keeps the float sums identical to
+// the plain kernel's.
+struct RayState
+{
+	int job;   // -1: idle
+	int phase; // 1: primary walk, 2: shadow walk
+	// Amanatides-Woo walk
+	v3 start, dir;
+	float tmax, t, tx, ty, tz, dx, dy, dz;
+	int ix, iy, iz, guard, wkey;
+	u32 word;
+	int cx, cy, cz; // shadow walk: the cell the ray starts in (exempt from the hit test); also the shaded cell
+	// sample context
+	v3 ray;       // view ray (world space)
+	float vu, tf; // screen u (show-depth split), distance at which the view ray leaves the volume
+	v3 p;         // shaded point
+	float depth;
+};
+
+__device__ __forceinline__ void walk_begin(const RenderParams &P, RayState &w, v3 start, v3 dir, float t0, float tmax)
+{
+	const int G = (int)P.G;
+	const float cs = 1.0f / (float)P.G;
+	const v3 p = start + dir * t0;
+	int ix = (int)floorf((p.x + kHalf) / cs), iy = (int)floorf((p.y + kHalf) / cs), iz = (int)floorf((p.z + kHalf) / cs);
+	ix = min(max(ix, 0), G - 1);
+	iy = min(max(iy, 0), G - 1);
+	iz = min(max(iz, 0), G - 1);
+	const int sx = dir.x > 0.0f ? 1 : -1, sy = dir.y > 0.0f ? 1 : -1, sz = dir.z > 0.0f ? 1 : -1;
+	const float big = 3.0e38f;
+	w.tx = dir.x != 0.0f ? (((float)(ix + (sx > 0 ? 1 : 0)) * cs - kHalf) - start.x) / dir.x : big;
+	w.ty = dir.y != 0.0f ? (((float)(iy + (sy > 0 ? 1 : 0)) * cs - kHalf) - start.y) / dir.y : big;
+	w.tz = dir.z != 0.0f ? (((float)(iz + (sz > 0 ? 1 : 0)) * cs - kHalf) - start.z) / dir.z : big;
+	w.dx = dir.x != 0.0f ? cs / fabsf(dir.x) : big;
+	w.dy = dir.y != 0.0f ? cs / fabsf(dir.y) : big;
+	w.dz = dir.z != 0.0f ? cs / fabsf(dir.z) : big;
+	w.start = start;
+	w.dir = dir;
+	w.tmax = tmax;
+	w.t = t0;
+	w.ix = ix; w.iy = iy; w.iz = iz;
+	w.word = 0;
+	w.wkey = -1;
+	w.guard = 0;
+}
+
+// One cell of `walk` above. 0: keep walking, 1: hit (tnear_out), 2: the ray left the volume / ran out of range.
+__device__ __forceinline__ int walk_step(const RenderParams &P, RayState &w, v3 half, bool shadow, float &tnear_out, u32 &visits)
+{
+	const int G = (int)P.G;
+	const float cs = 1.0f / (float)P.G;
+	if (w.guard >= 3 * G + 3) return 2;
+	w.guard++;
+	if (w.t >= w.tmax) return 2;
+	visits++;
+	bool alive;
+	if (P.legacy) alive = P.cells[(size_t)w.ix + ((size_t)w.iy + (size_t)w.iz * G) * G] == 1u;
+	else
+	{
+		const int key = (w.ix >> 5) + (w.iy + w.iz * G) * (int)P.cols;
+		if (key != w.wkey) { w.word = P.cells[key]; w.wkey = key; }
+		alive = (w.word >> (w.ix & 31)) & 1u;
+	}
+	if (alive)
+	{
+		if (!(shadow && w.ix == w.cx && w.iy == w.cy && w.iz == w.cz))
+		{
+			float tn, tf;
+			ray_cube(w.start, w.dir, cell_origin(cs, w.ix, w.iy, w.iz), half, tn, tf);
+			if (shadow ? (tn <= tf && tn >= 0.0f) : (tf >= 0.0f && tn <= tf))
+			{
+				tnear_out = tn;
+				return 1;
+			}
+		}
+	}
+	const int sx = w.dir.x > 0.0f ? 1 : -1, sy = w.dir.y > 0.0f ? 1 : -1, sz = w.dir.z > 0.0f ? 1 : -1;
+	const bool mx = w.tx <= w.ty && w.tx <= w.tz, my = !mx && w.ty <= w.tz, mz = !mx && !my;
+	w.t = mx ? w.tx : (my ? w.ty : w.tz);
+	w.tx += mx ? w.dx : 0.0f;
+	w.ty += my ? w.dy : 0.0f;
+	w.tz += mz ? w.dz : 0.0f;
+	w.ix += mx ? sx : 0;
+	w.iy += my ? sy : 0;
+	w.iz += mz ? sz : 0;
+	if ((u32)w.ix >= (u32)G || (u32)w.iy >= (u32)G || (u32)w.iz >= (u32)G) return 2;
+	return 0;
+}
+
+// The tail every sample goes through (shade_sample's last two blocks): light gizmo, show-depth split.
+__device__ __forceinline__ void sample_tail(const RenderParams &P, const RayState &st, Sample &s)
+{
+	const float *u = P.u;
+	const v3 cam = V(u[U_VIEW + 12], u[U_VIEW + 13], u[U_VIEW + 14]);
+	const v3 light_pos = V(u[U_LIGHT], u[U_LIGHT + 1], u[U_LIGHT + 2]);
+	float ln, lf;
+	ray_cube(cam, st.ray, light_pos, V(0.005f, 0.005f, 0.005f), ln, lf);
+	if (ln <= lf && lf >= 0.0f && s.r == 0.0f && s.g == 0.0f && s.b == 0.0f) { s.r = s.g = s.b = 1.0f; s.a = 1.0f; }
+	if (u[U_SHOWDEPTH] == 1.0f && st.vu < 0.5f) { s.r = s.depth; s.g = 0.0f; s.b = 0.0f; s.a = 1.0f; }
+}
+
+__device__ __forceinline__ void sample_clamp(Sample &s)
+{
+	s.r = fminf(fmaxf(s.r, 0.0f), 1.0f);
+	s.g = fminf(fmaxf(s.g, 0.0f), 1.0f);
+	s.b = fminf(fmaxf(s.b, 0.0f), 1.0f);
+	s.a = fminf(fmaxf(s.a, 0.0f), 1.0f);
+}
+
+// shade_sample up to the primary walk. true: the sample is complete (the view ray misses the volume).
+__device__ bool sample_begin(const RenderParams &P, RayState &st, float vu, float vv, Sample &s)
+{
+	const float *u = P.u;
+	const float *view = u + U_VIEW;
+	s = Sample{0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0u};
+	const v3 cam = V(view[12], view[13], view[14]);
+	const float r = u[U_WINDOW] / u[U_WINDOW + 1];
+	const v3 rl = norm3(V((vu - 0.5f) * r, vv - 0.5f, -(0.5f * P.cot_half_fov)));
+	const v3 ray = V(view[0] * rl.x + view[4] * rl.y + view[8] * rl.z, view[1] * rl.x + view[5] * rl.y + view[9] * rl.z,
+	                 view[2] * rl.x + view[6] * rl.y + view[10] * rl.z);
+	const v3 half = V(kHalf, kHalf, kHalf);
+	float tn, tf;
+	ray_cube(cam, ray, V(0.0f, 0.0f, 0.0f), half, tn, tf);
+	const float cam_dist = sd_box(cam, half);
+	st.ray = ray;
+	st.vu = vu;
+	if (tn <= tf && tf >= 0.0f)
+	{
+		v3 enter = cam;
+		const v3 exitp = cam + ray * tf;
+		if (cam_dist >= 0.0f) enter = cam + ray * tn;
+		const v3 seg = exitp - enter;
+		walk_begin(P, st, enter, norm3(seg), 0.0f, len3(seg));
+		st.tf = tf;
+		st.phase = 1;
+		return false;
+	}
+	sample_tail(P, st, s);
+	return true;
+}
+
+// shade_sample between the primary walk and the shadow walk. true: complete (nothing to light at the end point).
+__device__ bool sample_after_primary(const RenderParams &P, RayState &st, bool hit, float tnear, Sample &s)
+{
+	const float *u = P.u;
+	s = Sample{0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0u};
+	const v3 cam = V(u[U_VIEW + 12], u[U_VIEW + 13], u[U_VIEW + 14]);
+	const v3 half = V(kHalf, kHalf, kHalf);
+	const float cs = 1.0f / (float)P.G;
+	const float vis = cs * u[U_CELLSIZE] * 0.5f;
+	const v3 vhalf = V(vis, vis, vis);
+	const v3 exitp = cam + st.ray * st.tf;
+	const v3 final_point = hit ? st.start + st.dir * tnear : exitp;
+	s.depth = len3(final_point - cam);
+	const v3 p = cam + st.ray * s.depth;
+	const v3 f = V(floorf((p.x + kHalf) / cs), floorf((p.y + kHalf) / cs), floorf((p.z + kHalf) / cs));
+	const v3 origin = V(f.x * cs + cs * 0.5f - kHalf, f.y * cs + cs * 0.5f - kHalf, f.z * cs + cs * 0.5f - kHalf);
+	const int cx = (int)f.x, cy = (int)f.y, cz = (int)f.z;
+	const u32 state = cell_state(P, (u32)cx, (u32)cy, (u32)cz);
+	const float dist = sd_box(p - origin, vhalf);
+	st.depth = s.depth;
+	if (state == 1u && !(dist > 0.001f))
+	{
+		const v3 light_pos = V(u[U_LIGHT], u[U_LIGHT + 1], u[U_LIGHT + 2]);
+		const v3 ldir = norm3(light_pos - p);
+		float vn, vf;
+		ray_cube(p, ldir, V(0.0f, 0.0f, 0.0f), half, vn, vf);
+		const v3 vexit = p + ldir * vf;
+		const v3 sseg = vexit - p;
+		walk_begin(P, st, p, norm3(sseg), 0.0025f, len3(sseg));
+		st.cx = cx; st.cy = cy; st.cz = cz;
+		st.p = p;
+		st.phase = 2;
+		return false;
+	}
+	sample_clamp(s);
+	sample_tail(P, st, s);
+	return true;
+}
+
+// shade_sample after the shadow walk: lighting of st.p in cell (cx, cy, cz).
+__device__ void sample_after_shadow(const RenderParams &P, const RayState &st, bool occluded, Sample &s)
+{
+	const float *u = P.u;
+	s = Sample{0.0f, 0.0f, 0.0f, 1.0f, st.depth, 0u};
+	const v3 cam = V(u[U_VIEW + 12], u[U_VIEW + 13], u[U_VIEW + 14]);
+	const float cs = 1.0f / (float)P.G;
+	const v3 p = st.p;
+	const int cx = st.cx, cy = st.cy, cz = st.cz;
+	const v3 f = V((float)cx, (float)cy, (float)cz);
+	const v3 origin = V(f.x * cs + cs * 0.5f - kHalf, f.y * cs + cs * 0.5f - kHalf, f.z * cs + cs * 0.5f - kHalf);
+	const v3 light_pos = V(u[U_LIGHT], u[U_LIGHT + 1], u[U_LIGHT + 2]);
+	const float occ = occluded ? (P.legacy ? 0.095f : kOcclusion) : 1.0f;
+	if (P.legacy)
+	{
+		const v3 N = face_normal(p, origin);
+		const float Gf = (float)P.G;
+		const v3 colr = V(f.x / Gf, f.y / Gf, 1.0f - f.x / Gf);
+		const v3 view_dir = norm3(p - cam);
+		const float dl = len3(light_pos - p), dc = len3(cam - p);
+		const float fl = fmaxf(1.0f, powf(dl, 2.0f)), fc = fmaxf(1.0f, powf(dc, 2.0f));
+		const float incident = u[U_LIGHT + 3] / fl;
+		const v3 inc_dir = norm3(p - light_pos);
+		const float ndi = dot3(N, inc_dir);
+		const v3 refl = V(inc_dir.x - 2.0f * ndi * N.x, inc_dir.y - 2.0f * ndi * N.y, inc_dir.z - 2.0f * ndi * N.z);
+		const float reflected = incident * dot3(refl, V(-view_dir.x, -view_dir.y, -view_dir.z));
+		s.r = occ * ((colr.x * reflected + incident * colr.x) / fc);
+		s.g = occ * ((colr.y * reflected + incident * colr.y) / fc);
+		s.b = occ * ((colr.z * reflected + incident * colr.z) / fc);
+		s.a = occ;
+		s.shadow_ray = 1u;
+	}
+	else
+	{
+		const v3 N = face_normal(p, origin);
+		const float Gf = (float)P.G;
+		const float cxn = (float)(u32)cx / Gf, cyn = (float)(u32)cy / Gf;
+		v3 albedo = V(cxn, cyn, 1.0f - cxn);
+		if (u[U_MATERIALCOLOR] != 0.0f || u[U_MATERIALCOLOR + 1] != 0.0f || u[U_MATERIALCOLOR + 2] != 0.0f)
+			albedo = V(u[U_MATERIALCOLOR], u[U_MATERIALCOLOR + 1], u[U_MATERIALCOLOR + 2]);
+		const v3 Vd = norm3(cam - p);
+		const v3 L = norm3(light_pos - p);
+		const v3 F0 = V(u[U_REFLECTIVITY], u[U_REFLECTIVITY + 1], u[U_REFLECTIVITY + 2]);
+		const v3 brdf = surface_brdf(L, Vd, N, u[U_ROUGHNESS], albedo, F0);
+		const float mag = u[U_LIGHT + 3];
+		const float LoN = dot3(L, N);
+		s.r = occ * fmaxf(0.0f, brdf.x * mag * LoN);
+		s.g = occ * fmaxf(0.0f, brdf.y * mag * LoN);
+		s.b = occ * fmaxf(0.0f, brdf.z * mag * LoN);
+		s.shadow_ray = 1u;
+	}
+	sample_clamp(s);
+	sample_tail(P, st, s);
+}
+
+constexpr int kSchedChunk = 4; // samples per pixel scheduled together (LDS: 4 x 6 x 256 floats = 24 KiB per block)
+#ifndef CA3D_SCHED_LEAVE_DIV
+#define CA3D_SCHED_LEAVE_DIV 2
+#endif
+constexpr int kSchedLeaveDiv = CA3D_SCHED_LEAVE_DIV; // the walk loop is left when fewer than 1/N of its walkers are still walking
+
+__global__ __launch_bounds__(256) void ca_render_packed_sched(RenderParams P)
+{
+	__shared__ float res[kSchedChunk][6][256];
+	const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const u32 px = blockIdx.x * 16u + (threadIdx.x & 15u);
+	const u32 py = blockIdx.y * 16u + (threadIdx.x >> 4);
+	const float cs = 1.0f / (float)P.G;
+	const float vis = cs * P.u[U_CELLSIZE] * 0.5f;
+	const v3 vhalf = V(vis, vis, vis);
+	float r = 0.0f, g = 0.0f, b = 0.0f, a = 0.0f, d0 = 0.0f;
+	u32 shadow = 0, pvis = 0, svis = 0;
+	for (u32 k0 = 0; k0 < P.spp; k0 += (u32)kSchedChunk)
+	{
+		const int nk = (int)min((u32)kSchedChunk, P.spp - k0), total = 64 * nk;
+		int next = 0; // wave-uniform: first job nobody has taken
+		RayState st;
+		st.job = -1;
+		st.phase = 0;
+		auto complete = [&](const Sample &s) {
+			const int slot = wave * 64 + (st.job & 63), kk = st.job >> 6;
+			res[kk][0][slot] = s.r; res[kk][1][slot] = s.g; res[kk][2][slot] = s.b; res[kk][3][slot] = s.a;
+			res[kk][4][slot] = s.depth; res[kk][5][slot] = (float)s.shadow_ray;
+			st.job = -1;
+		};
+		for (;;)
+		{
+			// idle lanes take the next jobs, in lane order
+			const unsigned long long idle = __ballot(st.job < 0);
+			if (idle != 0ull && next < total)
+			{
+				const int j = next + __popcll(idle & ((1ull << lane) - 1ull));
+				if (st.job < 0 && j < total)
+				{
+					st.job = j;
+					const int lp = j & 63;
+					const u32 k = k0 + (u32)(j >> 6);
+					const u32 jx = blockIdx.x * 16u + (u32)(lp & 15), jy = blockIdx.y * 16u + (u32)(wave * 4 + (lp >> 4));
+					Sample s{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0u};
+					bool done = true;
+					if (jx < P.W && jy < P.H)
+					{
+						const float ox = P.spp == 1u ? 0.5f : ((k & 1u) ? 0.75f : 0.25f);
+						const float oy = P.spp == 1u ? 0.5f : ((k & 2u) ? 0.75f : 0.25f);
+						const float vu = ((float)jx + ox) / (float)P.W, vv = 1.0f - ((float)jy + oy) / (float)P.H;
+						done = sample_begin(P, st, vu, vv, s);
+					}
+					if (done) complete(s);
+				}
+				next += __popcll(idle);
+			}
+			const int entry = __popcll(__ballot(st.job >= 0));
+			if (entry == 0)
+			{
+				if (next >= total) break;
+				continue;
+			}
+			// walk until half of the walkers have finished (the tail of a chunk runs to the end)
+			const int leave_below = (next < total || entry > 16) ? max(entry / kSchedLeaveDiv, 1) : 1;
+			int term = 0;
+			float tnear = 0.0f;
+			for (;;)
+			{
+				if (st.job >= 0 && term == 0) term = walk_step(P, st, vhalf, st.phase == 2, tnear, st.phase == 2 ? svis : pvis);
+				const int walking = __popcll(__ballot(st.job >= 0 && term == 0));
+				if (walking == 0 || walking < leave_below) break;
+			}
+			if (st.job >= 0 && term != 0)
+			{
+				Sample s;
+				bool done = true;
+				if (st.phase == 1) done = sample_after_primary(P, st, term == 1, tnear, s);
+				else sample_after_shadow(P, st, term == 1, s);
+				if (done) complete(s);
+			}
+		}
+		// this lane's own pixel, samples in order: the same float sums as the plain kernel
+		__builtin_amdgcn_wave_barrier();
+		for (int kk = 0; kk < nk; kk++)
+		{
+			r += res[kk][0][tid]; g += res[kk][1][tid]; b += res[kk][2][tid]; a += res[kk][3][tid];
+			if (k0 == 0 && kk == 0) d0 = res[kk][4][tid];
+			shadow += (u32)res[kk][5][tid];
+		}
+		__builtin_amdgcn_wave_barrier();
+	}
+	if (px >= P.W || py >= P.H) return;
+	const float inv = 1.0f / (float)P.spp;
+	r *= inv; g *= inv; b *= inv; a *= inv;
+	const size_t i = (size_t)py * P.W + px;
+	if (P.light)
+	{
+		const __half2 rg = __floats2half2_rn(r, g), ba = __floats2half2_rn(b, 1.0f);
+		uint2 v;
+		v.x = *reinterpret_cast<const u32 *>(&rg);
+		v.y = *reinterpret_cast<const u32 *>(&ba);
+		P.light[i] = v;
+	}
+	if (P.depth)
+	{
+		const __half2 d = __floats2half2_rn(d0, 1.0f);
+		P.depth[i] = *reinterpret_cast<const u32 *>(&d);
+	}
+	if (P.presentation)
+	{
+		const float ig = P.legacy ? 1.0f / 2.2f : 1.0f / P.u[U_GAMMA];
 		P.presentation[i] = unorm8(powf(r, ig)) | (unorm8(powf(g, ig)) << 8) | (unorm8(powf(b, ig)) << 16) | (unorm8(a) << 24);
 	}
 	if (P.counters)
@@ -639,6 +1013,8 @@ hipError_t launch_render(const RenderLaunch &l, hipStream_t stream)
 		F.prev_depth = l.prev_depth;
 		hipLaunchKernelGGL(ca_render_frame_packed, grid, dim3(256), 0, stream, F);
 	}
+	else if (l.sched)
+		hipLaunchKernelGGL(ca_render_packed_sched, grid, dim3(256), 0, stream, P);
 	else
 		hipLaunchKernelGGL(ca_render_packed, grid, dim3(256), 0, stream, P);
 	return hipGetLastError();

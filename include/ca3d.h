@@ -199,7 +199,8 @@ int ca3d_get_render_stats(ca3d_t *h, ca3d_render_stats *out);
 /* Options (not part of the reference surface): "graph" 0/1 hipGraph batching; "fused" 0/1 two-step fused kernel
  * (bit-exact, off by default); "variant" 1 forces the generic / literal kernels; "jit" 0/1 run-time (hiprtc) specialisation of the step
  * kernel for the current rule, compiled inside ca3d_set_rules / ca3d_configure (on by default; a failed compile
- * silently keeps the pre-built kernels); "render_mode" 0/1;
+ * silently keeps the pre-built kernels); "render_mode" 0/1; "render_sched" 0/1 dynamic ray
+ * scheduling inside each wave of the renderer (on by default; the frame is the same bit for bit);
  * "render_reset_history". */
 int ca3d_set_option(ca3d_t *h, const char *name, int64_t value);
 

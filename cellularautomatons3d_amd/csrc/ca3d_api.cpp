@@ -64,7 +64,7 @@ struct ca3d_engine
 	int use_graph = 1;
 	int render_mode = 0;
 	int render_sched = 1; // dynamic ray scheduling in the converged-frame renderer (render.hip); 0: one pixel per lane, in order
-	int use_fused = 0; // the two-step fused kernel is bit-exact but measured slower than two single steps (DESIGN.md 4.5)
+	int use_fused = 0; // the two-step fused kernel is bit-exact but measured slower than two single steps (DESIGN.md 4.6)
 
 	// hipGraph of an even number of full-grid steps starting from buffer 0 (invalidated on any change)
 	hipGraphExec_t graph_exec = nullptr;

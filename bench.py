@@ -190,6 +190,8 @@ def main():
         run = se.run
         core = se.engine
 
+    if world == 1:
+        eng.set_option("graph_prepare", max(a.steps, a.warmup))  # graph capture / instantiation stays out of the timed region
     if a.warmup > 0:
         run(a.warmup)
     barrier()

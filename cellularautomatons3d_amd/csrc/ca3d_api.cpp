@@ -67,8 +67,8 @@ struct ca3d_engine
 	int use_fused = 0; // the two-step fused kernel is bit-exact but measured slower than two single steps
 
 	// hipGraph of an even number of full-grid steps starting from buffer 0 (invalidated on any change)
-	hipGraphExec_t graph_exec = nullptr;
-	uint32_t graph_steps = 0, graph_launches = 0;
+	hipGraphExec_t graph_exec[2] = {nullptr, nullptr}; // captured batches of kGraphSteps[i] steps from buffer 0
+	uint32_t graph_launches[2] = {0, 0};
 	std::map<uint64_t, hipGraphExec_t> slab_graphs; // (phase, start buffer, sub-steps) -> captured slab batch
 	uint32_t pending_edges = 0;                     // sub-steps of an edge phase awaiting its interior phase
 	int use_jit = 1;      // specialise kernels for the rule at run time (hiprtc) where a specialisation exists
@@ -101,12 +101,12 @@ namespace
 
 void drop_graph(ca3d_engine *h)
 {
-	if (h->graph_exec)
-	{
-		hipGraphExecDestroy(h->graph_exec);
-		h->graph_exec = nullptr;
-		h->graph_steps = 0;
-	}
+	for (int i = 0; i < 2; i++)
+		if (h->graph_exec[i])
+		{
+			hipGraphExecDestroy(h->graph_exec[i]);
+			h->graph_exec[i] = nullptr;
+		}
 	for (auto &kv : h->slab_graphs) hipGraphExecDestroy(kv.second);
 	h->slab_graphs.clear();
 }
@@ -241,7 +241,9 @@ int check_ready(ca3d_engine *h)
 	return CA3D_OK;
 }
 
-constexpr uint32_t kGraphSteps = 64;
+// Two graph sizes: consecutive graph launches leave ~9 us of idle GPU between them (measured on the slab path), which
+// is 0.13 us per step with 64-step graphs at 512^3 and negligible with 1024; short batches still get a graph.
+constexpr uint32_t kGraphSteps[2] = {1024, 64};
 
 // Launch plan for n steps that keeps the reference's ping-pong invariant (main_pathtraced.js:1580-1609): the
 // state after n steps sits in buffer (start + n) % 2 and the other buffer holds the state one step earlier. A
@@ -278,22 +280,21 @@ int enqueue_batch(ca3d_engine *h, uint32_t n, uint32_t start_buf, hipStream_t s,
 	return CA3D_OK;
 }
 
-int build_graph(ca3d_engine *h)
+int build_graph(ca3d_engine *h, int which)
 {
-	// Capture kGraphSteps steps starting at buffer 0: launch boundaries stay, the host cost per launch drops
+	// Capture kGraphSteps[which] steps starting at buffer 0: launch boundaries stay, the host cost per launch drops
 	// from ~4 us to the graph's amortised cost.
 	hipGraph_t graph = nullptr;
 	HIP_TRY(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
 	uint64_t launches = 0;
-	int rc = enqueue_batch(h, kGraphSteps, 0, h->stream, &launches);
+	int rc = enqueue_batch(h, kGraphSteps[which], 0, h->stream, &launches);
 	hipError_t e = hipStreamEndCapture(h->stream, &graph);
 	if (rc != CA3D_OK) { if (graph) hipGraphDestroy(graph); return rc; }
 	if (e != hipSuccess) return fail(CA3D_ERR_DEVICE, "hipStreamEndCapture: %s", hipGetErrorString(e));
-	e = hipGraphInstantiate(&h->graph_exec, graph, nullptr, nullptr, 0);
+	e = hipGraphInstantiate(&h->graph_exec[which], graph, nullptr, nullptr, 0);
 	hipGraphDestroy(graph);
-	if (e != hipSuccess) { h->graph_exec = nullptr; return fail(CA3D_ERR_DEVICE, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
-	h->graph_steps = kGraphSteps;
-	h->graph_launches = (uint32_t)launches;
+	if (e != hipSuccess) { h->graph_exec[which] = nullptr; return fail(CA3D_ERR_DEVICE, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
+	h->graph_launches[which] = (uint32_t)launches;
 	return CA3D_OK;
 }
 
@@ -493,21 +494,22 @@ int ca3d_step(ca3d_t *h, uint32_t n_steps)
 	// Graph replays are captured from buffer 0; take one single step first if the state sits in buffer 1.
 	while (left)
 	{
-		if (h->use_graph && h->stream != nullptr && h->cur == 0 && left >= kGraphSteps)
+		if (h->use_graph && h->stream != nullptr && h->cur == 0 && left >= kGraphSteps[1])
 		{
-			if (!h->graph_exec)
+			const int which = left >= kGraphSteps[0] ? 0 : 1;
+			if (!h->graph_exec[which])
 			{
-				rc = build_graph(h);
+				rc = build_graph(h, which);
 				if (rc) return rc;
 			}
-			HIP_TRY(hipGraphLaunch(h->graph_exec, h->stream));
-			h->step += h->graph_steps; // even: the buffer index is unchanged
-			left -= h->graph_steps;
-			launches += h->graph_launches;
+			HIP_TRY(hipGraphLaunch(h->graph_exec[which], h->stream));
+			h->step += kGraphSteps[which]; // even: the buffer index is unchanged
+			left -= kGraphSteps[which];
+			launches += h->graph_launches[which];
 			continue;
 		}
 		uint32_t n = left;
-		if (h->use_graph && h->stream != nullptr && left >= kGraphSteps) n = 1; // h->cur == 1: re-align for the graph
+		if (h->use_graph && h->stream != nullptr && left >= kGraphSteps[1]) n = 1; // h->cur == 1: re-align for the graph
 		rc = enqueue_batch(h, n, h->cur, h->stream, &launches);
 		if (rc) return rc;
 		h->step += n;
@@ -818,6 +820,22 @@ int ca3d_set_option(ca3d_t *h, const char *name, int64_t value)
 {
 	if (!h || !name) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL argument");
 	if (!strcmp(name, "graph")) { h->use_graph = value ? 1 : 0; return CA3D_OK; }
+	if (!strcmp(name, "graph_prepare"))
+	{
+		// capture and instantiate, now, the graphs a later ca3d_step(value) replays (otherwise built on first use)
+		int rc = check_ready(h);
+		if (rc) return rc;
+		rc = bind_device(h);
+		if (rc) return rc;
+		if (!h->use_graph || h->stream == nullptr || h->slab) return CA3D_OK;
+		for (int which = 0; which < 2; which++)
+			if ((uint64_t)value >= kGraphSteps[which] && !h->graph_exec[which])
+			{
+				rc = build_graph(h, which);
+				if (rc) return rc;
+			}
+		return CA3D_OK;
+	}
 	if (!strcmp(name, "render_sched")) { h->render_sched = value ? 1 : 0; return CA3D_OK; }
 	if (!strcmp(name, "render_mode"))
 	{

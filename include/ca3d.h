@@ -196,7 +196,8 @@ typedef struct ca3d_render_stats
 } ca3d_render_stats;
 int ca3d_get_render_stats(ca3d_t *h, ca3d_render_stats *out);
 
-/* Options (not part of the reference surface): "graph" 0/1 hipGraph batching; "fused" 0/1 two-step fused kernel
+/* Options (not part of the reference surface): "graph" 0/1 hipGraph batching; "graph_prepare" n builds now the
+ * graphs a later ca3d_step(n) replays (otherwise built on first use); "fused" 0/1 two-step fused kernel
  * (bit-exact, off by default); "variant" 1 forces the generic / literal kernels; "jit" 0/1 run-time (hiprtc) specialisation of the step
  * kernel for the current rule, compiled inside ca3d_set_rules / ca3d_configure (on by default; a failed compile
  * silently keeps the pre-built kernels); "render_mode" 0/1; "render_sched" 0/1 dynamic ray

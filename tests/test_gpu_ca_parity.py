@@ -245,6 +245,24 @@ def test_1024_cubed_one_step(eng):
     np.testing.assert_array_equal(eng.read_state(), ol.packed_step(G, st, r))
 
 
+def test_large_graph_replay_1024_steps(eng):
+    """ca3d_step replays captured graphs of 1024 and of 64 steps, then single launches: one call that uses all three
+    (and one from buffer 1, which first re-aligns with a single step) against the oracle."""
+    G = 128
+    r = rules("default")
+    eng.configure(G)
+    set_rules(eng, r)
+    st = host.random_fill(host.words_per_buffer(G), seed=21)
+    eng.upload_state(st)
+    eng.set_option("graph_prepare", 2000)
+    eng.step(1024 + 64 + 7)
+    want = ol.packed_run(G, st, r, 1024 + 64 + 7)
+    np.testing.assert_array_equal(eng.read_state(), want)
+    assert eng.info().current_buffer == 1
+    eng.step(1 + 1024)
+    np.testing.assert_array_equal(eng.read_state(), ol.packed_run(G, want, r, 1025))
+
+
 def test_graph_and_eager_agree(eng):
     G = 256
     r = rules("clustered")

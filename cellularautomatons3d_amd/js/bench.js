@@ -1,0 +1,55 @@
+#!/usr/bin/env node
+// The headline measurement from the JavaScript host (BASELINE north_star: "host code stays JavaScript (Node.js)
+// calling hand-written HIP kernels through a thin C-ABI shared library via N-API"): N CA steps of the 512^3 packed
+// grid, default rule, and 1080p / 4 spp frames, driven through ca3d.js -> ca3d_napi.node -> libca3d.so. Prints one
+// JSON line; bench.py (the driver's contract) measures the same kernels from Python.
+//   node cellularautomatons3d_amd/js/bench.js [--grid 512] [--steps 2048] [--warmup 256] [--frames 10 --uniforms u.f32]
+// The renderer leg needs the 128-float uniform block the UI's MemoryManager would supply (camera maths stays in
+// front of the engine): python -c "from cellularautomatons3d_amd import host; host.uniform_block(1920, 1080,
+// host.orbit_camera()).tofile('u.f32')"
+"use strict";
+const path = require("path");
+const c = require(path.join(__dirname, "ca3d.js"));
+
+const fs = require("fs");
+const arg = (name, dflt) => { const i = process.argv.indexOf("--" + name); return i > 0 ? Number(process.argv[i + 1]) : dflt; };
+const sarg = (name) => { const i = process.argv.indexOf("--" + name); return i > 0 ? process.argv[i + 1] : null; };
+const G = arg("grid", 512), steps = arg("steps", 2048), warmup = arg("warmup", 256), frames = arg("frames", 10);
+const uniformsPath = sarg("uniforms");
+
+const eng = new c.Engine(0);
+eng.configure(G);
+eng.setRuleStrings({});
+eng.uploadState(c.randomFill((G / 32) * G * G, 0xCA3D0001, 0));
+eng.setOption("graph_prepare", Math.max(steps, warmup));
+eng.step(warmup);
+eng.synchronize();
+const t0 = process.hrtime.bigint();
+eng.step(steps);
+eng.synchronize();
+const dt = Number(process.hrtime.bigint() - t0) / 1e9;
+const st = eng.stats();
+const launchUs = st.gpuMs * 1e3 / st.kernelLaunches;
+const out = {
+	metric: `Gcells/s CA step at ${G}^3 (Node.js host)`, value: +(G ** 3 * steps / dt / 1e9).toFixed(3), unit: "Gcells/s", steps, warmup,
+	ms_per_step: +(dt * 1e3 / steps).toFixed(6), kernel: eng.info().kernelName, launch_us: +launchUs.toFixed(3),
+	roofline_frac: +((0.25 * G ** 3) / (launchUs * 1e-6) / 8e12).toFixed(4), node: process.version
+};
+if (frames > 0 && uniformsPath)
+{
+	// a sparser scene for the renderer, as bench.py: density 2^-5
+	eng.uploadState(c.randomFill((G / 32) * G * G, 0xCA3D0001, 4));
+	const W = 1920, H = 1080, spp = 4;
+	const ub = fs.readFileSync(uniformsPath);
+	const u = new Float32Array(ub.buffer.slice(ub.byteOffset, ub.byteOffset + 512));
+	eng.render(u, W, H, spp, {});
+	eng.synchronize();
+	const r0 = process.hrtime.bigint();
+	for (let i = 0; i < frames; i++) { eng.render(u, W, H, spp, {}); }
+	eng.synchronize();
+	const rdt = Number(process.hrtime.bigint() - r0) / 1e9 / frames;
+	const rs = eng.renderStats();
+	out.render = { metric: "Mray/s path-trace 1080p", value: +((rs.primaryRays + rs.shadowRays) / rdt / 1e6).toFixed(2), ms_per_frame: +(rdt * 1e3).toFixed(4) };
+}
+console.log(JSON.stringify(out));
+eng.close();

@@ -70,3 +70,18 @@ def test_facade_runs_the_unmodified_reference_host_with_a_mock_engine():
 def test_facade_call_sequence_on_the_real_engine():
     r = _node("tests/js/facade_gpu_check.js")
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout + r.stderr)[-3000:]
+
+
+@pytest.mark.gpu
+def test_node_bench_reports_the_headline_metric(tmp_path):
+    """The north-star host path (Node.js -> N-API -> libca3d.so) timed end to end: js/bench.js on a small run."""
+    import json
+
+    from cellularautomatons3d_amd import host
+
+    host.uniform_block(1920, 1080, host.orbit_camera()).tofile(tmp_path / "u.f32")
+    r = _node("cellularautomatons3d_amd/js/bench.js", "--grid", "256", "--steps", "256", "--warmup", "64", "--frames", "2",
+              "--uniforms", str(tmp_path / "u.f32"))
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["kernel"].startswith("ca_packed_vn") and d["value"] > 100 and d["render"]["value"] > 10

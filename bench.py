@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--ghost", type=int, default=32, help="ghost planes per side = steps between halo exchanges (N>1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--no-render", action="store_true", help="skip the renderer leg (N=1 only)")
+    ap.add_argument("--no-render", action="store_true", help="skip the renderer leg")
     ap.add_argument("--render-size", default="1920x1080")
     ap.add_argument("--render-spp", type=int, default=4)
     ap.add_argument("--render-frames", type=int, default=10)
@@ -125,6 +125,54 @@ def render_leg(eng, G, a):
             "cell_visits_per_shadow_ray": round(st.shadow_cell_visits / max(1, st.shadow_rays), 2),
             "config": {"workload": f"{G}^3 packed volume, hashed fill density 2^-5, {W}x{H} @ {a.render_spp} spp, oblique pose "
                                    "(0.6 rad about (1,1,0), distance 1.4), exact DDA walk + shadow ray + Cook-Torrance"}}
+
+
+def render_leg_multi(se, G, a, world, rank, barrier):
+    """N > 1: the same scene rendered by all ranks together: each frame = all-gather of the packed
+    volume over RCCL + every rank's band of image rows + gather of the bands on rank 0. With --check rank 0 also
+    renders the frame alone and the two must be identical."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from cellularautomatons3d_amd import Engine, host, slab
+
+    W, H = (int(v) for v in a.render_size.lower().split("x"))
+    cells = host.random_fill(host.words_per_buffer(G), seed=0xCA3D0001, and_rounds=4)
+    pw = (G // 32) * G
+    se.upload_state(cells[se.z0 * pw:(se.z0 + se.nz) * pw])
+    sr = slab.SlabRenderer(se)
+    u = host.uniform_block(W, H, host.orbit_camera())
+    frame = sr.render(u, W, H, a.render_spp)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.render_frames):
+        frame = sr.render(u, W, H, a.render_spp)
+    barrier()
+    dt = time.perf_counter() - t0
+    y0, y1 = slab.band_rows(H, world, rank)
+    rays = 0
+    if y1 > y0:
+        st = sr.full.render_stats()
+        rays = int(st.primary_rays + st.shadow_rays)
+    t = torch.tensor([rays], dtype=torch.int64, device="cuda" if a.backend == "nccl" else "cpu")
+    dist.all_reduce(t)
+    out = None
+    if rank == 0:
+        out = {"metric": "Mray/s path-trace 1080p", "value": round(int(t.item()) * a.render_frames / dt / 1e6, 2), "unit": "Mray/s",
+               "ms_per_frame": round(dt * 1e3 / a.render_frames, 4),
+               "config": {"workload": f"{G}^3 packed volume all-gathered to every rank, hashed fill density 2^-5, {W}x{H} @ {a.render_spp} spp, "
+                                      f"bands of image rows over {world} ranks, frame assembled on rank 0 (read-back included)"}}
+        if a.check:
+            solo = Engine(se.device)
+            solo.configure(G)
+            solo.set_rule_strings()
+            solo.upload_state(cells)
+            want, _, _ = solo.render(u, W, H, a.render_spp)
+            solo.close()
+            out["frame_match"] = bool(np.array_equal(frame, want))
+    sr.close()
+    return out
 
 
 def pmc_traffic(kernel, G):
@@ -225,6 +273,10 @@ def main():
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             ok = bool(flag.item())
 
+    multi_render = None
+    if world > 1 and not a.no_render:
+        multi_render = render_leg_multi(se, G, a, world, rank, barrier)
+
     if rank == 0:
         # dominant kernel: HIP events on the engine's stream around the last step batch (get_stats), divided by the
         # launches in it; algorithmic bytes per launch = 0.25 B x cells the launch updates.
@@ -249,6 +301,10 @@ def main():
             out["oracle_match"] = ok
         if world == 1 and not a.no_render:
             out["render"] = render_leg(eng, G, a)
+        if multi_render is not None:
+            out["render"] = multi_render
+            if multi_render.get("frame_match") is False:
+                ok = False
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(G, rule_kw, a.cpu_seconds)
             out["cpu_baseline_js"] = cpu_baseline_js()

@@ -64,6 +64,7 @@ struct ca3d_engine
 	int use_graph = 1;
 	int render_mode = 0;
 	int render_sched = 1; // dynamic ray scheduling in the converged-frame renderer (render.hip); 0: one pixel per lane, in order
+	uint32_t render_row0 = 0, render_row1 = 0; // rows [row0, row1) of the frame are rendered (0, 0: all): a rank's band
 	int use_fused = 0; // the two-step fused kernel is bit-exact but measured slower than two single steps
 
 	// hipGraph of an even number of full-grid steps starting from buffer 0 (invalidated on any change)
@@ -780,6 +781,10 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 	l.counters = h->r_counters;
 	l.mode = h->render_mode;
 	l.sched = h->render_sched;
+	l.row0 = h->render_row0;
+	l.row1 = h->render_row1 > height ? height : h->render_row1;
+	if (l.row1 && l.row0 >= l.row1) return fail(CA3D_ERR_INVALID_ARGUMENT, "render rows [%u, %u) are empty for a target of %u rows", l.row0, h->render_row1, height);
+	if ((l.row0 || l.row1) && h->render_mode != 0) return fail(CA3D_ERR_UNSUPPORTED, "row bands are implemented for the converged-frame mode only");
 	l.legacy = h->layout == CA3D_LAYOUT_UNPACKED; // legacy volume -> legacy shader (pathtraced_fragment.wgsl)
 	l.prev_light = h->r_light[h->r_swap ^ 1]; // group 1 of the render pass: last frame's targets (1519-1555, 1787)
 	l.prev_depth = h->r_depth[h->r_swap ^ 1];
@@ -788,7 +793,7 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 	if (e != hipSuccess) return fail(CA3D_ERR_DEVICE, "render launch failed: %s", hipGetErrorString(e));
 	HIP_TRY(hipEventRecord(h->rev_stop, h->stream));
 	h->rev_valid = true;
-	h->rstats.primary_rays = (uint64_t)px * spp;
+	h->rstats.primary_rays = (uint64_t)width * ((l.row1 ? l.row1 : height) - l.row0) * spp;
 	if (presentation_rgba8) HIP_TRY(hipMemcpyAsync(presentation_rgba8, h->r_present, px * 4, hipMemcpyDeviceToHost, h->stream));
 	if (light_rgba16f) HIP_TRY(hipMemcpyAsync(light_rgba16f, h->r_light[h->r_swap], px * 8, hipMemcpyDeviceToHost, h->stream));
 	if (depth_rg16f) HIP_TRY(hipMemcpyAsync(depth_rg16f, h->r_depth[h->r_swap], px * 4, hipMemcpyDeviceToHost, h->stream));
@@ -837,6 +842,17 @@ int ca3d_set_option(ca3d_t *h, const char *name, int64_t value)
 		return CA3D_OK;
 	}
 	if (!strcmp(name, "render_sched")) { h->render_sched = value ? 1 : 0; return CA3D_OK; }
+	if (!strcmp(name, "render_row_begin") || !strcmp(name, "render_row_end"))
+	{
+		if (value < 0 || value > 16384) return fail(CA3D_ERR_INVALID_ARGUMENT, "row %lld is outside any target", (long long)value);
+		if (name[11] == 'b')
+		{
+			if (value % 16) return fail(CA3D_ERR_INVALID_ARGUMENT, "render_row_begin must be a multiple of 16 (the renderer's tile height)");
+			h->render_row0 = (uint32_t)value;
+		}
+		else h->render_row1 = (uint32_t)value;
+		return CA3D_OK;
+	}
 	if (!strcmp(name, "render_mode"))
 	{
 		if (value != 0 && value != 1) return fail(CA3D_ERR_INVALID_ARGUMENT, "render_mode must be 0 (converged frame) or 1 (one literal reference frame)");

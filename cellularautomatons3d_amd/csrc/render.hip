@@ -51,6 +51,7 @@ struct RenderParams
 	u32 *depth;                // RG16F
 	unsigned long long *counters; // [0] shadow rays, [1] primary cell visits, [2] shadow cell visits
 	u32 legacy; // 1: one-u32-per-cell volume + the shading of shaders/pathtraced_fragment.wgsl (R-legacy)
+	u32 row0, row1; // only image rows [row0, row1) are rendered (a rank's band of a frame shared between GPUs); row0 is a multiple of 16
 };
 
 constexpr float kPi = 3.14159265359f;
@@ -316,8 +317,8 @@ __device__ __forceinline__ u32 unorm8(float x) { return (u32)__float2int_rn(fmin
 __global__ __launch_bounds__(256) void ca_render_packed(RenderParams P)
 {
 	const u32 px = blockIdx.x * 16u + (threadIdx.x & 15u);
-	const u32 py = blockIdx.y * 16u + (threadIdx.x >> 4);
-	if (px >= P.W || py >= P.H) return;
+	const u32 py = P.row0 + blockIdx.y * 16u + (threadIdx.x >> 4);
+	if (px >= P.W || py >= P.row1) return;
 	float r = 0.0f, g = 0.0f, b = 0.0f, a = 0.0f, d0 = 0.0f;
 	u32 shadow = 0, pvis = 0, svis = 0;
 	for (u32 k = 0; k < P.spp; k++)
@@ -615,7 +616,7 @@ __global__ __launch_bounds__(256) void ca_render_packed_sched(RenderParams P)
 	__shared__ float res[kSchedChunk][6][256];
 	const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const u32 px = blockIdx.x * 16u + (threadIdx.x & 15u);
-	const u32 py = blockIdx.y * 16u + (threadIdx.x >> 4);
+	const u32 py = P.row0 + blockIdx.y * 16u + (threadIdx.x >> 4);
 	const float cs = 1.0f / (float)P.G;
 	const float vis = cs * P.u[U_CELLSIZE] * 0.5f;
 	const v3 vhalf = V(vis, vis, vis);
@@ -646,10 +647,10 @@ __global__ __launch_bounds__(256) void ca_render_packed_sched(RenderParams P)
 					st.job = j;
 					const int lp = j & 63;
 					const u32 k = k0 + (u32)(j >> 6);
-					const u32 jx = blockIdx.x * 16u + (u32)(lp & 15), jy = blockIdx.y * 16u + (u32)(wave * 4 + (lp >> 4));
+					const u32 jx = blockIdx.x * 16u + (u32)(lp & 15), jy = P.row0 + blockIdx.y * 16u + (u32)(wave * 4 + (lp >> 4));
 					Sample s{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0u};
 					bool done = true;
-					if (jx < P.W && jy < P.H)
+					if (jx < P.W && jy < P.row1)
 					{
 						const float ox = P.spp == 1u ? 0.5f : ((k & 1u) ? 0.75f : 0.25f);
 						const float oy = P.spp == 1u ? 0.5f : ((k & 2u) ? 0.75f : 0.25f);
@@ -695,7 +696,7 @@ __global__ __launch_bounds__(256) void ca_render_packed_sched(RenderParams P)
 		}
 		__builtin_amdgcn_wave_barrier();
 	}
-	if (px >= P.W || py >= P.H) return;
+	if (px >= P.W || py >= P.row1) return;
 	const float inv = 1.0f / (float)P.spp;
 	r *= inv; g *= inv; b *= inv; a *= inv;
 	const size_t i = (size_t)py * P.W + px;
@@ -1004,7 +1005,9 @@ hipError_t launch_render(const RenderLaunch &l, hipStream_t stream)
 	P.depth = l.depth;
 	P.counters = l.counters;
 	P.legacy = l.legacy ? 1u : 0u;
-	const dim3 grid((l.W + 15u) / 16u, (l.H + 15u) / 16u);
+	P.row0 = l.row0;
+	P.row1 = l.row1 ? l.row1 : l.H;
+	const dim3 grid((l.W + 15u) / 16u, (l.mode == 1 ? l.H + 15u : P.row1 - P.row0 + 15u) / 16u);
 	if (l.mode == 1)
 	{
 		FrameParams F;

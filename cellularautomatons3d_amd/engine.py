@@ -149,13 +149,16 @@ class Engine:
         _capi.check(self._lib.ca3d_set_option(self._h, name.encode(), int(value)))
 
     # -- rendering ------------------------------------------------------------------------------------------
-    def render(self, uniforms, width: int, height: int, spp: int = 1, readback: bool = True):
+    def render(self, uniforms, width: int, height: int, spp: int = 1, readback: bool = True, rows=None):
         """`_renderPass` on the current state. Returns (presentation u8[H,W,4], light f16[H,W,4], depth f16[H,W,2])
-        when `readback`, else None (targets stay on the device)."""
+        when `readback`, else None (targets stay on the device). `rows` = (begin, end): only that band of image rows
+        is rendered (begin a multiple of 16) — the other rows of the returned arrays are whatever the targets held."""
         u = np.ascontiguousarray(uniforms, dtype=np.float32)
         if u.size != 128:
             raise ValueError("the common uniform block holds 128 floats")
         up = u.ctypes.data_as(C.POINTER(C.c_float))
+        self.set_option("render_row_begin", rows[0] if rows else 0)
+        self.set_option("render_row_end", rows[1] if rows else 0)
         if not readback:
             _capi.check(self._lib.ca3d_render(self._h, up, width, height, spp, None, None, None))
             return None

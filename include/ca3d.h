@@ -200,7 +200,9 @@ int ca3d_get_render_stats(ca3d_t *h, ca3d_render_stats *out);
  * graphs a later ca3d_step(n) replays (otherwise built on first use); "fused" 0/1 two-step fused kernel
  * (bit-exact, off by default); "variant" 1 forces the generic / literal kernels; "jit" 0/1 run-time (hiprtc) specialisation of the step
  * kernel for the current rule, compiled inside ca3d_set_rules / ca3d_configure (on by default; a failed compile
- * silently keeps the pre-built kernels); "render_mode" 0/1; "render_sched" 0/1 dynamic ray
+ * silently keeps the pre-built kernels); "render_mode" 0/1; "render_row_begin" / "render_row_end":
+ * ca3d_render then fills image rows [begin, end) only (begin a multiple of 16; 0 / 0 = the whole frame) — a rank's
+ * band when the GPUs of a node share one frame; "render_sched" 0/1 dynamic ray
  * scheduling inside each wave of the renderer (on by default; the frame is the same bit for bit);
  * "render_reset_history". */
 int ca3d_set_option(ca3d_t *h, const char *name, int64_t value);

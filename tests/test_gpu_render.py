@@ -124,6 +124,32 @@ def test_full_hd_band_at_512(eng):
     _compare(eng, cells, G, host.uniform_block(W, H, host.orbit_camera()), W, H, 4, rows=(520, 544))
 
 
+def test_row_bands_stitch_into_the_full_frame(eng):
+    """A frame shared between GPUs is rendered in bands of image rows: the bands of one engine, stitched,
+    are the full frame bit for bit; rows outside a band are left untouched."""
+    G, W, H = 64, 200, 150
+    cells = host.random_fill(host.words_per_buffer(G), seed=5, and_rounds=3)
+    eng.configure(G)
+    set_rules(eng, rules("default"))
+    eng.upload_state(cells)
+    u = host.uniform_block(W, H, host.orbit_camera())
+    pres, light, depth = eng.render(u, W, H, 4)
+    got = np.zeros_like(pres)
+    for y0, y1 in ((0, 48), (48, 64), (64, 150)):
+        p, l, d = eng.render(u, W, H, 4, rows=(y0, y1))
+        got[y0:y1] = p[y0:y1]
+        np.testing.assert_array_equal(l[y0:y1].view(np.uint16), light[y0:y1].view(np.uint16))
+        np.testing.assert_array_equal(d[y0:y1].view(np.uint16), depth[y0:y1].view(np.uint16))
+        assert eng.render_stats().primary_rays == W * (y1 - y0) * 4
+    np.testing.assert_array_equal(got, pres)
+    from cellularautomatons3d_amd import Ca3dError
+    with pytest.raises(Ca3dError):
+        eng.render(u, W, H, 1, rows=(8, 64))     # a band starts on a tile row
+    with pytest.raises(Ca3dError):
+        eng.render(u, W, H, 1, rows=(160, 176))  # empty for this target
+    eng.render(u, W, H, 1)                       # rows=None restores the whole frame
+
+
 def test_render_errors(eng):
     from cellularautomatons3d_amd import Ca3dError
 

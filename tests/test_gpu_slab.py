@@ -154,10 +154,50 @@ def test_slab_engine_over_rccl_loopback(overlap):
         se.run(steps)
         se.engine.synchronize()
         got = se.engine.read_state()
+        want = ol.packed_run(G, full, r, steps)
+        np.testing.assert_array_equal(got, want)
+        # the renderer's volume gather through ncclAllGather on the engines' device buffers
+        sr = slab.SlabRenderer(se)
+        sr.gather_volume()
+        torch.cuda.synchronize()
+        vol = slab.device_tensor(*sr.full.device_buffer(0), 0).cpu().numpy().view(np.uint32)
+        np.testing.assert_array_equal(vol, want)
+        sr.close()
         se.close()
-        np.testing.assert_array_equal(got, ol.packed_run(G, full, r, steps))
     finally:
         dist.destroy_process_group()
+
+
+def test_slab_renderer_single_rank_equals_plain_render():
+    """SlabRenderer (volume gather + band render + band gather) on a one-rank chain: the frame of the stepped slab
+    state equals the frame a plain engine renders of the same state."""
+    from cellularautomatons3d_amd import Engine
+
+    G, K, steps, W, H = 128, 4, 6, 240, 136
+    r = rules("default")
+    full = host.random_fill(host.words_per_buffer(G), seed=17, and_rounds=2)
+    se = slab.SlabEngine(G, 0, 1, ghost=K, device=0)
+    set_rules(se.engine, r)
+    se.upload_state(full)
+    se.run(steps)
+    sr = slab.SlabRenderer(se)
+    u = host.uniform_block(W, H, host.orbit_camera())
+    frame = sr.render(u, W, H, 4)
+    state = se.engine.read_state()
+    sr.close()
+    se.close()
+    np.testing.assert_array_equal(state, ol.packed_run(G, full, r, steps))
+    e = Engine(0)
+    try:
+        e.configure(G)
+        set_rules(e, r)
+        e.upload_state(state)
+        want, _, _ = e.render(u, W, H, 4)
+    finally:
+        e.close()
+    np.testing.assert_array_equal(frame, want)
+    assert slab.band_rows(1080, 8, 0) == (0, 128) and slab.band_rows(1080, 8, 7) == (944, 1080)
+    assert [slab.band_rows(40, 4, k) for k in range(4)] == [(0, 0), (0, 16), (16, 32), (32, 40)]
 
 
 def test_slab_phase_order_is_enforced():
@@ -254,10 +294,12 @@ def test_bench_two_ranks_on_one_gpu_gloo_rehearsal(overlap):
     s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "21", "--warmup", "5",
-           "--grid", "256", "--ghost", "4", "--backend", "gloo", "--device-map", "0,0", "--check", "--no-cpu-baseline", "--overlap", overlap]
+           "--grid", "256", "--ghost", "4", "--backend", "gloo", "--device-map", "0,0", "--check", "--no-cpu-baseline", "--overlap", overlap,
+           "--render-size", "640x360", "--render-frames", "2"]
     r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["oracle_match"] is True and d["scaling"] == "strong"
+    assert d["render"]["frame_match"] is True and d["render"]["value"] > 0  # the two ranks' bands == one GPU's frame
     assert d["roofline"]["kernel"].startswith("ca_packed_vn")

@@ -175,6 +175,26 @@ def render_leg_multi(se, G, a, world, rank, barrier):
     return out
 
 
+def copy_ceiling_gbs():
+    """Measured device-to-device copy rate (read + write bytes per second) of a 1 GiB buffer: the practical HBM
+    ceiling SURVEY 8(d) asks to be reported next to the 8 TB/s vendor peak."""
+    import torch
+
+    n = 1 << 30
+    a = torch.empty(n, dtype=torch.uint8, device="cuda")
+    b = torch.empty(n, dtype=torch.uint8, device="cuda")
+    a.zero_()
+    b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(8):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * n * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def pmc_traffic(kernel, G):
     """HBM bytes per launch from a committed rocprofv3 PMC run (profiles/pmc_traffic.json), or None."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -297,6 +317,10 @@ def main():
                          "kernel": kernel, "launch_us": round(launch_ms * 1e3, 3),
                          "algorithmic_bytes_per_launch": bytes_per_launch, "launches_timed": int(st.kernel_launches)},
         }
+        if world == 1:
+            ceiling = copy_ceiling_gbs()
+            out["roofline"]["copy_ceiling"] = round(ceiling, 1)  # GB/s, measured here: 1 GiB device-to-device copy, read + write
+            out["roofline"]["frac_of_copy_ceiling"] = round(achieved / ceiling, 4)
         if ok is not None:
             out["oracle_match"] = ok
         if world == 1 and not a.no_render:

@@ -875,7 +875,7 @@ int ca3d_set_option(ca3d_t *h, const char *name, int64_t value)
 	if (!strcmp(name, "fused")) { drop_graph(h); h->use_fused = value ? 1 : 0; return CA3D_OK; }
 	if (!strcmp(name, "variant"))
 	{
-		if (value < 0 || value > 0x2FF) return fail(CA3D_ERR_INVALID_ARGUMENT, "variant must be 0 (auto) or 1 (generic kernel)");
+		if (value != 0 && value != 1) return fail(CA3D_ERR_INVALID_ARGUMENT, "variant must be 0 (auto) or 1 (generic kernel)");
 		drop_graph(h);
 		h->variant = (int)value;
 		refresh_kernels(h);

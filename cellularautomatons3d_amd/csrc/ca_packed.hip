@@ -45,7 +45,6 @@ struct FusedGeom
 	u32 LPR, lpr_shift; // lanes per row (C / W), power of two, <= 8
 	u32 nstrips;        // strips along y
 	u32 nchunks;        // chunks along z
-	u32 dbg;            // profiling aid: 1 = skip the compute (memory phases only), 2 = skip the stores too
 };
 
 template <int W> struct VecT;
@@ -186,9 +185,8 @@ __global__ __launch_bounds__(64) void ca_packed_fused(const u32 *__restrict__ in
 #pragma unroll
 		for (int k = 0; k < W; k++) val[k] = raw[i][k] & m0;
 		R0[i] = rows_of(val);
-		if (g.dbg) { R1[i] = R0[i]; }
 		// ---- generation 1 of plane p-1 (stream index i-1)
-		if (!g.dbg && i >= 2)
+		if (i >= 2)
 		{
 			const int p1 = p - 1;
 			bool zl1, zd1;
@@ -207,20 +205,12 @@ __global__ __launch_bounds__(64) void ca_packed_fused(const u32 *__restrict__ in
 		{
 			const int p2 = p - 2;
 			u32 o[W];
-			if (!g.dbg)
-			{
-				bool zd2;
-				if (pr.wrap_full) { const int w2 = p2 >= G ? p2 - G : p2; zd2 = w2 == 0; }
-				else { zd2 = global_z(pr, (u32)p2) == 0; }
-				if (FAST) evolve<W, MAIN, E, C_>(R1[i - 3], R1[i - 2], R1[i - 1], zd2 ? 0u : 0xFFFFFFFFu, frules, o);
-				else evolve<W, MAIN, E, C_>(R1[i - 3], R1[i - 2], R1[i - 1], zd2 ? 0u : 0xFFFFFFFFu, rules_in, o);
-			}
-			else
-			{
-#pragma unroll
-				for (int k = 0; k < W; k++) o[k] = R1[i - 2].c.w[k];
-			}
-			if (g.dbg != 2 && store_row && p2 >= (int)pr.lo && p2 < (int)pr.hi && p2 < zc0 + ZC)
+			bool zd2;
+			if (pr.wrap_full) { const int w2 = p2 >= G ? p2 - G : p2; zd2 = w2 == 0; }
+			else { zd2 = global_z(pr, (u32)p2) == 0; }
+			if (FAST) evolve<W, MAIN, E, C_>(R1[i - 3], R1[i - 2], R1[i - 1], zd2 ? 0u : 0xFFFFFFFFu, frules, o);
+			else evolve<W, MAIN, E, C_>(R1[i - 3], R1[i - 2], R1[i - 1], zd2 ? 0u : 0xFFFFFFFFu, rules_in, o);
+			if (store_row && p2 >= (int)pr.lo && p2 < (int)pr.hi && p2 < zc0 + ZC)
 				vec_store<W>(out + (size_t)p2 * plane_words + (size_t)gy * C + cx0, o);
 		}
 	}
@@ -245,7 +235,6 @@ bool fused_geometry(uint32_t G, FusedGeom *g, int *words_per_lane)
 	const u32 UR = 64u / LPR - 4u;
 	g->nstrips = (G + UR - 1u) / UR;
 	g->nchunks = 0;
-	g->dbg = 0;
 	*words_per_lane = W;
 	return true;
 }
@@ -256,7 +245,6 @@ hipError_t launch_fused_w(const PackedLaunch &l, hipStream_t stream, FusedGeom g
 {
 	const u32 planes = l.pr.hi - l.pr.lo;
 	g.nchunks = (planes + kFuseZC - 1) / kFuseZC;
-	g.dbg = (u32)(l.variant >> 8);
 	const dim3 grid(g.nstrips * g.nchunks);
 	if (rules_fit_fast(*l.rules))
 		hipLaunchKernelGGL((ca_packed_fused<MAIN, E, C_, W, kFuseZC, true>), grid, dim3(64), 0, stream, l.in, l.out, l.pr, g, l.rules->prog);
@@ -411,7 +399,7 @@ int class_zrun(const CanonRules &r)
 
 bool use_class_kernel(const CanonRules &r, uint32_t G, int variant)
 {
-	return (variant & 0xFF) != 1 && r.fast && ((G / 32u) % 4u) == 0;
+	return variant != 1 && r.fast && ((G / 32u) % 4u) == 0;
 }
 
 
@@ -433,7 +421,7 @@ int packed_fused_steps(const CanonRules &r, uint32_t G, int variant)
 {
 	FusedGeom g;
 	int W;
-	if ((variant & 0xFF) != 0 || !use_class_kernel(r, G, variant & 0xFF)) return 0;
+	if (variant != 0 || !use_class_kernel(r, G, variant)) return 0;
 	if (r.main != MAIN_VN && r.main != MAIN_VN2D) return 0; // instantiated for the face neighbourhoods so far
 	if (r.need[1] || r.need[2]) return 0;
 	return fused_geometry(G, &g, &W) ? 2 : 0;

@@ -64,7 +64,7 @@ int log2_exact(u32 x)
 // The rule reduces to two truth tables over the von Neumann count and the grid is a power of two in [256, 8192].
 bool vn_kernel_applies(const CanonRules &r, uint32_t G, int variant)
 {
-	if ((variant & 0xFF) == 1 || !r.fast || r.main != MAIN_VN) return false;
+	if (variant == 1 || !r.fast || r.main != MAIN_VN) return false;
 	for (int s = 1; s < 3; s++)
 	{
 		const uint32_t reachable = (2u << r.lists.n[s]) - 1u;

@@ -118,13 +118,31 @@ def render_leg(eng, G, a):
     dt = time.perf_counter() - t0
     st = eng.render_stats()
     rays = st.primary_rays + st.shadow_rays
-    return {"metric": "Mray/s path-trace 1080p", "value": round(rays * a.render_frames / dt / 1e6, 2), "unit": "Mray/s",
+    dense = {"metric": "Mray/s path-trace 1080p", "value": round(rays * a.render_frames / dt / 1e6, 2), "unit": "Mray/s",
             "ms_per_frame": round(dt * 1e3 / a.render_frames, 4), "kernel_ms": round(st.gpu_ms, 4),
             "primary_rays": int(st.primary_rays), "shadow_rays": int(st.shadow_rays),
             "cell_visits_per_primary_ray": round(st.primary_cell_visits / max(1, st.primary_rays), 2),
             "cell_visits_per_shadow_ray": round(st.shadow_cell_visits / max(1, st.shadow_rays), 2),
             "config": {"workload": f"{G}^3 packed volume, hashed fill density 2^-5, {W}x{H} @ {a.render_spp} spp, oblique pose "
                                    "(0.6 rad about (1,1,0), distance 1.4), exact DDA walk + shadow ray + Cook-Torrance"}}
+    # the reference UI's own start-up scene (SURVEY 8(d) "sparse"): the single seed evolved 30 steps, default pose
+    eng.upload_state(host.initial_state(G))
+    eng.step(30)
+    us = host.uniform_block(W, H, host.camera_matrix())
+    eng.render(us, W, H, a.render_spp, readback=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.render_frames):
+        eng.render(us, W, H, a.render_spp, readback=False)
+    torch.cuda.synchronize()
+    dts = time.perf_counter() - t0
+    sts = eng.render_stats()
+    dense["sparse_scene"] = {"ms_per_frame": round(dts * 1e3 / a.render_frames, 4),
+                             "value": round((sts.primary_rays + sts.shadow_rays) * a.render_frames / dts / 1e6, 2), "unit": "Mray/s",
+                             "cell_visits_per_primary_ray": round(sts.primary_cell_visits / max(1, sts.primary_rays), 2),
+                             "workload": f"{G}^3, single seed after 30 default-rule steps, default pose, {W}x{H} @ {a.render_spp} spp, "
+                                         "empty-space skipping over 32x8x8-cell occupancy blocks"}
+    return dense
 
 
 def render_leg_multi(se, G, a, world, rank, barrier):

@@ -86,6 +86,9 @@ struct ca3d_engine
 	void *r_light[2] = {nullptr, nullptr};
 	uint32_t *r_depth[2] = {nullptr, nullptr};
 	unsigned long long *r_counters = nullptr;
+	unsigned long long *r_occ = nullptr; // block-occupancy bits of the current state + count, rebuilt per frame (render.hip)
+	size_t r_occ_words = 0;
+	int render_skip = 1; // empty-space skipping on sparse volumes
 	int r_swap = 0;
 	hipEvent_t rev_start = nullptr, rev_stop = nullptr;
 	bool rev_valid = false;
@@ -359,6 +362,7 @@ int ca3d_destroy(ca3d_t *h)
 	free_buffers(h);
 	free_render_targets(h);
 	if (h->r_counters) hipFree(h->r_counters);
+	if (h->r_occ) hipFree(h->r_occ);
 	if (h->rev_start) hipEventDestroy(h->rev_start);
 	if (h->rev_stop) hipEventDestroy(h->rev_stop);
 	if (h->ev_start) hipEventDestroy(h->ev_start);
@@ -779,6 +783,19 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 	l.light = h->r_light[h->r_swap];
 	l.depth = h->r_depth[h->r_swap];
 	l.counters = h->r_counters;
+	if (h->render_skip && h->layout == CA3D_LAYOUT_PACKED32)
+	{
+		const size_t words = ((size_t)(h->G / 32u) * (h->G / 8u) * (h->G / 8u) + 63u) / 64u + 1u;
+		if (words != h->r_occ_words)
+		{
+			if (h->r_occ) HIP_TRY(hipFree(h->r_occ));
+			h->r_occ = nullptr;
+			h->r_occ_words = 0;
+			HIP_TRY(hipMalloc((void **)&h->r_occ, words * sizeof(unsigned long long)));
+			h->r_occ_words = words;
+		}
+		l.occ = h->r_occ;
+	}
 	l.mode = h->render_mode;
 	l.sched = h->render_sched;
 	l.row0 = h->render_row0;
@@ -842,6 +859,7 @@ int ca3d_set_option(ca3d_t *h, const char *name, int64_t value)
 		return CA3D_OK;
 	}
 	if (!strcmp(name, "render_sched")) { h->render_sched = value ? 1 : 0; return CA3D_OK; }
+	if (!strcmp(name, "render_skip")) { h->render_skip = value ? 1 : 0; return CA3D_OK; }
 	if (!strcmp(name, "render_row_begin") || !strcmp(name, "render_row_end"))
 	{
 		if (value < 0 || value > 16384) return fail(CA3D_ERR_INVALID_ARGUMENT, "row %lld is outside any target", (long long)value);

@@ -51,6 +51,8 @@ struct RenderParams
 	u32 *depth;                // RG16F
 	unsigned long long *counters; // [0] shadow rays, [1] primary cell visits, [2] shadow cell visits
 	u32 legacy; // 1: one-u32-per-cell volume + the shading of shaders/pathtraced_fragment.wgsl (R-legacy)
+	const unsigned long long *occ; // block occupancy (ca_occupancy) or null; the word after the bits counts the set bits
+	u32 occ_words;                 // 64-bit words of occupancy bits
 	u32 row0, row1; // only image rows [row0, row1) are rendered (a rank's band of a frame shared between GPUs); row0 is a multiple of 16
 };
 
@@ -134,9 +136,59 @@ __device__ v3 surface_brdf(v3 L, v3 Vd, v3 N, float roughness, v3 albedo, v3 F0)
 	return V(fL.x + (D * Gm * F.x) / denom, fL.y + (D * Gm * F.y) / denom, fL.z + (D * Gm * F.z) / denom);
 }
 
+// ---- empty-space skipping ------------------------------------------------------------------------------------
+// One occupancy bit per block of 32 x 8 x 8 cells (ca_occupancy below). When the walk enters an empty block it
+// jumps to the block's exit face and re-seeds its boundary times in closed form there. Used only on sparse volumes
+// (< 1/4 of the blocks occupied, decided per frame from the bit count): there it visits the same cells as the
+// cell-by-cell walk except where a ray grazes a cell corner within rounding (re-seeded times are not the accumulated
+// ones) — inside the renderer's stated tolerance, not bit-identical to the unskipped walk.
+__device__ __forceinline__ bool occ_skip_enabled(const RenderParams &P)
+{
+	if (!P.occ) return false;
+	const unsigned long long set = P.occ[P.occ_words];
+	return set * 4ull < (unsigned long long)P.cols * (P.G >> 3) * (P.G >> 3);
+}
+
+__device__ __forceinline__ bool block_occupied(const RenderParams &P, int ix, int iy, int iz)
+{
+	const int bk = (ix >> 5) + ((iy >> 3) + (iz >> 3) * ((int)P.G >> 3)) * (int)P.cols;
+	return (P.occ[bk >> 6] >> (bk & 63)) & 1ull;
+}
+
+// The ray is in cell (ix, iy, iz) of an empty block: move to the first cell past the block. false: the ray ends or
+// leaves the volume first.
+__device__ __forceinline__ bool block_jump(const RenderParams &P, v3 start, v3 dir, float tmax, int &ix, int &iy, int &iz, float &t,
+                                           float &tx, float &ty, float &tz)
+{
+	const int G = (int)P.G;
+	const float cs = 1.0f / (float)P.G, big = 3.0e38f;
+	const int sx = dir.x > 0.0f ? 1 : -1, sy = dir.y > 0.0f ? 1 : -1, sz = dir.z > 0.0f ? 1 : -1;
+	const int bx0 = ix & ~31, by0 = iy & ~7, bz0 = iz & ~7;
+	const float tex = dir.x != 0.0f ? (((float)(sx > 0 ? bx0 + 32 : bx0) * cs - kHalf) - start.x) / dir.x : big;
+	const float tey = dir.y != 0.0f ? (((float)(sy > 0 ? by0 + 8 : by0) * cs - kHalf) - start.y) / dir.y : big;
+	const float tez = dir.z != 0.0f ? (((float)(sz > 0 ? bz0 + 8 : bz0) * cs - kHalf) - start.z) / dir.z : big;
+	const bool mx = tex <= tey && tex <= tez, my = !mx && tey <= tez;
+	const float te = mx ? tex : (my ? tey : tez);
+	if (te >= tmax) return false;
+	const v3 p = start + dir * te;
+	int nx = min(max((int)floorf((p.x + kHalf) / cs), bx0), bx0 + 31);
+	int ny = min(max((int)floorf((p.y + kHalf) / cs), by0), by0 + 7);
+	int nz = min(max((int)floorf((p.z + kHalf) / cs), bz0), bz0 + 7);
+	if (mx) nx = sx > 0 ? bx0 + 32 : bx0 - 1;
+	else if (my) ny = sy > 0 ? by0 + 8 : by0 - 1;
+	else nz = sz > 0 ? bz0 + 8 : bz0 - 1;
+	if ((u32)nx >= (u32)G || (u32)ny >= (u32)G || (u32)nz >= (u32)G) return false;
+	ix = nx; iy = ny; iz = nz;
+	t = te;
+	tx = dir.x != 0.0f ? (((float)(ix + (sx > 0 ? 1 : 0)) * cs - kHalf) - start.x) / dir.x : big;
+	ty = dir.y != 0.0f ? (((float)(iy + (sy > 0 ? 1 : 0)) * cs - kHalf) - start.y) / dir.y : big;
+	tz = dir.z != 0.0f ? (((float)(iz + (sz > 0 ? 1 : 0)) * cs - kHalf) - start.z) / dir.z : big;
+	return true;
+}
+
 // Exact cell walk (Amanatides-Woo) from `start` along unit `dir` over (t0, tmax). SHADOW selects the visit test.
 // Returns true on a hit; `tnear_out` is the slab entry of the hit cube (primary only).
-template <bool SHADOW>
+template <bool SHADOW, bool SKIP>
 __device__ bool walk(const RenderParams &P, v3 start, v3 dir, float t0, float tmax, v3 half, int sx0, int sy0, int sz0,
                      float &tnear_out, u32 &visits)
 {
@@ -162,6 +214,11 @@ __device__ bool walk(const RenderParams &P, v3 start, v3 dir, float t0, float tm
 	{
 		if (t >= tmax) return false;
 		visits++;
+		if (SKIP && !block_occupied(P, ix, iy, iz))
+		{
+			if (!block_jump(P, start, dir, tmax, ix, iy, iz, t, tx, ty, tz)) return false;
+			continue;
+		}
 		bool alive;
 		if (P.legacy) alive = P.cells[(size_t)ix + ((size_t)iy + (size_t)iz * G) * G] == 1u; // `== 1` (pathtraced_fragment.wgsl:530)
 		else
@@ -204,6 +261,7 @@ struct Sample
 	u32 shadow_ray;
 };
 
+template <bool SKIP>
 __device__ Sample shade_sample(const RenderParams &P, float vu, float vv, u32 &pvis, u32 &svis)
 {
 	const float *u = P.u;
@@ -231,7 +289,7 @@ __device__ Sample shade_sample(const RenderParams &P, float vu, float vv, u32 &p
 		const float vis = cs * u[U_CELLSIZE] * 0.5f;
 		const v3 vhalf = V(vis, vis, vis);
 		float tnear = 0.0f;
-		const bool hit = walk<false>(P, enter, dir, 0.0f, depth_len, vhalf, 0, 0, 0, tnear, pvis);
+		const bool hit = walk<false, SKIP>(P, enter, dir, 0.0f, depth_len, vhalf, 0, 0, 0, tnear, pvis);
 		const v3 final_point = hit ? enter + dir * tnear : exitp;
 		s.depth = len3(final_point - cam);  // :762, 774
 		const v3 p = cam + ray * s.depth;   // moreAccurateSamplePoint :840
@@ -252,7 +310,7 @@ __device__ Sample shade_sample(const RenderParams &P, float vu, float vv, u32 &p
 			const v3 sdir = norm3(sseg);
 			const float slen = len3(sseg);
 			float dummy = 0.0f;
-			const bool occluded = walk<true>(P, p, sdir, 0.0025f, slen, vhalf, cx, cy, cz, dummy, svis);
+			const bool occluded = walk<true, SKIP>(P, p, sdir, 0.0025f, slen, vhalf, cx, cy, cz, dummy, svis);
 			const float occ = occluded ? (P.legacy ? 0.095f : kOcclusion) : 1.0f; // pathtraced_fragment.wgsl:67 / clustered :72
 			if (P.legacy)
 			{
@@ -314,8 +372,13 @@ __device__ Sample shade_sample(const RenderParams &P, float vu, float vv, u32 &p
 
 __device__ __forceinline__ u32 unorm8(float x) { return (u32)__float2int_rn(fminf(fmaxf(x, 0.0f), 1.0f) * 255.0f); }
 
+// SKIP: the variant with empty-space skipping. Both variants are launched for every frame and the one that does not
+// match the frame's occupancy (occ_skip_enabled) returns at once: the choice is made on the device, without a host
+// round trip, and the variant that runs carries none of the other's code in its loops.
+template <bool SKIP>
 __global__ __launch_bounds__(256) void ca_render_packed(RenderParams P)
 {
+	if ((!P.legacy && occ_skip_enabled(P)) != SKIP) return;
 	const u32 px = blockIdx.x * 16u + (threadIdx.x & 15u);
 	const u32 py = P.row0 + blockIdx.y * 16u + (threadIdx.x >> 4);
 	if (px >= P.W || py >= P.row1) return;
@@ -326,7 +389,7 @@ __global__ __launch_bounds__(256) void ca_render_packed(RenderParams P)
 		const float ox = P.spp == 1u ? 0.5f : ((k & 1u) ? 0.75f : 0.25f);
 		const float oy = P.spp == 1u ? 0.5f : ((k & 2u) ? 0.75f : 0.25f);
 		const float vu = ((float)px + ox) / (float)P.W, vv = 1.0f - ((float)py + oy) / (float)P.H;
-		const Sample s = shade_sample(P, vu, vv, pvis, svis);
+		const Sample s = shade_sample<SKIP>(P, vu, vv, pvis, svis);
 		r += s.r; g += s.g; b += s.b; a += s.a;
 		if (k == 0) d0 = s.depth;
 		shadow += s.shadow_ray;
@@ -417,6 +480,7 @@ __device__ __forceinline__ void walk_begin(const RenderParams &P, RayState &w, v
 }
 
 // One cell of `walk` above. 0: keep walking, 1: hit (tnear_out), 2: the ray left the volume / ran out of range.
+template <bool SKIP>
 __device__ __forceinline__ int walk_step(const RenderParams &P, RayState &w, v3 half, bool shadow, float &tnear_out, u32 &visits)
 {
 	const int G = (int)P.G;
@@ -425,6 +489,8 @@ __device__ __forceinline__ int walk_step(const RenderParams &P, RayState &w, v3 
 	w.guard++;
 	if (w.t >= w.tmax) return 2;
 	visits++;
+	if (SKIP && !block_occupied(P, w.ix, w.iy, w.iz))
+		return block_jump(P, w.start, w.dir, w.tmax, w.ix, w.iy, w.iz, w.t, w.tx, w.ty, w.tz) ? 0 : 2;
 	bool alive;
 	if (P.legacy) alive = P.cells[(size_t)w.ix + ((size_t)w.iy + (size_t)w.iz * G) * G] == 1u;
 	else
@@ -611,8 +677,10 @@ constexpr int kSchedChunk = 4; // samples per pixel scheduled together (LDS: 4 x
 #endif
 constexpr int kSchedLeaveDiv = CA3D_SCHED_LEAVE_DIV; // the walk loop is left when fewer than 1/N of its walkers are still walking
 
+template <bool SKIP>
 __global__ __launch_bounds__(256) void ca_render_packed_sched(RenderParams P)
 {
+	if ((!P.legacy && occ_skip_enabled(P)) != SKIP) return;
 	__shared__ float res[kSchedChunk][6][256];
 	const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const u32 px = blockIdx.x * 16u + (threadIdx.x & 15u);
@@ -673,7 +741,7 @@ __global__ __launch_bounds__(256) void ca_render_packed_sched(RenderParams P)
 			float tnear = 0.0f;
 			for (;;)
 			{
-				if (st.job >= 0 && term == 0) term = walk_step(P, st, vhalf, st.phase == 2, tnear, st.phase == 2 ? svis : pvis);
+				if (st.job >= 0 && term == 0) term = walk_step<SKIP>(P, st, vhalf, st.phase == 2, tnear, st.phase == 2 ? svis : pvis);
 				const int walking = __popcll(__ballot(st.job >= 0 && term == 0));
 				if (walking == 0 || walking < leave_below) break;
 			}
@@ -723,6 +791,30 @@ __global__ __launch_bounds__(256) void ca_render_packed_sched(RenderParams P)
 		atomicAdd(&P.counters[0], (unsigned long long)shadow);
 		atomicAdd(&P.counters[1], (unsigned long long)pvis);
 		atomicAdd(&P.counters[2], (unsigned long long)svis);
+	}
+}
+
+// ================================================================================================ occupancy
+// occ: one bit per block of 32 x 8 x 8 cells (index wx + cols * (by + G/8 * bz)), set when any cell of the block is
+// alive; the 64-bit word after the bits accumulates their count. Rebuilt from the current state before every frame
+// (one read of the volume: ~5 us at 512^3).
+__global__ __launch_bounds__(256) void ca_occupancy(const u32 *__restrict__ cells, unsigned long long *__restrict__ occ, u32 G, u32 cols,
+                                                     u32 nblocks, u32 occ_words)
+{
+	const u32 bk = blockIdx.x * 256u + threadIdx.x; // consecutive lanes = consecutive wx
+	u32 any = 0;
+	if (bk < nblocks)
+	{
+		const u32 nb = G >> 3;
+		const u32 wx = bk % cols, byz = bk / cols, by = byz % nb, bz = byz / nb;
+		for (u32 dz = 0; dz < 8; dz++)
+			for (u32 dy = 0; dy < 8; dy++) any |= cells[wx + ((size_t)(by * 8 + dy) + (size_t)(bz * 8 + dz) * G) * cols];
+	}
+	const unsigned long long m = __ballot(any != 0);
+	if ((threadIdx.x & 63u) == 0 && (bk >> 6) < occ_words)
+	{
+		occ[bk >> 6] = m;
+		if (m) atomicAdd(&occ[occ_words], (unsigned long long)__popcll(m));
 	}
 }
 
@@ -1005,6 +1097,17 @@ hipError_t launch_render(const RenderLaunch &l, hipStream_t stream)
 	P.depth = l.depth;
 	P.counters = l.counters;
 	P.legacy = l.legacy ? 1u : 0u;
+	P.occ = nullptr;
+	P.occ_words = 0;
+	if (!l.legacy && l.mode != 1 && l.occ)
+	{
+		const u32 nblocks = P.cols * (l.G >> 3) * (l.G >> 3);
+		P.occ_words = (nblocks + 63u) / 64u;
+		hipError_t e = hipMemsetAsync(l.occ + P.occ_words, 0, sizeof(unsigned long long), stream);
+		if (e != hipSuccess) return e;
+		hipLaunchKernelGGL(ca_occupancy, dim3((nblocks + 255u) / 256u), dim3(256), 0, stream, l.cells, l.occ, l.G, P.cols, nblocks, P.occ_words);
+		P.occ = l.occ;
+	}
 	P.row0 = l.row0;
 	P.row1 = l.row1 ? l.row1 : l.H;
 	const dim3 grid((l.W + 15u) / 16u, (l.mode == 1 ? l.H + 15u : P.row1 - P.row0 + 15u) / 16u);
@@ -1017,9 +1120,15 @@ hipError_t launch_render(const RenderLaunch &l, hipStream_t stream)
 		hipLaunchKernelGGL(ca_render_frame_packed, grid, dim3(256), 0, stream, F);
 	}
 	else if (l.sched)
-		hipLaunchKernelGGL(ca_render_packed_sched, grid, dim3(256), 0, stream, P);
+	{
+		hipLaunchKernelGGL(ca_render_packed_sched<false>, grid, dim3(256), 0, stream, P);
+		if (P.occ) hipLaunchKernelGGL(ca_render_packed_sched<true>, grid, dim3(256), 0, stream, P);
+	}
 	else
-		hipLaunchKernelGGL(ca_render_packed, grid, dim3(256), 0, stream, P);
+	{
+		hipLaunchKernelGGL(ca_render_packed<false>, grid, dim3(256), 0, stream, P);
+		if (P.occ) hipLaunchKernelGGL(ca_render_packed<true>, grid, dim3(256), 0, stream, P);
+	}
 	return hipGetLastError();
 }
 

@@ -202,7 +202,9 @@ int ca3d_get_render_stats(ca3d_t *h, ca3d_render_stats *out);
  * kernel for the current rule, compiled inside ca3d_set_rules / ca3d_configure (on by default; a failed compile
  * silently keeps the pre-built kernels); "render_mode" 0/1; "render_row_begin" / "render_row_end":
  * ca3d_render then fills image rows [begin, end) only (begin a multiple of 16; 0 / 0 = the whole frame) — a rank's
- * band when the GPUs of a node share one frame; "render_sched" 0/1 dynamic ray
+ * band when the GPUs of a node share one frame; "render_skip" 0/1 empty-space skipping by
+ * 32x8x8-cell occupancy blocks, active on sparse volumes only (on by default; within the renderer's tolerance of
+ * the cell-by-cell walk, not bit-identical to it); "render_sched" 0/1 dynamic ray
  * scheduling inside each wave of the renderer (on by default; the frame is the same bit for bit);
  * "render_reset_history". */
 int ca3d_set_option(ca3d_t *h, const char *name, int64_t value);

@@ -76,6 +76,26 @@ def test_evolved_seed_volume(eng):
     _compare(eng, cells, G, host.uniform_block(W, H, host.orbit_camera(1.2, (1.0, 0.3, 0.0), 0.8)), W, H, 1)
 
 
+@pytest.mark.parametrize("G,W,H,spp", [(128, 320, 180, 4), (256, 480, 270, 1)])
+def test_empty_space_skipping_on_a_sparse_volume(eng, G, W, H, spp):
+    """The evolved single seed fills a few percent of the 32 x 8 x 8 blocks: walks jump over the empty ones. Against
+    the oracle's cell-by-cell walk (tolerance of this file), against the unskipped GPU walk (same tolerance: re-seeded
+    boundary times may tie-break differently at cell corners), and far fewer cell visits."""
+    cells = ol.packed_run(G, host.initial_state(G), rules("default"), 30)
+    for pose in (host.camera_matrix(), host.orbit_camera(1.2, (1.0, 0.3, 0.0), 0.8)):
+        u = host.uniform_block(W, H, pose)
+        _compare(eng, cells, G, u, W, H, spp)               # skipping is on by default: GPU vs oracle
+        skipped = eng.render(u, W, H, spp)
+        v_skip = eng.render_stats().primary_cell_visits
+        eng.set_option("render_skip", 0)
+        plain = eng.render(u, W, H, spp)
+        v_plain = eng.render_stats().primary_cell_visits
+        eng.set_option("render_skip", 1)
+        same = (np.abs(skipped[1].astype(np.float32) - plain[1].astype(np.float32)).max(-1) <= 2e-3)
+        assert same.mean() >= 0.999, same.mean()
+        assert v_skip * 3 < v_plain, (v_skip, v_plain)
+
+
 def test_camera_inside_volume(eng):
     G, W, H = 64, 160, 90
     cells = host.random_fill(host.words_per_buffer(G), seed=5, and_rounds=5)

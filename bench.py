@@ -141,7 +141,7 @@ def render_leg(eng, G, a):
                              "value": round((sts.primary_rays + sts.shadow_rays) * a.render_frames / dts / 1e6, 2), "unit": "Mray/s",
                              "cell_visits_per_primary_ray": round(sts.primary_cell_visits / max(1, sts.primary_rays), 2),
                              "workload": f"{G}^3, single seed after 30 default-rule steps, default pose, {W}x{H} @ {a.render_spp} spp, "
-                                         "empty-space skipping over 32x8x8-cell occupancy blocks"}
+                                         "empty-space skipping over two levels of occupancy blocks"}
     return dense
 
 

@@ -785,7 +785,8 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 	l.counters = h->r_counters;
 	if (h->render_skip && h->layout == CA3D_LAYOUT_PACKED32)
 	{
-		const size_t words = ((size_t)(h->G / 32u) * (h->G / 8u) * (h->G / 8u) + 63u) / 64u + 1u;
+		const size_t fine = (size_t)(h->G / 32u) * (h->G / 8u) * (h->G / 8u); // fine bits, count word, coarse bits (render.hip)
+		const size_t words = (fine + 63u) / 64u + 1u + (fine / 64u + 63u) / 64u;
 		if (words != h->r_occ_words)
 		{
 			if (h->r_occ) HIP_TRY(hipFree(h->r_occ));

@@ -100,7 +100,7 @@ struct RenderLaunch
 	const uint32_t *prev_depth;   // previous frame's RG16F (mode 1)
 	int sched = 1;                // mode 0: dynamic ray scheduling inside each wave (same frame, bit for bit)
 	unsigned long long *occ = nullptr; // mode 0, packed: scratch for the block-occupancy bits + their count,
-	                                   // (G/32)(G/8)(G/8)/64 + 1 words (null: no empty-space skipping)
+	                                   // sized by ca3d_render (null: no empty-space skipping)
 	uint32_t row0 = 0, row1 = 0;  // mode 0: render image rows [row0, row1) only (row1 == 0: all); row0 % 16 == 0
 };
 

@@ -52,7 +52,8 @@ struct RenderParams
 	unsigned long long *counters; // [0] shadow rays, [1] primary cell visits, [2] shadow cell visits
 	u32 legacy; // 1: one-u32-per-cell volume + the shading of shaders/pathtraced_fragment.wgsl (R-legacy)
 	const unsigned long long *occ; // block occupancy (ca_occupancy) or null; the word after the bits counts the set bits
-	u32 occ_words;                 // 64-bit words of occupancy bits
+	u32 occ_words;                 // 64-bit words of (fine) occupancy bits
+	u32 occ_coarse;                // != 0: coarse bits (blocks of 128 x 32 x 32 cells) follow the count word
 	u32 row0, row1; // only image rows [row0, row1) are rendered (a rank's band of a frame shared between GPUs); row0 is a multiple of 16
 };
 
@@ -155,28 +156,37 @@ __device__ __forceinline__ bool block_occupied(const RenderParams &P, int ix, in
 	return (P.occ[bk >> 6] >> (bk & 63)) & 1ull;
 }
 
+// second level: blocks of 128 x 32 x 32 cells (4 x 4 x 4 fine blocks), grids that are multiples of 128 only
+__device__ __forceinline__ bool coarse_occupied(const RenderParams &P, int ix, int iy, int iz)
+{
+	const int ck = (ix >> 7) + ((iy >> 5) + (iz >> 5) * ((int)P.G >> 5)) * ((int)P.cols >> 2);
+	return (P.occ[P.occ_words + 1u + (u32)(ck >> 6)] >> (ck & 63)) & 1ull;
+}
+
 // The ray is in cell (ix, iy, iz) of an empty block: move to the first cell past the block. false: the ray ends or
 // leaves the volume first.
+template <int LX, int LY, int LZ> // log2 of the block's extent in cells
 __device__ __forceinline__ bool block_jump(const RenderParams &P, v3 start, v3 dir, float tmax, int &ix, int &iy, int &iz, float &t,
                                            float &tx, float &ty, float &tz)
 {
+	constexpr int BX = 1 << LX, BY = 1 << LY, BZ = 1 << LZ;
 	const int G = (int)P.G;
 	const float cs = 1.0f / (float)P.G, big = 3.0e38f;
 	const int sx = dir.x > 0.0f ? 1 : -1, sy = dir.y > 0.0f ? 1 : -1, sz = dir.z > 0.0f ? 1 : -1;
-	const int bx0 = ix & ~31, by0 = iy & ~7, bz0 = iz & ~7;
-	const float tex = dir.x != 0.0f ? (((float)(sx > 0 ? bx0 + 32 : bx0) * cs - kHalf) - start.x) / dir.x : big;
-	const float tey = dir.y != 0.0f ? (((float)(sy > 0 ? by0 + 8 : by0) * cs - kHalf) - start.y) / dir.y : big;
-	const float tez = dir.z != 0.0f ? (((float)(sz > 0 ? bz0 + 8 : bz0) * cs - kHalf) - start.z) / dir.z : big;
+	const int bx0 = ix & ~(BX - 1), by0 = iy & ~(BY - 1), bz0 = iz & ~(BZ - 1);
+	const float tex = dir.x != 0.0f ? (((float)(sx > 0 ? bx0 + BX : bx0) * cs - kHalf) - start.x) / dir.x : big;
+	const float tey = dir.y != 0.0f ? (((float)(sy > 0 ? by0 + BY : by0) * cs - kHalf) - start.y) / dir.y : big;
+	const float tez = dir.z != 0.0f ? (((float)(sz > 0 ? bz0 + BZ : bz0) * cs - kHalf) - start.z) / dir.z : big;
 	const bool mx = tex <= tey && tex <= tez, my = !mx && tey <= tez;
 	const float te = mx ? tex : (my ? tey : tez);
 	if (te >= tmax) return false;
 	const v3 p = start + dir * te;
-	int nx = min(max((int)floorf((p.x + kHalf) / cs), bx0), bx0 + 31);
-	int ny = min(max((int)floorf((p.y + kHalf) / cs), by0), by0 + 7);
-	int nz = min(max((int)floorf((p.z + kHalf) / cs), bz0), bz0 + 7);
-	if (mx) nx = sx > 0 ? bx0 + 32 : bx0 - 1;
-	else if (my) ny = sy > 0 ? by0 + 8 : by0 - 1;
-	else nz = sz > 0 ? bz0 + 8 : bz0 - 1;
+	int nx = min(max((int)floorf((p.x + kHalf) / cs), bx0), bx0 + BX - 1);
+	int ny = min(max((int)floorf((p.y + kHalf) / cs), by0), by0 + BY - 1);
+	int nz = min(max((int)floorf((p.z + kHalf) / cs), bz0), bz0 + BZ - 1);
+	if (mx) nx = sx > 0 ? bx0 + BX : bx0 - 1;
+	else if (my) ny = sy > 0 ? by0 + BY : by0 - 1;
+	else nz = sz > 0 ? bz0 + BZ : bz0 - 1;
 	if ((u32)nx >= (u32)G || (u32)ny >= (u32)G || (u32)nz >= (u32)G) return false;
 	ix = nx; iy = ny; iz = nz;
 	t = te;
@@ -214,10 +224,18 @@ __device__ bool walk(const RenderParams &P, v3 start, v3 dir, float t0, float tm
 	{
 		if (t >= tmax) return false;
 		visits++;
-		if (SKIP && !block_occupied(P, ix, iy, iz))
+		if (SKIP)
 		{
-			if (!block_jump(P, start, dir, tmax, ix, iy, iz, t, tx, ty, tz)) return false;
-			continue;
+			if (P.occ_coarse && !coarse_occupied(P, ix, iy, iz))
+			{
+				if (!block_jump<7, 5, 5>(P, start, dir, tmax, ix, iy, iz, t, tx, ty, tz)) return false;
+				continue;
+			}
+			if (!block_occupied(P, ix, iy, iz))
+			{
+				if (!block_jump<5, 3, 3>(P, start, dir, tmax, ix, iy, iz, t, tx, ty, tz)) return false;
+				continue;
+			}
 		}
 		bool alive;
 		if (P.legacy) alive = P.cells[(size_t)ix + ((size_t)iy + (size_t)iz * G) * G] == 1u; // `== 1` (pathtraced_fragment.wgsl:530)
@@ -489,8 +507,13 @@ __device__ __forceinline__ int walk_step(const RenderParams &P, RayState &w, v3 
 	w.guard++;
 	if (w.t >= w.tmax) return 2;
 	visits++;
-	if (SKIP && !block_occupied(P, w.ix, w.iy, w.iz))
-		return block_jump(P, w.start, w.dir, w.tmax, w.ix, w.iy, w.iz, w.t, w.tx, w.ty, w.tz) ? 0 : 2;
+	if (SKIP)
+	{
+		if (P.occ_coarse && !coarse_occupied(P, w.ix, w.iy, w.iz))
+			return block_jump<7, 5, 5>(P, w.start, w.dir, w.tmax, w.ix, w.iy, w.iz, w.t, w.tx, w.ty, w.tz) ? 0 : 2;
+		if (!block_occupied(P, w.ix, w.iy, w.iz))
+			return block_jump<5, 3, 3>(P, w.start, w.dir, w.tmax, w.ix, w.iy, w.iz, w.t, w.tx, w.ty, w.tz) ? 0 : 2;
+	}
 	bool alive;
 	if (P.legacy) alive = P.cells[(size_t)w.ix + ((size_t)w.iy + (size_t)w.iz * G) * G] == 1u;
 	else
@@ -818,6 +841,26 @@ __global__ __launch_bounds__(256) void ca_occupancy(const u32 *__restrict__ cell
 	}
 }
 
+// Second level from the first: one bit per 4 x 4 x 4 fine blocks (128 x 32 x 32 cells), stored after the count word.
+__global__ __launch_bounds__(256) void ca_occupancy_coarse(unsigned long long *__restrict__ occ, u32 G, u32 cols, u32 ncoarse, u32 occ_words)
+{
+	const u32 ck = blockIdx.x * 256u + threadIdx.x; // cwx + (cols / 4) * (cby + (G / 32) * cbz)
+	u32 any = 0;
+	if (ck < ncoarse)
+	{
+		const u32 ccols = cols >> 2, nb = G >> 3, cnb = G >> 5;
+		const u32 cwx = ck % ccols, cbyz = ck / ccols, cby = cbyz % cnb, cbz = cbyz / cnb;
+		for (u32 dz = 0; dz < 4; dz++)
+			for (u32 dy = 0; dy < 4; dy++)
+			{
+				const u32 bk = cwx * 4u + cols * ((cby * 4u + dy) + nb * (cbz * 4u + dz)); // 4 consecutive bits: cols % 4 == 0
+				any |= (u32)((occ[bk >> 6] >> (bk & 63u)) & 0xFull);
+			}
+	}
+	const unsigned long long m = __ballot(any != 0);
+	if ((threadIdx.x & 63u) == 0 && ck < ((ncoarse + 63u) & ~63u)) occ[occ_words + 1u + (ck >> 6)] = m;
+}
+
 // ================================================================================================ literal frame
 // One frame exactly as fragment_main (800-890) produces it — jittered fixed-step marches, history look-ups,
 // depth repair, temporal blend — for hosts that want the reference's own accumulation behaviour
@@ -1099,13 +1142,17 @@ hipError_t launch_render(const RenderLaunch &l, hipStream_t stream)
 	P.legacy = l.legacy ? 1u : 0u;
 	P.occ = nullptr;
 	P.occ_words = 0;
+	P.occ_coarse = 0;
 	if (!l.legacy && l.mode != 1 && l.occ)
 	{
 		const u32 nblocks = P.cols * (l.G >> 3) * (l.G >> 3);
 		P.occ_words = (nblocks + 63u) / 64u;
+		P.occ_coarse = l.G % 128u == 0 ? 1u : 0u;
 		hipError_t e = hipMemsetAsync(l.occ + P.occ_words, 0, sizeof(unsigned long long), stream);
 		if (e != hipSuccess) return e;
 		hipLaunchKernelGGL(ca_occupancy, dim3((nblocks + 255u) / 256u), dim3(256), 0, stream, l.cells, l.occ, l.G, P.cols, nblocks, P.occ_words);
+		if (P.occ_coarse)
+			hipLaunchKernelGGL(ca_occupancy_coarse, dim3((nblocks / 64u + 255u) / 256u), dim3(256), 0, stream, l.occ, l.G, P.cols, nblocks / 64u, P.occ_words);
 		P.occ = l.occ;
 	}
 	P.row0 = l.row0;

@@ -26,6 +26,10 @@ rocprofv3 --output-format csv --pmc FETCH_SIZE --kernel-trace -d "$out/${tag}_pm
 rocprofv3 --output-format csv --pmc WRITE_SIZE --kernel-trace -d "$out/${tag}_pmc_write512" -o p -- python $B512 > /dev/null
 rocprofv3 --output-format csv --pmc FETCH_SIZE --kernel-trace -d "$out/${tag}_pmc_fetch1024" -o p -- python $B1024 > /dev/null
 rocprofv3 --output-format csv --pmc WRITE_SIZE --kernel-trace -d "$out/${tag}_pmc_write1024" -o p -- python $B1024 > /dev/null
+python -c "from cellularautomatons3d_amd import host; host.uniform_block(1920, 1080, host.orbit_camera()).tofile('/tmp/ca3d_u.f32')"
+node cellularautomatons3d_amd/js/bench.js --uniforms /tmp/ca3d_u.f32 > "$out/${tag}_bench_node.json"
+python tools/run_slab_rccl.py --ghost 32 --batches 40 2>/dev/null | grep "^slab" > "$out/${tag}_slab_rccl_loopback.txt"
+python tools/run_slab_rccl.py --grid 2048 --planes 256 --ghost 16 --batches 15 2>/dev/null | grep "^slab" >> "$out/${tag}_slab_rccl_loopback.txt"
 python tools/pmc_reduce.py "ca_packed_vn@512" ca_packed_vn "$out/${tag}_pmc_fetch512" "$out/${tag}_pmc_write512" "$out/${tag}_pmc_traffic.json"
 python tools/pmc_reduce.py "ca_packed_vn@1024" ca_packed_vn "$out/${tag}_pmc_fetch1024" "$out/${tag}_pmc_write1024" "$out/${tag}_pmc_traffic.json"
 # keep only summaries: the raw per-dispatch traces are large

@@ -42,7 +42,10 @@ def parse():
     ap.add_argument("--ghost", type=int, default=32, help="ghost planes per side = steps between halo exchanges (N>1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--no-render", action="store_true", help="skip the renderer leg")
+    ap.add_argument("--no-render", action="store_true", help="skip the renderer leg (N=1)")
+    ap.add_argument("--multi-render", action="store_true",
+                    help="N>1: also time the frame shared between the ranks (volume all-gather + bands of image rows); "
+                         "off by default so that the scaling run times the CA step alone")
     ap.add_argument("--render-size", default="1920x1080")
     ap.add_argument("--render-spp", type=int, default=4)
     ap.add_argument("--render-frames", type=int, default=10)
@@ -312,7 +315,7 @@ def main():
             ok = bool(flag.item())
 
     multi_render = None
-    if world > 1 and not a.no_render:
+    if world > 1 and a.multi_render:
         multi_render = render_leg_multi(se, G, a, world, rank, barrier)
 
     if rank == 0:

@@ -295,7 +295,7 @@ def test_bench_two_ranks_on_one_gpu_gloo_rehearsal(overlap):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "21", "--warmup", "5",
            "--grid", "256", "--ghost", "4", "--backend", "gloo", "--device-map", "0,0", "--check", "--no-cpu-baseline", "--overlap", overlap,
-           "--render-size", "640x360", "--render-frames", "2"]
+           "--multi-render", "--render-size", "640x360", "--render-frames", "2"]
     r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]

@@ -28,6 +28,8 @@ RULES = {
     "default": dict(neighbourhood="von neumann", born="1,3", survive="0-6"),
     "clustered": dict(neighbourhood="moore", born="5-7", survive="4-7", born_edges="4", survive_edges="3-5",
                       born_corners="3", survive_corners="2-4"),
+    "vn_b24_s135": dict(neighbourhood="von neumann", born="2,4", survive="1,3,5"),  # a von Neumann rule without a pre-built kernel
+    "life2d": dict(neighbourhood="moore 2D", born="3", survive="2,3"),
 }
 
 

@@ -21,6 +21,7 @@ rocprofv3 --output-format csv --kernel-trace --stats -d "$out/${tag}_stats_slab"
 rocprofv3 --output-format csv --kernel-trace --stats -d "$out/${tag}_stats_slab_phased" -o s -- python tools/run_slab.py --ghost 16 --batches 50 --phased 1 > "$out/${tag}_slab_phased.log"
 for g in 256 1024; do python bench.py --no-cpu-baseline --no-render --grid $g --steps 1024 --warmup 128 >> "$out/${tag}_bench_matrix.jsonl"; done
 for g in 256 512 1024; do python bench.py --no-cpu-baseline --no-render --grid $g --rule clustered --steps 256 --warmup 64 >> "$out/${tag}_bench_matrix.jsonl"; done
+for r in vn_b24_s135 life2d; do python bench.py --no-cpu-baseline --no-render --grid 512 --rule $r --steps 1024 --warmup 128 >> "$out/${tag}_bench_matrix.jsonl"; done
 
 rocprofv3 --output-format csv --pmc FETCH_SIZE --kernel-trace -d "$out/${tag}_pmc_fetch512" -o p -- python $B512 > /dev/null
 rocprofv3 --output-format csv --pmc WRITE_SIZE --kernel-trace -d "$out/${tag}_pmc_write512" -o p -- python $B512 > /dev/null

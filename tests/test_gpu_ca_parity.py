@@ -245,6 +245,20 @@ def test_1024_cubed_one_step(eng):
     np.testing.assert_array_equal(eng.read_state(), ol.packed_step(G, st, r))
 
 
+def test_2048_cubed_two_steps(eng):
+    """BASELINE config 5's grid (1 GiB per buffer, offsets past 2^32 bits): two steps of the default rule, whole state
+    compared with the oracle."""
+    G = 2048
+    r = rules("default")
+    eng.configure(G)
+    set_rules(eng, r)
+    st = host.random_fill(host.words_per_buffer(G), seed=7)
+    eng.upload_state(st)
+    eng.step(2)
+    np.testing.assert_array_equal(eng.read_state(), ol.packed_run(G, st, r, 2))
+    eng.configure(32)  # release the 2 GiB before the next test
+
+
 def test_large_graph_replay_1024_steps(eng):
     """ca3d_step replays captured graphs of 1024 and of 64 steps, then single launches: one call that uses all three
     (and one from buffer 1, which first re-aligns with a single step) against the oracle."""

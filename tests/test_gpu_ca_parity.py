@@ -64,6 +64,39 @@ def test_vn_truth_table_kernel_random_tables(eng, G):
         eng.set_option("jit", 1)
 
 
+def test_random_rules_through_the_rule_compilers(eng):
+    """Random rule strings over all six main neighbourhoods with random edges / corners rule-sets (including counts no
+    neighbourhood can reach, the "27" convention and empty lists): the run-time compiled truth-table kernels, the
+    pre-built cube-program kernels and the generic kernel all against the oracle."""
+    rng = np.random.default_rng(20260614)
+    G = 128
+    st = host.random_fill(host.words_per_buffer(G), seed=404)
+    eng.configure(G)
+    hoods = ["von neumann", "von neumann 2D", "moore", "moore 2D", "edges", "corners"]
+
+    def rule_string(max_count, p_empty=0.15):
+        if rng.random() < p_empty:
+            return "27" if rng.random() < 0.5 else ""
+        ks = sorted(set(int(k) for k in rng.integers(0, max_count + 3, size=int(rng.integers(1, 6)))))
+        return ",".join(str(k) for k in ks)
+
+    for case in range(14):
+        kw = dict(neighbourhood=hoods[case % 6], born=rule_string(26, 0.0), survive=rule_string(26, 0.05),
+                  born_edges=rule_string(12, 0.4), survive_edges=rule_string(12, 0.4),
+                  born_corners=rule_string(8, 0.4), survive_corners=rule_string(8, 0.4))
+        r = ol.Rules.from_strings(**kw)
+        want = ol.packed_run(G, st, r, 2)
+        for jit, variant in ((1, 0), (0, 0), (0, 1)):
+            eng.set_option("jit", jit)
+            eng.set_option("variant", variant)
+            set_rules(eng, r)
+            eng.upload_state(st)
+            eng.step(2)
+            np.testing.assert_array_equal(eng.read_state(), want, err_msg=f"{kw} jit={jit} variant={variant} {eng.info().kernel_name}")
+    eng.set_option("jit", 1)
+    eng.set_option("variant", 0)
+
+
 @pytest.mark.parametrize("G", [128, 256])
 @pytest.mark.parametrize("name", list(RULESETS))
 def test_generic_kernel_equals_class_kernel(eng, G, name):

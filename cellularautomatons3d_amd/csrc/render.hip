@@ -700,28 +700,34 @@ constexpr int kSchedChunk = 4; // samples per pixel scheduled together (LDS: 4 x
 #endif
 constexpr int kSchedLeaveDiv = CA3D_SCHED_LEAVE_DIV; // the walk loop is left when fewer than 1/N of its walkers are still walking
 
-template <bool SKIP>
+// PPW pixels per wave (64: 16 x 4, 128: 32 x 4, 256: 32 x 8; a block is 4 waves stacked in y), NK samples per pixel
+// scheduled together: a wave has PPW x NK jobs in flight per chunk, and 4 x PPW x NK x 6 floats of LDS per block hold
+// the results. More jobs per wave = more refills before the tail: one sample per pixel (the interactive case) takes
+// 256 pixels per wave, four samples 64.
+template <bool SKIP, int PPW, int NK>
 __global__ __launch_bounds__(256) void ca_render_packed_sched(RenderParams P)
 {
 	if ((!P.legacy && occ_skip_enabled(P)) != SKIP) return;
-	__shared__ float res[kSchedChunk][6][256];
+	constexpr int TW = PPW == 64 ? 16 : 32, RW = PPW / TW, PPL = PPW / 64; // tile width, rows per wave, pixels per lane
+	__shared__ float res[NK][6][4 * PPW];
 	const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	const u32 px = blockIdx.x * 16u + (threadIdx.x & 15u);
-	const u32 py = P.row0 + blockIdx.y * 16u + (threadIdx.x >> 4);
+	const u32 x0 = blockIdx.x * (u32)TW, y0 = P.row0 + blockIdx.y * (u32)(4 * RW) + (u32)(wave * RW); // this wave's tile
 	const float cs = 1.0f / (float)P.G;
 	const float vis = cs * P.u[U_CELLSIZE] * 0.5f;
 	const v3 vhalf = V(vis, vis, vis);
-	float r = 0.0f, g = 0.0f, b = 0.0f, a = 0.0f, d0 = 0.0f;
+	float r[PPL], g[PPL], b[PPL], a[PPL], d0[PPL];
 	u32 shadow = 0, pvis = 0, svis = 0;
-	for (u32 k0 = 0; k0 < P.spp; k0 += (u32)kSchedChunk)
+#pragma unroll
+	for (int i = 0; i < PPL; i++) { r[i] = 0.0f; g[i] = 0.0f; b[i] = 0.0f; a[i] = 0.0f; d0[i] = 0.0f; }
+	for (u32 k0 = 0; k0 < P.spp; k0 += (u32)NK)
 	{
-		const int nk = (int)min((u32)kSchedChunk, P.spp - k0), total = 64 * nk;
+		const int nk = (int)min((u32)NK, P.spp - k0), total = PPW * nk;
 		int next = 0; // wave-uniform: first job nobody has taken
 		RayState st;
 		st.job = -1;
 		st.phase = 0;
 		auto complete = [&](const Sample &s) {
-			const int slot = wave * 64 + (st.job & 63), kk = st.job >> 6;
+			const int slot = wave * PPW + st.job % PPW, kk = st.job / PPW;
 			res[kk][0][slot] = s.r; res[kk][1][slot] = s.g; res[kk][2][slot] = s.b; res[kk][3][slot] = s.a;
 			res[kk][4][slot] = s.depth; res[kk][5][slot] = (float)s.shadow_ray;
 			st.job = -1;
@@ -736,9 +742,9 @@ __global__ __launch_bounds__(256) void ca_render_packed_sched(RenderParams P)
 				if (st.job < 0 && j < total)
 				{
 					st.job = j;
-					const int lp = j & 63;
-					const u32 k = k0 + (u32)(j >> 6);
-					const u32 jx = blockIdx.x * 16u + (u32)(lp & 15), jy = P.row0 + blockIdx.y * 16u + (u32)(wave * 4 + (lp >> 4));
+					const int lp = j % PPW;
+					const u32 k = k0 + (u32)(j / PPW);
+					const u32 jx = x0 + (u32)(lp % TW), jy = y0 + (u32)(lp / TW);
 					Sample s{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0u};
 					bool done = true;
 					if (jx < P.W && jy < P.row1)
@@ -777,37 +783,46 @@ __global__ __launch_bounds__(256) void ca_render_packed_sched(RenderParams P)
 				if (done) complete(s);
 			}
 		}
-		// this lane's own pixel, samples in order: the same float sums as the plain kernel
+		// this lane's own pixels, samples in order: the same float sums as the plain kernel
 		__builtin_amdgcn_wave_barrier();
-		for (int kk = 0; kk < nk; kk++)
+#pragma unroll
+		for (int i = 0; i < PPL; i++)
 		{
-			r += res[kk][0][tid]; g += res[kk][1][tid]; b += res[kk][2][tid]; a += res[kk][3][tid];
-			if (k0 == 0 && kk == 0) d0 = res[kk][4][tid];
-			shadow += (u32)res[kk][5][tid];
+			const int slot = wave * PPW + i * 64 + lane;
+			for (int kk = 0; kk < nk; kk++)
+			{
+				r[i] += res[kk][0][slot]; g[i] += res[kk][1][slot]; b[i] += res[kk][2][slot]; a[i] += res[kk][3][slot];
+				if (k0 == 0 && kk == 0) d0[i] = res[kk][4][slot];
+				shadow += (u32)res[kk][5][slot];
+			}
 		}
 		__builtin_amdgcn_wave_barrier();
 	}
-	if (px >= P.W || py >= P.row1) return;
 	const float inv = 1.0f / (float)P.spp;
-	r *= inv; g *= inv; b *= inv; a *= inv;
-	const size_t i = (size_t)py * P.W + px;
-	if (P.light)
+	const float ig = P.legacy ? 1.0f / 2.2f : 1.0f / P.u[U_GAMMA];
+#pragma unroll
+	for (int i = 0; i < PPL; i++)
 	{
-		const __half2 rg = __floats2half2_rn(r, g), ba = __floats2half2_rn(b, 1.0f);
-		uint2 v;
-		v.x = *reinterpret_cast<const u32 *>(&rg);
-		v.y = *reinterpret_cast<const u32 *>(&ba);
-		P.light[i] = v;
-	}
-	if (P.depth)
-	{
-		const __half2 d = __floats2half2_rn(d0, 1.0f);
-		P.depth[i] = *reinterpret_cast<const u32 *>(&d);
-	}
-	if (P.presentation)
-	{
-		const float ig = P.legacy ? 1.0f / 2.2f : 1.0f / P.u[U_GAMMA];
-		P.presentation[i] = unorm8(powf(r, ig)) | (unorm8(powf(g, ig)) << 8) | (unorm8(powf(b, ig)) << 16) | (unorm8(a) << 24);
+		const int lp = i * 64 + lane;
+		const u32 px = x0 + (u32)(lp % TW), py = y0 + (u32)(lp / TW);
+		if (px >= P.W || py >= P.row1) continue;
+		const float rr = r[i] * inv, gg = g[i] * inv, bb = b[i] * inv, aa = a[i] * inv;
+		const size_t idx = (size_t)py * P.W + px;
+		if (P.light)
+		{
+			const __half2 rg = __floats2half2_rn(rr, gg), ba = __floats2half2_rn(bb, 1.0f);
+			uint2 v;
+			v.x = *reinterpret_cast<const u32 *>(&rg);
+			v.y = *reinterpret_cast<const u32 *>(&ba);
+			P.light[idx] = v;
+		}
+		if (P.depth)
+		{
+			const __half2 d = __floats2half2_rn(d0[i], 1.0f);
+			P.depth[idx] = *reinterpret_cast<const u32 *>(&d);
+		}
+		if (P.presentation)
+			P.presentation[idx] = unorm8(powf(rr, ig)) | (unorm8(powf(gg, ig)) << 8) | (unorm8(powf(bb, ig)) << 16) | (unorm8(aa) << 24);
 	}
 	if (P.counters)
 	{
@@ -1166,10 +1181,17 @@ hipError_t launch_render(const RenderLaunch &l, hipStream_t stream)
 		F.prev_depth = l.prev_depth;
 		hipLaunchKernelGGL(ca_render_frame_packed, grid, dim3(256), 0, stream, F);
 	}
+	else if (l.sched && l.spp == 1)
+	{
+		// one sample per pixel: 256 pixels per wave (a block covers 32 x 32 pixels)
+		const dim3 g1((l.W + 31u) / 32u, (P.row1 - P.row0 + 31u) / 32u);
+		hipLaunchKernelGGL((ca_render_packed_sched<false, 256, 1>), g1, dim3(256), 0, stream, P);
+		if (P.occ) hipLaunchKernelGGL((ca_render_packed_sched<true, 256, 1>), g1, dim3(256), 0, stream, P);
+	}
 	else if (l.sched)
 	{
-		hipLaunchKernelGGL(ca_render_packed_sched<false>, grid, dim3(256), 0, stream, P);
-		if (P.occ) hipLaunchKernelGGL(ca_render_packed_sched<true>, grid, dim3(256), 0, stream, P);
+		hipLaunchKernelGGL((ca_render_packed_sched<false, 64, kSchedChunk>), grid, dim3(256), 0, stream, P);
+		if (P.occ) hipLaunchKernelGGL((ca_render_packed_sched<true, 64, kSchedChunk>), grid, dim3(256), 0, stream, P);
 	}
 	else
 	{

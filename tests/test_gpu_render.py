@@ -153,15 +153,16 @@ def test_row_bands_stitch_into_the_full_frame(eng):
     set_rules(eng, rules("default"))
     eng.upload_state(cells)
     u = host.uniform_block(W, H, host.orbit_camera())
-    pres, light, depth = eng.render(u, W, H, 4)
-    got = np.zeros_like(pres)
-    for y0, y1 in ((0, 48), (48, 64), (64, 150)):
-        p, l, d = eng.render(u, W, H, 4, rows=(y0, y1))
-        got[y0:y1] = p[y0:y1]
-        np.testing.assert_array_equal(l[y0:y1].view(np.uint16), light[y0:y1].view(np.uint16))
-        np.testing.assert_array_equal(d[y0:y1].view(np.uint16), depth[y0:y1].view(np.uint16))
-        assert eng.render_stats().primary_rays == W * (y1 - y0) * 4
-    np.testing.assert_array_equal(got, pres)
+    for spp in (4, 1):  # 16-row tiles at 4 samples per pixel, 32-row tiles at 1: bands start on multiples of 16 in both
+        pres, light, depth = eng.render(u, W, H, spp)
+        got = np.zeros_like(pres)
+        for y0, y1 in ((0, 48), (48, 64), (64, 150)):
+            p, l, d = eng.render(u, W, H, spp, rows=(y0, y1))
+            got[y0:y1] = p[y0:y1]
+            np.testing.assert_array_equal(l[y0:y1].view(np.uint16), light[y0:y1].view(np.uint16))
+            np.testing.assert_array_equal(d[y0:y1].view(np.uint16), depth[y0:y1].view(np.uint16))
+            assert eng.render_stats().primary_rays == W * (y1 - y0) * spp
+        np.testing.assert_array_equal(got, pres)
     from cellularautomatons3d_amd import Ca3dError
     with pytest.raises(Ca3dError):
         eng.render(u, W, H, 1, rows=(8, 64))     # a band starts on a tile row

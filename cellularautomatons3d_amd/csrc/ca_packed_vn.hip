@@ -9,9 +9,11 @@
 //     bases are scalar, row offsets are three 32-bit VGPRs;
 //   * the words either side of a segment come from the neighbour lanes by DPP moves (no LDS round trip);
 //   * the rule is two 8-entry truth tables over the three count planes (survive, born). v_bitop3_b32 evaluates any
-//     3-input truth table in ONE instruction but takes the table as an immediate, so the kernel carries all 256
-//     of them behind a wave-uniform jump: 3 VALU per 32 cells for the whole rule instead of ~22 through the cube
-//     programs of ca_bitslice.inc.
+//     3-input truth table in ONE instruction but takes the table as an immediate: 3 VALU per 32 cells for the whole
+//     rule instead of ~22 through the cube programs of ca_bitslice.inc. The tables are compile-time constants in the
+//     kernels ca_jit.cpp builds per rule at run time (and in the pre-built specialisation of the start-up rule);
+//     the fallback carries all 256 tables behind a wave-uniform jump.
+// This file: the ahead-of-time instantiations and the launcher. The device code is ca_packed_vn_kernel.inc.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

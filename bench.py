@@ -1,21 +1,30 @@
 #!/usr/bin/env python3
 """Headline benchmark: Gcells/s of the bit-packed CA step (BASELINE.json metric), one process per GPU.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W          (N > 1: spawns its N ranks itself)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-      bench.py --gpus N --steps K --warmup W
+      bench.py --gpus N --steps K --warmup W             (the same, launched from outside)
 
-A "step" is one CA step (one dispatch of the reference's compute pass) over the whole grid. N = 1 runs the 512^3
-packed grid the metric is quoted on; N > 1 runs the 1024^3 grid Z-slabbed over the ranks (per-GPU cell count at
-N = 8 equals the N = 1 workload) with the ghost planes exchanged by RCCL. The state is resident in HBM before the
-timed region; the timed region is bracketed by barrier + synchronize and the max over ranks is taken.
+A "step" is one CA step (one dispatch of the reference's compute pass, main_pathtraced.js:1796-1809) over the whole
+grid. The batch of K steps is repeated (`reps`) until at least 50 ms are timed, so the value does not depend on K.
+--config picks the BASELINE configuration:
+  3 (default at N = 1)  512^3, default rule, + the 1920x1080 @ 4 spp render leg          BASELINE configs[2]
+  4 (default at N > 1)  1024^3, default rule, Z-slabs over the ranks, RCCL halo exchange   BASELINE configs[3]
+  5                     2048^3, clustered rule-set, halo overlapped with compute, + the 3840x2160 frame   configs[4]
+Configs 4 and 5 at N = 1 run the same grid on one GPU: the base of the scaling curve (the N = 1 line of config 3 also
+carries it as `scaling_base`, measured in the same run). The state is resident in HBM before the timed region; the
+timed region is bracketed by barrier + synchronize and the max over ranks is taken.
 
-Prints ONE JSON line on rank 0 with `roofline` (algorithmic bytes per launch / measured launch duration against
-the 8 TB/s HBM peak) and, at N = 1, `cpu_baseline` (the CPU oracle timed on this host's cores on a bounded sample).
+Prints ONE JSON line on rank 0 with `roofline` (algorithmic bytes per launch / launch duration from HIP events recorded
+on the engine's stream around the timed region, against the 8 TB/s HBM peak) and, at N = 1, `cpu_baseline` (the CPU
+oracle timed on this host's cores on a bounded sample).
 """
 import argparse
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,6 +32,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+INFINITY_CACHE_BYTES = 256 << 20
+MIN_TIMED_SECONDS = 0.05
 
 RULES = {
     "default": dict(neighbourhood="von neumann", born="1,3", survive="0-6"),
@@ -32,31 +43,68 @@ RULES = {
     "life2d": dict(neighbourhood="moore 2D", born="3", survive="2,3"),
 }
 
+CONFIGS = {  # BASELINE.json configs[2..4]
+    3: dict(grid=512, rule="default", render_size="1920x1080"),
+    4: dict(grid=1024, rule="default", render_size="1920x1080"),
+    5: dict(grid=2048, rule="clustered", render_size="3840x2160", overlap="on"),
+}
 
-def parse():
+
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2048)
     ap.add_argument("--warmup", type=int, default=256)
-    ap.add_argument("--grid", type=int, default=0, help="grid edge (default: 512 at N=1, 1024 at N>1)")
-    ap.add_argument("--rule", choices=sorted(RULES), default="default")
+    ap.add_argument("--config", type=int, choices=sorted(CONFIGS), default=0, help="BASELINE configuration (default: 3 at N=1, 4 at N>1)")
+    ap.add_argument("--grid", type=int, default=0, help="grid edge (overrides the configuration's)")
+    ap.add_argument("--rule", choices=sorted(RULES), default="", help="rule-set (overrides the configuration's)")
     ap.add_argument("--density-rounds", type=int, default=0, help="AND rounds of the hashed fill: density 2^-(1+r)")
     ap.add_argument("--ghost", type=int, default=32, help="ghost planes per side = steps between halo exchanges (N>1)")
+    ap.add_argument("--min-seconds", type=float, default=MIN_TIMED_SECONDS, help="repeat the batch until this much is timed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--no-render", action="store_true", help="skip the renderer leg (N=1)")
+    ap.add_argument("--no-render", action="store_true", help="skip the renderer legs (N=1)")
+    ap.add_argument("--no-scaling-base", action="store_true", help="N=1, config 3: skip the 1024^3 single-GPU leg")
     ap.add_argument("--multi-render", action="store_true",
                     help="N>1: also time the frame shared between the ranks (volume all-gather + bands of image rows); "
-                         "off by default so that the scaling run times the CA step alone")
-    ap.add_argument("--render-size", default="1920x1080")
+                         "off by default (on for --config 5) so that the scaling run times the CA step alone")
+    ap.add_argument("--render-size", default="")
     ap.add_argument("--render-spp", type=int, default=4)
     ap.add_argument("--render-frames", type=int, default=10)
-    ap.add_argument("--overlap", choices=["auto", "on", "off"], default="auto",
+    ap.add_argument("--overlap", choices=["auto", "on", "off"], default="",
                     help="N>1: run the halo exchange under the interior phase of each batch (auto: by slab size, see slab.py)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="gloo = rehearsal transport through host memory")
+    ap.add_argument("--transport", choices=["auto", "native", "torch"], default="auto",
+                    help="N>1 halo exchange: native = ncclSend/ncclRecv captured inside the engine's slab graph (RCCL only); "
+                         "torch = torch.distributed point-to-point from Python")
     ap.add_argument("--device-map", default="", help="comma list: GPU index per rank (default: LOCAL_RANK)")
     ap.add_argument("--check", action="store_true", help="verify the final state against the oracle (small grids)")
-    return ap.parse_args()
+    a = ap.parse_args(argv)
+    a.config = a.config or (3 if a.gpus == 1 else 4)
+    cfg = CONFIGS[a.config]
+    a.grid = a.grid or cfg["grid"]
+    a.rule = a.rule or cfg["rule"]
+    a.render_size = a.render_size or cfg["render_size"]
+    a.overlap = a.overlap or cfg.get("overlap", "auto")
+    if a.config == 5 and a.gpus > 1:
+        a.multi_render = True
+    return a
+
+
+def spawn_ranks(a) -> int:
+    """`python bench.py --gpus N` from a plain shell: start the N ranks as children (torch.distributed.run), before
+    anything in this process has touched the GPU, and hand back their exit code. Rank 0's JSON line is the only
+    thing the children write to stdout."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env, cwd=ROOT)
 
 
 def cpu_baseline(G, rule_kw, seconds):
@@ -84,7 +132,6 @@ def cpu_baseline(G, rule_kw, seconds):
 def cpu_baseline_js(seconds=4.0, G=256):
     """the JavaScript CPU stepper (oracle/js_stepper.js), single thread, on this host."""
     import shutil
-    import subprocess
 
     node = shutil.which("node")
     if not node:
@@ -100,53 +147,47 @@ def cpu_baseline_js(seconds=4.0, G=256):
         return {"error": str(e)}
 
 
-def render_leg(eng, G, a):
-    """Second half of BASELINE's metric: Mray/s of the volume renderer at 1080p, 4 spp, on the same grid size.
-    Volume = hashed fill of density 2^-5 (dense silhouette), oblique bench pose; rays = primary +
-    shadow rays traced; frames stay on the device (no read-back in the timed region)."""
+def time_frames(eng, u, W, H, spp, frames):
     import torch
 
+    for _ in range(2):
+        eng.render(u, W, H, spp, readback=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        eng.render(u, W, H, spp, readback=False)
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, eng.render_stats()
+
+
+def render_leg(eng, G, a, size=None, sparse=True):
+    """Second half of BASELINE's metric: Mray/s of the volume renderer at 1080p (config 5: 3840x2160), 4 spp, on the
+    same grid size. Volume = hashed fill of density 2^-5 (dense silhouette), oblique bench pose (SURVEY 8(d));
+    rays = primary + shadow rays traced; frames stay on the device (no read-back in the timed region)."""
     from cellularautomatons3d_amd import host
 
-    W, H = (int(v) for v in a.render_size.lower().split("x"))
+    W, H = (int(v) for v in (size or a.render_size).lower().split("x"))
     cells = host.random_fill(host.words_per_buffer(G), seed=0xCA3D0001, and_rounds=4)
     eng.upload_state(cells)
-    u = host.uniform_block(W, H, host.orbit_camera())
-    for _ in range(2):
-        eng.render(u, W, H, a.render_spp, readback=False)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    gpu_ms = 0.0
-    for _ in range(a.render_frames):
-        eng.render(u, W, H, a.render_spp, readback=False)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    st = eng.render_stats()
+    dt, st = time_frames(eng, host.uniform_block(W, H, host.orbit_camera()), W, H, a.render_spp, a.render_frames)
     rays = st.primary_rays + st.shadow_rays
-    dense = {"metric": "Mray/s path-trace 1080p", "value": round(rays * a.render_frames / dt / 1e6, 2), "unit": "Mray/s",
-            "ms_per_frame": round(dt * 1e3 / a.render_frames, 4), "kernel_ms": round(st.gpu_ms, 4),
-            "primary_rays": int(st.primary_rays), "shadow_rays": int(st.shadow_rays),
-            "cell_visits_per_primary_ray": round(st.primary_cell_visits / max(1, st.primary_rays), 2),
-            "cell_visits_per_shadow_ray": round(st.shadow_cell_visits / max(1, st.shadow_rays), 2),
-            "config": {"workload": f"{G}^3 packed volume, hashed fill density 2^-5, {W}x{H} @ {a.render_spp} spp, oblique pose "
-                                   "(0.6 rad about (1,1,0), distance 1.4), exact DDA walk + shadow ray + Cook-Torrance"}}
-    # the reference UI's own start-up scene (SURVEY 8(d) "sparse"): the single seed evolved 30 steps, default pose
-    eng.upload_state(host.initial_state(G))
-    eng.step(30)
-    us = host.uniform_block(W, H, host.camera_matrix())
-    eng.render(us, W, H, a.render_spp, readback=False)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.render_frames):
-        eng.render(us, W, H, a.render_spp, readback=False)
-    torch.cuda.synchronize()
-    dts = time.perf_counter() - t0
-    sts = eng.render_stats()
-    dense["sparse_scene"] = {"ms_per_frame": round(dts * 1e3 / a.render_frames, 4),
-                             "value": round((sts.primary_rays + sts.shadow_rays) * a.render_frames / dts / 1e6, 2), "unit": "Mray/s",
-                             "cell_visits_per_primary_ray": round(sts.primary_cell_visits / max(1, sts.primary_rays), 2),
-                             "workload": f"{G}^3, single seed after 30 default-rule steps, default pose, {W}x{H} @ {a.render_spp} spp, "
-                                         "empty-space skipping over two levels of occupancy blocks"}
+    dense = {"metric": f"Mray/s path-trace {'1080p' if H == 1080 else f'{W}x{H}'}", "value": round(rays * a.render_frames / dt / 1e6, 2), "unit": "Mray/s",
+             "ms_per_frame": round(dt * 1e3 / a.render_frames, 4), "kernel_ms": round(st.gpu_ms, 4),
+             "primary_rays": int(st.primary_rays), "shadow_rays": int(st.shadow_rays),
+             "cell_visits_per_primary_ray": round(st.primary_cell_visits / max(1, st.primary_rays), 2),
+             "cell_visits_per_shadow_ray": round(st.shadow_cell_visits / max(1, st.shadow_rays), 2),
+             "config": {"workload": f"{G}^3 packed volume, hashed fill density 2^-5, {W}x{H} @ {a.render_spp} spp, oblique pose "
+                                    "(0.6 rad about (1,1,0), distance 1.4), exact DDA walk + shadow ray + Cook-Torrance"}}
+    if sparse:
+        # the reference UI's own start-up scene (SURVEY 8(d) "sparse"): the single seed evolved 30 steps, default pose
+        eng.upload_state(host.initial_state(G))
+        eng.step(30)
+        dts, sts = time_frames(eng, host.uniform_block(W, H, host.camera_matrix()), W, H, a.render_spp, a.render_frames)
+        dense["sparse_scene"] = {"ms_per_frame": round(dts * 1e3 / a.render_frames, 4),
+                                 "value": round((sts.primary_rays + sts.shadow_rays) * a.render_frames / dts / 1e6, 2), "unit": "Mray/s",
+                                 "cell_visits_per_primary_ray": round(sts.primary_cell_visits / max(1, sts.primary_rays), 2),
+                                 "workload": f"{G}^3, single seed after 30 default-rule steps, default pose, {W}x{H} @ {a.render_spp} spp, "
+                                             "empty-space skipping over two levels of occupancy blocks"}
     return dense
 
 
@@ -182,7 +223,7 @@ def render_leg_multi(se, G, a, world, rank, barrier):
     dist.all_reduce(t)
     out = None
     if rank == 0:
-        out = {"metric": "Mray/s path-trace 1080p", "value": round(int(t.item()) * a.render_frames / dt / 1e6, 2), "unit": "Mray/s",
+        out = {"metric": f"Mray/s path-trace {'1080p' if H == 1080 else f'{W}x{H}'}", "value": round(int(t.item()) * a.render_frames / dt / 1e6, 2), "unit": "Mray/s",
                "ms_per_frame": round(dt * 1e3 / a.render_frames, 4),
                "config": {"workload": f"{G}^3 packed volume all-gathered to every rank, hashed fill density 2^-5, {W}x{H} @ {a.render_spp} spp, "
                                       f"bands of image rows over {world} ranks, frame assembled on rank 0 (read-back included)"}}
@@ -219,30 +260,122 @@ def copy_ceiling_gbs():
 
 
 def pmc_traffic(kernel, G):
-    """HBM bytes per launch from a committed rocprofv3 PMC run (profiles/pmc_traffic.json), or None."""
+    """Fabric bytes per launch (FETCH_SIZE + WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes) from the committed
+    rocprofv3 PMC passes of this command (profiles/pmc_traffic.json; tools/profile_round.sh collects them), or None:
+    counters cannot be read from inside an un-profiled run."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.exists(p):
         return None
     try:
         d = json.load(open(p))
-        return d.get(f"{kernel}@{G}", {}).get("hbm_bytes_per_launch")
+        for key in (f"{kernel}@{G}", f"{kernel.split('(')[0].split('<')[0]}@{G}"):
+            if key in d:
+                return d[key].get("hbm_bytes_per_launch")
     except Exception:
-        return None
+        pass
+    return None
+
+
+def rule_payload(rule_kw):
+    from cellularautomatons3d_amd import host
+
+    b, s = host.recalculate_rules_values(rule_kw.get("born", "1,3"), rule_kw.get("survive", "0-6"), rule_kw.get("born_edges", "27"),
+                                          rule_kw.get("survive_edges", "27"), rule_kw.get("born_corners", "27"), rule_kw.get("survive_corners", "27"))
+    offs = (host.NEIGHBOURHOOD_MAP[rule_kw["neighbourhood"]], host.NEIGHBOURHOOD_MAP["edges"], host.NEIGHBOURHOOD_MAP["corners"])
+    return offs, s, b
+
+
+def timed_region(run, stream, steps, warmup, min_seconds, barrier, world, backend):
+    """W warm-up steps, then `reps` batches of K steps between barrier + synchronize; reps is chosen (the same on every
+    rank) so that at least `min_seconds` are timed. Returns (wall seconds, max over ranks; reps; HIP-event ms between
+    the first and the last enqueue of the timed region on the engine's stream)."""
+    import torch
+    import torch.distributed as dist
+
+    if warmup > 0:
+        run(warmup)
+    barrier()
+    t0 = time.perf_counter()
+    run(steps)  # calibration batch (also warm: graphs for K steps exist afterwards)
+    barrier()
+    est = time.perf_counter() - t0
+    reps = max(1, min(1 << 20, int(math.ceil(min_seconds / max(est, 1e-7)))))
+    if world > 1:
+        t = torch.tensor([reps], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        reps = int(t.item())
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    barrier()
+    t0 = time.perf_counter()
+    e0.record(stream)
+    for _ in range(reps):
+        run(steps)
+    e1.record(stream)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, reps, e0.elapsed_time(e1)
+
+
+def single_gpu_leg(device, G, rule, steps, warmup, min_seconds, density_rounds=0):
+    """One GPU, whole grid: returns the numbers of the timed region plus the engine (state = the bench state advanced)."""
+    import torch
+
+    from cellularautomatons3d_amd import Engine, host
+
+    offs, s, b = rule_payload(RULES[rule])
+    eng = Engine(device)
+    eng.configure(G)
+    eng.set_rules(*offs, s, b)
+    full = host.random_fill(host.words_per_buffer(G), seed=0xCA3D0001, and_rounds=density_rounds)
+    eng.upload_state(full)
+    stream = torch.cuda.Stream(device=device)  # the engine runs on a torch-visible stream so torch events bracket its work
+    eng.set_stream(stream.cuda_stream)
+    eng.set_option("graph_prepare", steps)  # graph capture / instantiation stays out of the timed region
+    if warmup:
+        eng.set_option("graph_prepare", warmup)
+
+    def barrier():
+        torch.cuda.synchronize()
+
+    dt, reps, ev_ms = timed_region(eng.step, stream, steps, warmup, min_seconds, barrier, 1, "nccl")
+    return eng, full, dt, reps, ev_ms
+
+
+def roofline_block(kernel, G, bytes_per_launch, launches, ev_ms, state_bytes):
+    launch_ms = ev_ms / max(1, launches)
+    achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+    traffic = pmc_traffic(kernel, G)
+    fits = 2 * state_bytes <= INFINITY_CACHE_BYTES
+    return {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "traffic_source": None if traffic is None else "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
+                                                          "(fabric requests, Infinity Cache hits included), not measured in this run",
+            "kernel": kernel, "launch_us": round(launch_ms * 1e3, 3),
+            "algorithmic_bytes_per_launch": bytes_per_launch, "launches_timed": int(launches),
+            "timing": "HIP events on the engine's stream around the whole timed region / launches in it",
+            "working_set_bytes": 2 * state_bytes,
+            "resident": "infinity cache (both ping-pong buffers fit in 256 MiB: the rate is an algorithmic-byte rate against the HBM peak, "
+                        "not DRAM traffic)" if fits else "hbm (the ping-pong buffers exceed the 256 MiB Infinity Cache)"}
 
 
 def main():
     a = parse()
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus > 1 and world_env == 1 and "RANK" not in os.environ:
+        raise SystemExit(spawn_ranks(a))
     import torch
     import torch.distributed as dist
 
-    from cellularautomatons3d_amd import Engine, host, slab
+    from cellularautomatons3d_amd import host, slab
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = world_env
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         raise SystemExit(f"--gpus {a.gpus} does not match WORLD_SIZE {world}")
     if a.device_map:
         local_rank = int(a.device_map.split(",")[rank])
@@ -254,52 +387,41 @@ def main():
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    G = a.grid or (512 if world == 1 else 1024)
+    G = a.grid
     rule_kw = RULES[a.rule]
-    b, s = host.recalculate_rules_values(rule_kw.get("born", "1,3"), rule_kw.get("survive", "0-6"), rule_kw.get("born_edges", "27"),
-                                          rule_kw.get("survive_edges", "27"), rule_kw.get("born_corners", "27"), rule_kw.get("survive_corners", "27"))
-    offs = (host.NEIGHBOURHOOD_MAP[rule_kw["neighbourhood"]], host.NEIGHBOURHOOD_MAP["edges"], host.NEIGHBOURHOOD_MAP["corners"])
+    pw = (G // 32) * G
+    state_bytes = pw * G * 4
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    full = host.random_fill(host.words_per_buffer(G), seed=0xCA3D0001, and_rounds=a.density_rounds)
-    pw = (G // 32) * G
+    se = None
     if world == 1:
-        eng = Engine(local_rank)
-        eng.configure(G)
-        eng.set_rules(*offs, s, b)
-        eng.upload_state(full)
-        run = eng.step
+        eng, full, dt, reps, ev_ms = single_gpu_leg(local_rank, G, a.rule, a.steps, a.warmup, a.min_seconds, a.density_rounds)
         core = eng
     else:
-        se = slab.SlabEngine(G, rank, world, ghost=a.ghost, device=local_rank, host_staging=a.backend == "gloo", overlap={"auto": "auto", "on": True, "off": False}[a.overlap])
+        offs, s, b = rule_payload(rule_kw)
+        full = host.random_fill(host.words_per_buffer(G), seed=0xCA3D0001, and_rounds=a.density_rounds)
+        native = a.backend == "nccl" and a.transport != "torch" and hasattr(slab, "NativeSlabEngine")
+        if a.transport == "native" and not native:
+            raise SystemExit("--transport native needs the RCCL backend and a libca3d.so built with RCCL")
+        if native:
+            se = slab.NativeSlabEngine(G, rank, world, ghost=a.ghost, device=local_rank, overlap={"auto": "auto", "on": True, "off": False}[a.overlap])
+        else:
+            se = slab.SlabEngine(G, rank, world, ghost=a.ghost, device=local_rank, host_staging=a.backend == "gloo",
+                                 overlap={"auto": "auto", "on": True, "off": False}[a.overlap])
         se.engine.set_rules(*offs, s, b)
         se.upload_state(full[se.z0 * pw:(se.z0 + se.nz) * pw])
-        run = se.run
         core = se.engine
+        dt, reps, ev_ms = timed_region(se.run, se.stream, a.steps, a.warmup, a.min_seconds, barrier, world, a.backend)
 
-    if world == 1:
-        eng.set_option("graph_prepare", max(a.steps, a.warmup))  # graph capture / instantiation stays out of the timed region
-    if a.warmup > 0:
-        run(a.warmup)
-    barrier()
-    t0 = time.perf_counter()
-    run(a.steps)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if a.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    st = core.stats()
+    total_steps = a.steps * reps
     info = core.info()
     kernel = info.kernel_name.decode()
     cells = float(G) ** 3
-    value = cells * a.steps / dt / 1e9
+    value = cells * total_steps / dt / 1e9
 
     ok = None
     if a.check:
@@ -307,7 +429,7 @@ def main():
         import numpy as np
         import oracle_lib as ol
 
-        want = ol.packed_run(G, full, ol.Rules.from_strings(**rule_kw), a.warmup + a.steps)
+        want = ol.packed_run(G, full, ol.Rules.from_strings(**rule_kw), a.warmup + a.steps * (reps + 1))
         got = core.read_state()
         lo = 0 if world == 1 else se.z0 * pw
         ok = bool(np.array_equal(got, want[lo:lo + got.size]))
@@ -321,39 +443,51 @@ def main():
         multi_render = render_leg_multi(se, G, a, world, rank, barrier)
 
     if rank == 0:
-        # dominant kernel: HIP events on the engine's stream around the last step batch (get_stats), divided by the
-        # launches in it; algorithmic bytes per launch = 0.25 B x cells the launch updates.
-        launch_ms = st.gpu_ms / max(1, st.kernel_launches)
-        bytes_per_launch = st.algorithmic_bytes / max(1, st.kernel_launches)
-        achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+        # dominant kernel: one launch = one step over this rank's planes; algorithmic bytes per launch = 0.25 B x the
+        # cells this rank owns; launches timed = steps in the timed region (an overlapped slab batch
+        # issues two smaller launches per step: the pair counts as one)
+        own_cells = cells if world == 1 else float(G) * G * se.nz
         out = {
             "metric": "Gcells/s CA step at 512^3" if G == 512 else f"Gcells/s CA step at {G}^3",
-            "value": round(value, 3), "unit": "Gcells/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(dt * 1e3 / a.steps, 6), "higher_is_better": True,
+            "value": round(value, 3), "unit": "Gcells/s", "n_gpus": world, "steps": a.steps, "reps": reps, "warmup": a.warmup,
+            "ms_per_step": round(dt * 1e3 / total_steps, 6), "higher_is_better": True,
             "scaling": "strong" if world > 1 else "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": f"{G}^3 uint32-packed grid, rule '{a.rule}' ({rule_kw['neighbourhood']} B{rule_kw['born']}/S{rule_kw['survive']}), "
-                                   f"hashed fill seed 0xCA3D0001 density {2.0 ** -(1 + a.density_rounds):g}, one CA step per bench step",
-                       "grid": G, "layout": "packed32", "rule": a.rule,
-                       "parallelism": "1 GPU" if world == 1 else f"z-slab x{world}, ghost {a.ghost} planes, RCCL send/recv every {a.ghost} steps" + (" overlapped with the interior phase" if se.overlap else "")},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(kernel, G),
-                         "kernel": kernel, "launch_us": round(launch_ms * 1e3, 3),
-                         "algorithmic_bytes_per_launch": bytes_per_launch, "launches_timed": int(st.kernel_launches)},
+                                   f"hashed fill seed 0xCA3D0001 density {2.0 ** -(1 + a.density_rounds):g}, one CA step per bench step, "
+                                   f"{reps} batches of {a.steps} steps timed",
+                       "baseline_config": a.config, "grid": G, "layout": "packed32", "rule": a.rule,
+                       "parallelism": "1 GPU" if world == 1 else f"z-slab x{world}, ghost {a.ghost} planes, RCCL send/recv every {a.ghost} steps"
+                                      + (" overlapped with the interior phase" if se.overlap else "")
+                                      + (", exchange captured in the slab graph (native RCCL)" if getattr(se, "native", False) else ", exchange through torch.distributed")},
+            "roofline": roofline_block(kernel, G, 0.25 * own_cells, total_steps, ev_ms, state_bytes),
         }
         if world == 1:
             ceiling = copy_ceiling_gbs()
             out["roofline"]["copy_ceiling"] = round(ceiling, 1)  # GB/s, measured here: 1 GiB device-to-device copy, read + write
-            out["roofline"]["frac_of_copy_ceiling"] = round(achieved / ceiling, 4)
+            out["roofline"]["frac_of_copy_ceiling"] = round(out["roofline"]["achieved"] / ceiling, 4)
         if ok is not None:
             out["oracle_match"] = ok
         if world == 1 and not a.no_render:
             out["render"] = render_leg(eng, G, a)
+            if a.config == 3 and a.render_size == "1920x1080":
+                out["render_4k"] = render_leg(eng, G, a, size="3840x2160", sparse=False)  # BASELINE configs[4]'s frame size
+        if world == 1 and a.config == 3 and G == 512 and not a.no_scaling_base:
+            # the single-GPU point of the multi-GPU curve, on the multi-GPU grid, in the same run (N > 1 runs 1024^3)
+            eng.close()
+            e2, _, dt2, reps2, ev2 = single_gpu_leg(local_rank, 1024, "default", 256, 64, a.min_seconds)
+            k2 = e2.info().kernel_name.decode()
+            out["scaling_base"] = {"grid": 1024, "rule": "default", "n_gpus": 1, "value": round(1024.0 ** 3 * 256 * reps2 / dt2 / 1e9, 3), "unit": "Gcells/s",
+                                   "ms_per_step": round(dt2 * 1e3 / (256 * reps2), 6), "steps": 256, "reps": reps2,
+                                   "roofline": roofline_block(k2, 1024, 0.25 * 1024.0 ** 3, 256 * reps2, ev2, 128 << 20),
+                                   "note": "divide the N > 1 values (config 4: 1024^3) by this, not by the 512^3 headline; "
+                                           "`python bench.py --gpus 1 --config 5` gives the base of the 2048^3 clustered curve"}
+            e2.close()
         if multi_render is not None:
             out["render"] = multi_render
             if multi_render.get("frame_match") is False:
                 ok = False
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(G, rule_kw, a.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(min(G, 512), rule_kw, a.cpu_seconds)
             out["cpu_baseline_js"] = cpu_baseline_js()
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -67,9 +67,11 @@ struct ca3d_engine
 	uint32_t render_row0 = 0, render_row1 = 0; // rows [row0, row1) of the frame are rendered (0, 0: all): a rank's band
 	int use_fused = 0; // the two-step fused kernel is bit-exact but measured slower than two single steps
 
-	// hipGraph of an even number of full-grid steps starting from buffer 0 (invalidated on any change)
-	hipGraphExec_t graph_exec[2] = {nullptr, nullptr}; // captured batches of kGraphSteps[i] steps from buffer 0
-	uint32_t graph_launches[2] = {0, 0};
+	// captured batches of full-grid steps, keyed by (steps in the batch, buffer it starts from); invalidated on any
+	// change of rules, kernels, stream or buffers
+	struct StepGraph { hipGraphExec_t exec = nullptr; uint32_t launches = 0; };
+	std::map<uint64_t, StepGraph> step_graphs;
+	uint32_t graph_min = 8; // shorter batches are launched kernel by kernel
 	std::map<uint64_t, hipGraphExec_t> slab_graphs; // (phase, start buffer, sub-steps) -> captured slab batch
 	uint32_t pending_edges = 0;                     // sub-steps of an edge phase awaiting its interior phase
 	int use_jit = 1;      // specialise kernels for the rule at run time (hiprtc) where a specialisation exists
@@ -105,12 +107,8 @@ namespace
 
 void drop_graph(ca3d_engine *h)
 {
-	for (int i = 0; i < 2; i++)
-		if (h->graph_exec[i])
-		{
-			hipGraphExecDestroy(h->graph_exec[i]);
-			h->graph_exec[i] = nullptr;
-		}
+	for (auto &kv : h->step_graphs) hipGraphExecDestroy(kv.second.exec);
+	h->step_graphs.clear();
 	for (auto &kv : h->slab_graphs) hipGraphExecDestroy(kv.second);
 	h->slab_graphs.clear();
 }
@@ -141,6 +139,7 @@ void free_buffers(ca3d_engine *h)
 	h->has_state = false;
 	h->step = 0;
 	h->cur = 0;
+	h->pending_edges = 0; // an edge phase belongs to the state that has just gone
 }
 
 int bind_device(ca3d_engine *h)
@@ -236,6 +235,13 @@ void refresh_kernels(ca3d_engine *h)
 	}
 }
 
+// A failed specialisation is not an error of the call that triggered it (the ahead-of-time kernels take over), but it
+// must not be silent: the message goes where the caller looks (ca3d_last_error, ca3d_get_jit_log).
+void note_jit_failure(const ca3d_engine *h)
+{
+	if (!h->jit_log.empty()) g_last_error = "run-time kernel specialisation failed, pre-built kernels in use: " + h->jit_log;
+}
+
 int check_ready(ca3d_engine *h)
 {
 	if (!h) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL engine handle");
@@ -245,9 +251,10 @@ int check_ready(ca3d_engine *h)
 	return CA3D_OK;
 }
 
-// Two graph sizes: consecutive graph launches leave ~9 us of idle GPU between them (measured on the slab path), which
-// is 0.13 us per step with 64-step graphs at 512^3 and negligible with 1024; short batches still get a graph.
-constexpr uint32_t kGraphSteps[2] = {1024, 64};
+// Longest captured batch: consecutive graph launches leave a few microseconds of idle GPU between them, negligible
+// against 1024 steps; a batch of n < 1024 steps gets a graph of exactly n steps (cached per n and start buffer).
+constexpr uint32_t kMaxGraphSteps = 1024;
+constexpr size_t kMaxStepGraphs = 24;
 
 // Launch plan for n steps that keeps the reference's ping-pong invariant (main_pathtraced.js:1580-1609): the
 // state after n steps sits in buffer (start + n) % 2 and the other buffer holds the state one step earlier. A
@@ -284,22 +291,42 @@ int enqueue_batch(ca3d_engine *h, uint32_t n, uint32_t start_buf, hipStream_t s,
 	return CA3D_OK;
 }
 
-int build_graph(ca3d_engine *h, int which)
+// Captured batch of n steps starting from buffer `start` (built on first use).
+int step_graph(ca3d_engine *h, uint32_t n, uint32_t start, ca3d_engine::StepGraph **out)
 {
-	// Capture kGraphSteps[which] steps starting at buffer 0: launch boundaries stay, the host cost per launch drops
-	// from ~4 us to the graph's amortised cost.
+	const uint64_t key = ((uint64_t)start << 32) | n;
+	auto it = h->step_graphs.find(key);
+	if (it != h->step_graphs.end()) { *out = &it->second; return CA3D_OK; }
+	if (h->step_graphs.size() >= kMaxStepGraphs)
+	{
+		// a caller cycling through many batch lengths: start over rather than grow without bound
+		HIP_TRY(hipStreamSynchronize(h->stream));
+		for (auto &kv : h->step_graphs) hipGraphExecDestroy(kv.second.exec);
+		h->step_graphs.clear();
+	}
+	// Launch boundaries stay; the host cost per launch drops from ~4 us to the graph's amortised cost.
 	hipGraph_t graph = nullptr;
 	HIP_TRY(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
 	uint64_t launches = 0;
-	int rc = enqueue_batch(h, kGraphSteps[which], 0, h->stream, &launches);
+	int rc = enqueue_batch(h, n, start, h->stream, &launches);
 	hipError_t e = hipStreamEndCapture(h->stream, &graph);
 	if (rc != CA3D_OK) { if (graph) hipGraphDestroy(graph); return rc; }
 	if (e != hipSuccess) return fail(CA3D_ERR_DEVICE, "hipStreamEndCapture: %s", hipGetErrorString(e));
-	e = hipGraphInstantiate(&h->graph_exec[which], graph, nullptr, nullptr, 0);
+	ca3d_engine::StepGraph g;
+	e = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
 	hipGraphDestroy(graph);
-	if (e != hipSuccess) { h->graph_exec[which] = nullptr; return fail(CA3D_ERR_DEVICE, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
-	h->graph_launches[which] = (uint32_t)launches;
+	if (e != hipSuccess) return fail(CA3D_ERR_DEVICE, "hipGraphInstantiate: %s", hipGetErrorString(e));
+	g.launches = (uint32_t)launches;
+	*out = &h->step_graphs.emplace(key, g).first->second;
 	return CA3D_OK;
+}
+
+// The unpacked layout's first step after an upload with cell values > 1 must be the literal kernel (raw u32 sums,
+// compute.wgsl:160-174); every later state is 0 / 1. Graphs are only ever captured in the 0 / 1 regime, so a
+// cached graph can never replay the wrong kernel after a new upload.
+bool graphs_allowed(const ca3d_engine *h)
+{
+	return h->use_graph && h->stream != nullptr && !(h->layout == CA3D_LAYOUT_UNPACKED && !h->binary_state);
 }
 
 } // namespace
@@ -401,7 +428,7 @@ int ca3d_configure(ca3d_t *h, uint32_t gx, uint32_t gy, uint32_t gz, int layout)
 	h->ghost = 0;
 	h->nplanes = gx;
 	rc = allocate(h);
-	if (rc == CA3D_OK) refresh_kernels(h);
+	if (rc == CA3D_OK) { refresh_kernels(h); note_jit_failure(h); }
 	return rc;
 }
 
@@ -418,7 +445,7 @@ int ca3d_configure_slab(ca3d_t *h, uint32_t g, int layout, uint32_t z0, uint32_t
 	h->ghost = ghost;
 	h->nplanes = nz + 2u * ghost;
 	rc = allocate(h);
-	if (rc == CA3D_OK) refresh_kernels(h);
+	if (rc == CA3D_OK) { refresh_kernels(h); note_jit_failure(h); }
 	return rc;
 }
 
@@ -436,6 +463,7 @@ int ca3d_set_rules(ca3d_t *h, const int32_t *main_offsets, uint32_t n_main, cons
 	drop_graph(h);
 	h->rules = r;
 	refresh_kernels(h);
+	note_jit_failure(h);
 	return CA3D_OK;
 }
 
@@ -460,6 +488,7 @@ int ca3d_upload_state(ca3d_t *h, const uint32_t *words, size_t n_words)
 	HIP_TRY(hipStreamSynchronize(h->stream));
 	h->step = 0;
 	h->cur = 0;
+	h->pending_edges = 0; // a restart between the two phases of a batch abandons the batch
 	h->has_state = true;
 	h->binary_state = false;
 	if (h->layout == CA3D_LAYOUT_UNPACKED)
@@ -496,27 +525,23 @@ int ca3d_step(ca3d_t *h, uint32_t n_steps)
 	HIP_TRY(hipEventRecord(h->ev_start, h->stream));
 	uint32_t left = n_steps;
 	uint64_t launches = 0;
-	// Graph replays are captured from buffer 0; take one single step first if the state sits in buffer 1.
 	while (left)
 	{
-		if (h->use_graph && h->stream != nullptr && h->cur == 0 && left >= kGraphSteps[1])
+		uint32_t n = left > kMaxGraphSteps ? kMaxGraphSteps : left;
+		if (!graphs_allowed(h) && h->use_graph && h->stream != nullptr) n = 1; // non-binary unpacked state: one literal step, then graphs
+		if (graphs_allowed(h) && n >= h->graph_min)
 		{
-			const int which = left >= kGraphSteps[0] ? 0 : 1;
-			if (!h->graph_exec[which])
-			{
-				rc = build_graph(h, which);
-				if (rc) return rc;
-			}
-			HIP_TRY(hipGraphLaunch(h->graph_exec[which], h->stream));
-			h->step += kGraphSteps[which]; // even: the buffer index is unchanged
-			left -= kGraphSteps[which];
-			launches += h->graph_launches[which];
-			continue;
+			ca3d_engine::StepGraph *g = nullptr;
+			rc = step_graph(h, n, h->cur, &g);
+			if (rc) return rc;
+			HIP_TRY(hipGraphLaunch(g->exec, h->stream));
+			launches += g->launches;
 		}
-		uint32_t n = left;
-		if (h->use_graph && h->stream != nullptr && left >= kGraphSteps[1]) n = 1; // h->cur == 1: re-align for the graph
-		rc = enqueue_batch(h, n, h->cur, h->stream, &launches);
-		if (rc) return rc;
+		else
+		{
+			rc = enqueue_batch(h, n, h->cur, h->stream, &launches);
+			if (rc) return rc;
+		}
 		h->step += n;
 		h->cur = (h->cur + n) & 1u;
 		left -= n;
@@ -725,6 +750,19 @@ int ca3d_get_info(ca3d_t *h, ca3d_info *out)
 	return CA3D_OK;
 }
 
+int ca3d_get_jit_log(ca3d_t *h, char *buf, size_t n_bytes, size_t *needed)
+{
+	if (!h) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL engine handle");
+	if (needed) *needed = h->jit_log.size() + 1;
+	if (buf && n_bytes)
+	{
+		const size_t n = h->jit_log.size() < n_bytes - 1 ? h->jit_log.size() : n_bytes - 1;
+		memcpy(buf, h->jit_log.data(), n);
+		buf[n] = '\0';
+	}
+	return CA3D_OK;
+}
+
 int ca3d_get_stats(ca3d_t *h, ca3d_stats *out)
 {
 	if (!h || !out) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL argument");
@@ -850,13 +888,32 @@ int ca3d_set_option(ca3d_t *h, const char *name, int64_t value)
 		if (rc) return rc;
 		rc = bind_device(h);
 		if (rc) return rc;
-		if (!h->use_graph || h->stream == nullptr || h->slab) return CA3D_OK;
-		for (int which = 0; which < 2; which++)
-			if ((uint64_t)value >= kGraphSteps[which] && !h->graph_exec[which])
+		if (!graphs_allowed(h) || h->slab || value <= 0) return CA3D_OK;
+		// the batches ca3d_step(value) will replay, from either buffer (an odd batch length alternates)
+		uint64_t left = (uint64_t)value;
+		uint32_t cur = h->cur;
+		for (int pass = 0; pass < 2; pass++)
+		{
+			for (uint64_t l = left; l;)
 			{
-				rc = build_graph(h, which);
-				if (rc) return rc;
+				const uint32_t n = l > kMaxGraphSteps ? kMaxGraphSteps : (uint32_t)l;
+				if (n >= h->graph_min)
+				{
+					ca3d_engine::StepGraph *g = nullptr;
+					rc = step_graph(h, n, cur, &g);
+					if (rc) return rc;
+				}
+				cur = (cur + n) & 1u;
+				l -= n;
 			}
+			if (cur == h->cur) break; // even total: the next call starts from the same buffer
+		}
+		return CA3D_OK;
+	}
+	if (!strcmp(name, "graph_min"))
+	{
+		if (value < 1 || value > kMaxGraphSteps) return fail(CA3D_ERR_INVALID_ARGUMENT, "graph_min must be in [1, %u]", kMaxGraphSteps);
+		h->graph_min = (uint32_t)value;
 		return CA3D_OK;
 	}
 	if (!strcmp(name, "render_sched")) { h->render_sched = value ? 1 : 0; return CA3D_OK; }
@@ -898,6 +955,7 @@ int ca3d_set_option(ca3d_t *h, const char *name, int64_t value)
 		drop_graph(h);
 		h->variant = (int)value;
 		refresh_kernels(h);
+		note_jit_failure(h);
 		return CA3D_OK;
 	}
 	if (!strcmp(name, "jit"))
@@ -905,6 +963,7 @@ int ca3d_set_option(ca3d_t *h, const char *name, int64_t value)
 		drop_graph(h);
 		h->use_jit = value ? 1 : 0;
 		refresh_kernels(h);
+		note_jit_failure(h);
 		return CA3D_OK;
 	}
 	return fail(CA3D_ERR_INVALID_ARGUMENT, "unknown option '%s'", name);

@@ -11,6 +11,8 @@
 // with one __ballot per 64 cells — the loads are plain coalesced dwords —, updates it with the same bit-sliced
 // adders and rule programs as the packed kernel, and expands the result back to one u32 per cell on the way
 // out. HBM sees each cell ~1.2 times in and once out instead of 7-27 cached re-reads per cell.
+#include <mutex>
+
 #include "ca3d_internal.h"
 
 namespace ca3d
@@ -208,12 +210,21 @@ hipError_t launch_ballot_fz(const UnpackedLaunch &l, hipStream_t stream, const P
 	auto kern = ca_unpacked_ballot<MAIN, FAST, kBTZ>;
 	u32 cv_shift = 0;
 	while ((1u << cv_shift) < C / 4u) cv_shift++;
-	static bool attr_set = false;
-	if (!attr_set)
+	// the opt-in to > 64 KiB of dynamic LDS belongs to the function object of the CURRENT device: once per (device,
+	// instantiation), under a lock (engines on different devices / threads share this code)
+	static std::mutex attr_mutex;
+	static uint64_t attr_devices = 0; // bit d: set on device d
 	{
-		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+		int dev = 0;
+		hipError_t e = hipGetDevice(&dev);
 		if (e != hipSuccess) return e;
-		attr_set = true;
+		std::lock_guard<std::mutex> lock(attr_mutex);
+		if (dev < 0 || dev >= 64 || !(attr_devices >> dev & 1u))
+		{
+			e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+			if (e != hipSuccess) return e;
+			if (dev >= 0 && dev < 64) attr_devices |= 1ull << dev;
+		}
 	}
 	hipLaunchKernelGGL(kern, dim3(ny * nz), dim3(kBThreads), lds_bytes, stream, l.in, l.out, l.pr, ny, cv_shift, prog);
 	return hipGetLastError();

@@ -186,6 +186,15 @@ class Engine:
         _capi.check(self._lib.ca3d_get_info(self._h, C.byref(i)))
         return i
 
+    def jit_log(self) -> str:
+        """Compiler log of the last failed run-time specialisation ('' when none failed): the pre-built kernels are
+        then in charge and `info().kernel_name` carries no '(jit)'."""
+        need = C.c_size_t()
+        _capi.check(self._lib.ca3d_get_jit_log(self._h, None, 0, C.byref(need)))
+        buf = C.create_string_buffer(max(1, need.value))
+        _capi.check(self._lib.ca3d_get_jit_log(self._h, buf, len(buf), None))
+        return buf.value.decode("utf-8", "replace")
+
     def stats(self) -> Stats:
         s = Stats()
         _capi.check(self._lib.ca3d_get_stats(self._h, C.byref(s)))

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define CA3D_ABI_VERSION 1
+#define CA3D_ABI_VERSION 2
 #define CA3D_LUT_LEN 81 /* 3 rule-sets x 27 slots (main_pathtraced.js:10, 155-159) */
 
 typedef struct ca3d_engine ca3d_t;
@@ -155,6 +155,16 @@ typedef struct ca3d_info
 } ca3d_info;
 int ca3d_get_info(ca3d_t *h, ca3d_info *out);
 
+/*
+ * createShaderModule / createComputePipeline (main_pathtraced.js:1421-1433) report compile problems through the
+ * browser console; here the step kernel is specialised for the rule at run time inside ca3d_set_rules /
+ * ca3d_configure (option "jit"), and a failed compile does NOT fail those calls — the pre-built kernels take over,
+ * ca3d_get_info().kernel_name lacks its "(jit)" suffix, ca3d_last_error() holds the message right after the call and
+ * this getter returns the compiler log of the most recent attempt (empty string: no failure). `needed` (nullable)
+ * receives the size including the terminator; the text is truncated to n_bytes.
+ */
+int ca3d_get_jit_log(ca3d_t *h, char *buf, size_t n_bytes, size_t *needed);
+
 typedef struct ca3d_stats
 {
 	uint64_t steps;          /* steps in the last ca3d_step / ca3d_slab_step batch */
@@ -197,10 +207,12 @@ typedef struct ca3d_render_stats
 int ca3d_get_render_stats(ca3d_t *h, ca3d_render_stats *out);
 
 /* Options (not part of the reference surface): "graph" 0/1 hipGraph batching; "graph_prepare" n builds now the
- * graphs a later ca3d_step(n) replays (otherwise built on first use); "fused" 0/1 two-step fused kernel
+ * graphs a later ca3d_step(n) replays — a batch of any length up to 1024 steps is one graph of exactly that many
+ * steps (otherwise built on first use); "fused" 0/1 two-step fused kernel
  * (bit-exact, off by default); "variant" 1 forces the generic / literal kernels; "jit" 0/1 run-time (hiprtc) specialisation of the step
  * kernel for the current rule, compiled inside ca3d_set_rules / ca3d_configure (on by default; a failed compile
- * silently keeps the pre-built kernels); "render_mode" 0/1; "render_row_begin" / "render_row_end":
+ * keeps the pre-built kernels and is reported through ca3d_get_jit_log); "graph_min" n: batches shorter than n
+ * steps are launched kernel by kernel instead of as a captured graph; "render_mode" 0/1; "render_row_begin" / "render_row_end":
  * ca3d_render then fills image rows [begin, end) only (begin a multiple of 16; 0 / 0 = the whole frame) — a rank's
  * band when the GPUs of a node share one frame; "render_skip" 0/1 empty-space skipping by
  * 32x8x8-cell occupancy blocks, active on sparse volumes only (on by default; within the renderer's tolerance of

@@ -278,18 +278,74 @@ def test_1024_cubed_one_step(eng):
     np.testing.assert_array_equal(eng.read_state(), ol.packed_step(G, st, r))
 
 
-def test_2048_cubed_two_steps(eng):
-    """BASELINE config 5's grid (1 GiB per buffer, offsets past 2^32 bits): two steps of the default rule, whole state
+@pytest.mark.parametrize("name", ["default", "clustered"])
+def test_2048_cubed_two_steps(eng, name):
+    """BASELINE config 5's grid (1 GiB per buffer, offsets past 2^32 bits) under the default rule and under config 5's
+    own clustered rule-set (all three rule-sets of compute_clustered.wgsl:192-247 live): two steps, whole state
     compared with the oracle."""
     G = 2048
-    r = rules("default")
+    r = rules(name)
     eng.configure(G)
     set_rules(eng, r)
     st = host.random_fill(host.words_per_buffer(G), seed=7)
     eng.upload_state(st)
     eng.step(2)
+    assert "(jit)" in eng.info().kernel_name.decode() or name == "default"
     np.testing.assert_array_equal(eng.read_state(), ol.packed_run(G, st, r, 2))
     eng.configure(32)  # release the 2 GiB before the next test
+
+
+def test_batches_of_any_length_replay_as_graphs(eng):
+    """A batch of n < 1024 steps is one captured graph of exactly n steps, cached per (n, start buffer): odd lengths
+    alternate between the two buffers; short batches (< graph_min) are launched kernel by kernel."""
+    G = 128
+    r = rules("vn_b24_s135")
+    eng.configure(G)
+    set_rules(eng, r)
+    st = host.random_fill(host.words_per_buffer(G), seed=22)
+    eng.upload_state(st)
+    eng.set_option("graph_prepare", 21)
+    total = 0
+    for n in (21, 21, 3, 20, 21, 1, 37):
+        eng.step(n)
+        total += n
+        assert eng.info().current_buffer == total % 2
+    np.testing.assert_array_equal(eng.read_state(), ol.packed_run(G, st, r, total))
+    eng.set_option("graph_min", 2)
+    eng.upload_state(st)
+    for n in (2, 3, 5):
+        eng.step(n)
+    np.testing.assert_array_equal(eng.read_state(), ol.packed_run(G, st, r, 10))
+    eng.set_option("graph_min", 8)
+
+
+def test_jit_failure_is_reported_and_falls_back(monkeypatch):
+    """A failed run-time specialisation must not fail ca3d_set_rules, and must not be silent: the pre-built kernel is
+    selected (no "(jit)" in the kernel name), ca3d_last_error / ca3d_get_jit_log carry the compiler's message, and the
+    step is still bit-exact."""
+    from cellularautomatons3d_amd import Engine, _capi
+
+    G = 128
+    st = host.random_fill(host.words_per_buffer(G), seed=23)
+    monkeypatch.setenv("CA3D_JIT_FLAGS", "-DCA3D_JIT_MAIN=this_is_not_a_main_kind -DCA3D_TEST_BREAK=1")
+    with Engine(0) as e:
+        e.configure(G)
+        r2 = ol.Rules.from_strings("moore", "4,9", "4,11")  # tables unique to this test: not in the module cache
+        e.set_rules(r2.main, r2.edges, r2.corners, r2.survive, r2.born)  # returns normally
+        assert "(jit)" not in e.info().kernel_name.decode()
+        msg = _capi.load().ca3d_last_error().decode()
+        assert "specialisation failed" in msg and "hiprtc" in msg
+        log = e.jit_log()
+        assert "error" in log.lower() and len(log) > 20
+        e.upload_state(st)
+        e.step(2)
+        np.testing.assert_array_equal(e.read_state(), ol.packed_run(G, st, r2, 2))
+        monkeypatch.delenv("CA3D_JIT_FLAGS")
+        e.set_rules(r2.main, r2.edges, r2.corners, r2.survive, r2.born)
+        assert "(jit)" in e.info().kernel_name.decode() and e.jit_log() == ""
+        e.upload_state(st)
+        e.step(2)
+        np.testing.assert_array_equal(e.read_state(), ol.packed_run(G, st, r2, 2))
 
 
 def test_large_graph_replay_1024_steps(eng):

@@ -144,6 +144,40 @@ def test_full_hd_band_at_512(eng):
     _compare(eng, cells, G, host.uniform_block(W, H, host.orbit_camera()), W, H, 4, rows=(520, 544))
 
 
+def test_4k_band_at_512(eng):
+    # BASELINE config 5's render leg: 3840x2160 @ 4 spp (fragment_main, pathtraced_fragment_clustered.wgsl:800-890,
+    # once per pixel of a 4K target); the oracle renders a 16-row band through the middle of the volume's silhouette.
+    G, W, H = 512, 3840, 2160
+    cells = host.random_fill(host.words_per_buffer(G), seed=0xCA3D0001, and_rounds=4)
+    _compare(eng, cells, G, host.uniform_block(W, H, host.orbit_camera()), W, H, 4, rows=(1040, 1056))
+
+
+def test_4k_band_on_the_evolved_2048_grid(eng):
+    # config 5 as a whole: the 2048^3 grid under the clustered rule-set, then the 4K frame of that state (1 spp band
+    # against the oracle; the oracle steps the same state on the CPU)
+    G, W, H = 2048, 3840, 2160
+    r = rules("clustered")
+    st = host.random_fill(host.words_per_buffer(G), seed=11, and_rounds=2)
+    want = ol.packed_run(G, st, r, 1)
+    eng.configure(G)
+    set_rules(eng, r)
+    eng.upload_state(st)
+    eng.step(1)
+    assert np.array_equal(eng.read_state(), want)
+    u = host.uniform_block(W, H, host.orbit_camera())
+    pres, light, depth = eng.render(u, W, H, 1, rows=(1072, 1088))
+    olight, odepth, opres, _ = ol.render(want, G, u, W, H, 1, (1072, 1088))
+    sl = slice(1072, 1088)
+    ok = (np.abs(light[sl].astype(np.float32)[..., :3] - olight[sl][..., :3]).max(-1) <= 2e-3)
+    od16 = odepth[sl].astype(np.float16).astype(np.float32)
+    ulp = np.maximum(np.spacing(od16.astype(np.float16)).astype(np.float32), 1e-4)
+    ok &= np.abs(depth[sl].astype(np.float32)[..., 0] - od16[..., 0]) <= ulp[..., 0]
+    ok &= np.abs(pres[sl].astype(np.float32) - np.rint(np.clip(opres[sl], 0, 1) * 255.0)).max(-1) <= 1.0
+    assert ok.mean() >= 0.999, ok.mean()
+    assert olight[sl][..., :3].max() > 0.05
+    eng.configure(32)  # release the 2 GiB
+
+
 def test_row_bands_stitch_into_the_full_frame(eng):
     """A frame shared between GPUs is rendered in bands of image rows: the bands of one engine, stitched,
     are the full frame bit for bit; rows outside a band are left untouched."""

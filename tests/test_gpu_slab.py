@@ -129,6 +129,24 @@ def test_unpacked_slabs_overlapped_schedule():
     np.testing.assert_array_equal(got, cur)
 
 
+@pytest.mark.parametrize("G,P,K,steps,name,overlapped", [
+    (1024, 8, 1, 3, "default", False),      # BASELINE configs[3]: 1024^3 over 8 slabs, one-voxel halo every step
+    (1024, 8, 16, 33, "default", False),    # the deep-halo schedule the bench runs (exchange every K steps)
+    (1024, 8, 16, 18, "clustered", True),   # class kernels, two-range edge launches + interior
+    (2048, 8, 8, 9, "clustered", True),     # BASELINE configs[4]: 2048^3 clustered, halo overlapped with compute
+])
+def test_packed_slabs_at_the_baseline_widths(G, P, K, steps, name, overlapped):
+    """Slab mode at the grid widths BASELINE's multi-GPU configurations name: the slab kernels (`ca_packed_vn<3|4, ..>`,
+    the class kernels' two-range launches) on 1024- and 2048-wide planes, P = 8 slabs on one GPU with device copies
+    following the product halo plan, against the oracle's full-grid run."""
+    r = rules(name)
+    full = host.random_fill(host.words_per_buffer(G), seed=1000 + G + K)
+    run = _run_slabs_overlapped if overlapped else _run_slabs
+    got = run(G, P, K, steps, r, LAYOUT_PACKED32, full)
+    want = ol.packed_run(G, full, r, steps)
+    assert np.array_equal(got, want)  # (assert_array_equal would format 1 GiB arrays on failure)
+
+
 @pytest.mark.parametrize("overlap", [True, False])
 def test_slab_engine_over_rccl_loopback(overlap):
     """The product's exchange through the real transport on one GPU: a one-rank RCCL group, the wrap message (rank
@@ -294,7 +312,7 @@ def test_bench_two_ranks_on_one_gpu_gloo_rehearsal(overlap):
     s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "21", "--warmup", "5",
-           "--grid", "256", "--ghost", "4", "--backend", "gloo", "--device-map", "0,0", "--check", "--no-cpu-baseline", "--overlap", overlap,
+           "--grid", "256", "--ghost", "4", "--backend", "gloo", "--device-map", "0,0", "--check", "--no-cpu-baseline", "--overlap", overlap, "--min-seconds", "0",
            "--multi-render", "--render-size", "640x360", "--render-frames", "2"]
     r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
@@ -303,3 +321,24 @@ def test_bench_two_ranks_on_one_gpu_gloo_rehearsal(overlap):
     assert d["n_gpus"] == 2 and d["oracle_match"] is True and d["scaling"] == "strong"
     assert d["render"]["frame_match"] is True and d["render"]["value"] > 0  # the two ranks' bands == one GPU's frame
     assert d["roofline"]["kernel"].startswith("ca_packed_vn")
+
+
+def test_bench_plain_invocation_spawns_its_ranks():
+    """`python bench.py --gpus 2 ...` with no launcher around it: the parent starts the two ranks itself (before it has
+    touched the GPU) and rank 0's JSON line is the only stdout; same rehearsal set-up as above (gloo, both ranks on
+    GPU 0), final state checked against the oracle."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "9", "--warmup", "3", "--grid", "256", "--ghost", "4",
+           "--backend", "gloo", "--device-map", "0,0", "--check", "--no-cpu-baseline", "--min-seconds", "0"]
+    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["oracle_match"] is True and d["reps"] == 1 and d["config"]["grid"] == 256

@@ -90,3 +90,25 @@ def test_non_binary_upload_takes_the_literal_kernel_first():
         assert e.info().kernel_name == b"ca_unpacked_ballot"  # every cell is 0 / 1 after a step
         s3 = ol.unpacked_step(G, ol.unpacked_step(G, s1, r.main, r.survive, r.born), r.main, r.survive, r.born)
         np.testing.assert_array_equal(e.read_state(), s3)
+
+
+def test_graph_replay_after_a_non_binary_upload():
+    """A captured graph must never replay the 0/1-only ballot kernel on a state with cell values > 1: binary upload,
+    a graph-sized batch, then an upload with values > 1 and the same batch again (compute.wgsl:160-174 sums raw u32
+    values and tests `== 1` / `== 0`)."""
+    from cellularautomatons3d_amd import Engine
+
+    G, n = 128, 64
+    r = ol.Rules.from_strings("von neumann", "1,3", "0-6")
+    a = (host.random_fill(G ** 3, seed=41) & 1).astype(np.uint32)
+    b = (host.random_fill(G ** 3, seed=42) % 4).astype(np.uint32)  # values 0..3
+    with Engine(0) as e:
+        e.configure(G, LAYOUT_UNPACKED)
+        e.set_rules(r.main, r.edges, r.corners, r.survive, r.born)
+        for st in (a, b, a):
+            e.upload_state(st)
+            e.step(n)
+            cur = st
+            for _ in range(n):
+                cur = ol.unpacked_step(G, cur, r.main, r.survive, r.born)
+            np.testing.assert_array_equal(e.read_state(), cur)

@@ -334,6 +334,7 @@ def single_gpu_leg(device, G, rule, steps, warmup, min_seconds, density_rounds=0
     eng.upload_state(full)
     stream = torch.cuda.Stream(device=device)  # the engine runs on a torch-visible stream so torch events bracket its work
     eng.set_stream(stream.cuda_stream)
+    eng.set_option("stats", 0)  # no per-call event pair inside the timed region: the events below bracket all of it
     eng.set_option("graph_prepare", steps)  # graph capture / instantiation stays out of the timed region
     if warmup:
         eng.set_option("graph_prepare", warmup)
@@ -349,7 +350,7 @@ def roofline_block(kernel, G, bytes_per_launch, launches, ev_ms, state_bytes):
     launch_ms = ev_ms / max(1, launches)
     achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
     traffic = pmc_traffic(kernel, G)
-    fits = 2 * state_bytes <= INFINITY_CACHE_BYTES
+    fits = 2 * state_bytes < INFINITY_CACHE_BYTES
     return {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "traffic_source": None if traffic is None else "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
@@ -367,6 +368,11 @@ def main():
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     if a.gpus > 1 and world_env == 1 and "RANK" not in os.environ:
         raise SystemExit(spawn_ranks(a))
+    # stdout carries the JSON line and nothing else: libraries that print there (gloo's connection banner ...) are sent
+    # to stderr from here on
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
@@ -489,7 +495,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(min(G, 512), rule_kw, a.cpu_seconds)
             out["cpu_baseline_js"] = cpu_baseline_js()
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -71,12 +71,19 @@ struct ca3d_engine
 	// change of rules, kernels, stream or buffers
 	struct StepGraph { hipGraphExec_t exec = nullptr; uint32_t launches = 0; };
 	std::map<uint64_t, StepGraph> step_graphs;
-	uint32_t graph_min = 8; // shorter batches are launched kernel by kernel
+	// Shorter batches are launched kernel by kernel: measured at 512^3 (tools/step_gap.py) back-to-back 20-step batches
+	// run 6.48 us per step as graphs and 6.13 launched one by one, 64-step batches 5.96 / 5.85, 256-step batches 5.78 / 5.76
+	// — a graph launch has a start-up and a completion cost of its own, worth paying once the host would fall behind.
+	uint32_t graph_min = 128;
+	int want_stats = 1; // record the event pair ca3d_get_stats reads (a marker packet each: costs ~1 us of GPU idle per call)
 	std::map<uint64_t, hipGraphExec_t> slab_graphs; // (phase, start buffer, sub-steps) -> captured slab batch
 	uint32_t pending_edges = 0;                     // sub-steps of an edge phase awaiting its interior phase
+	int roll_z = 0;       // forced planes per thread of the rolling-window kernel (0: automatic)
+	int use_roll = 1;     // rolling-window form of the class kernels where it applies (needs use_jit)
 	int use_jit = 1;      // specialise kernels for the rule at run time (hiprtc) where a specialisation exists
 	VnJit vn_jit;         // valid when vn_jit.cvl >= 0
 	ClassJit class_jit;   // valid when class_jit.main >= 0
+	RollJit roll_jit;     // valid when roll_jit.cvl >= 0
 	std::string jit_log;  // why the last specialisation attempt failed (empty: none failed)
 
 	ca3d_stats stats{};
@@ -182,7 +189,7 @@ int enqueue_step(ca3d_engine *h, int src, uint32_t lo, uint32_t hi, hipStream_t 
 	{
 		pr.lo2 = lo2;
 		pr.hi2 = hi2;
-		PackedLaunch l{h->buf[src], h->buf[src ^ 1], pr, &h->rules, h->variant, h->vn_jit.cvl >= 0 ? &h->vn_jit : nullptr, h->class_jit.main >= 0 ? &h->class_jit : nullptr};
+		PackedLaunch l{h->buf[src], h->buf[src ^ 1], pr, &h->rules, h->variant, h->vn_jit.cvl >= 0 ? &h->vn_jit : nullptr, h->class_jit.main >= 0 ? &h->class_jit : nullptr, h->roll_jit.cvl >= 0 ? &h->roll_jit : nullptr, h->roll_z};
 		e = fused ? launch_packed_fused(l, s, &h->kernel_name) : launch_packed_step(l, s, &h->kernel_name);
 	}
 	else
@@ -208,6 +215,7 @@ void refresh_kernels(ca3d_engine *h)
 {
 	h->vn_jit = VnJit{};
 	h->class_jit = ClassJit{};
+	h->roll_jit = RollJit{};
 	h->jit_log.clear();
 	if (!h->configured || !h->rules.valid) return;
 	if (h->layout != CA3D_LAYOUT_PACKED32) { h->kernel_name = "ca_unpacked_literal"; return; }
@@ -221,6 +229,12 @@ void refresh_kernels(ca3d_engine *h)
 		if (hipSetDevice(h->device) != hipSuccess) return;
 		ClassJit cj;
 		if (jit_class_kernels(h->device, h->rules, &cj, &h->jit_log) == CA3D_OK) h->class_jit = cj;
+		else return;
+		if (h->use_roll && roll_kernel_applies(h->rules, h->G, h->variant))
+		{
+			RollJit rj;
+			if (jit_roll_kernels(h->device, h->rules, vn_grid_log2(h->G), &rj, &h->jit_log) == CA3D_OK) h->roll_jit = rj;
+		}
 		return;
 	}
 	uint32_t ls = 0, lb = 0;
@@ -522,7 +536,7 @@ int ca3d_step(ca3d_t *h, uint32_t n_steps)
 	rc = bind_device(h);
 	if (rc) return rc;
 	if (n_steps == 0) return CA3D_OK;
-	HIP_TRY(hipEventRecord(h->ev_start, h->stream));
+	if (h->want_stats) HIP_TRY(hipEventRecord(h->ev_start, h->stream));
 	uint32_t left = n_steps;
 	uint64_t launches = 0;
 	while (left)
@@ -546,8 +560,8 @@ int ca3d_step(ca3d_t *h, uint32_t n_steps)
 		h->cur = (h->cur + n) & 1u;
 		left -= n;
 	}
-	HIP_TRY(hipEventRecord(h->ev_stop, h->stream));
-	h->ev_valid = true;
+	if (h->want_stats) HIP_TRY(hipEventRecord(h->ev_stop, h->stream));
+	h->ev_valid = h->want_stats != 0;
 	h->stats.steps = n_steps;
 	h->stats.kernel_launches = launches;
 	h->stats.cell_steps = (double)n_steps * h->cells_per_plane() * h->G;
@@ -746,7 +760,10 @@ int ca3d_get_info(ca3d_t *h, ca3d_info *out)
 	}
 	const bool class_jit = h->configured && h->rules.valid && h->layout == CA3D_LAYOUT_PACKED32 && h->class_jit.main >= 0 &&
 	                       !(h->use_fused && !h->slab && packed_fused_steps(h->rules, h->G, h->variant) == 2);
-	snprintf(out->kernel_name, sizeof out->kernel_name, "%s%s", name, class_jit ? "(jit)" : "");
+	if (class_jit && h->roll_jit.cvl >= 0 && !strncmp(name, "ca_packed_class", 15))
+		snprintf(out->kernel_name, sizeof out->kernel_name, "ca_packed_class_roll%s(jit)", name + 15); // rolling-window form
+	else
+		snprintf(out->kernel_name, sizeof out->kernel_name, "%s%s", name, class_jit ? "(jit)" : "");
 	return CA3D_OK;
 }
 
@@ -766,7 +783,7 @@ int ca3d_get_jit_log(ca3d_t *h, char *buf, size_t n_bytes, size_t *needed)
 int ca3d_get_stats(ca3d_t *h, ca3d_stats *out)
 {
 	if (!h || !out) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL argument");
-	if (!h->ev_valid) return fail(CA3D_ERR_NOT_CONFIGURED, "no step batch has been issued yet");
+	if (!h->ev_valid) return fail(CA3D_ERR_NOT_CONFIGURED, "no step batch has been timed yet (or option \"stats\" is 0)");
 	int rc = bind_device(h);
 	if (rc) return rc;
 	HIP_TRY(hipEventSynchronize(h->ev_stop));
@@ -910,6 +927,7 @@ int ca3d_set_option(ca3d_t *h, const char *name, int64_t value)
 		}
 		return CA3D_OK;
 	}
+	if (!strcmp(name, "stats")) { h->want_stats = value ? 1 : 0; if (!value) h->ev_valid = false; return CA3D_OK; }
 	if (!strcmp(name, "graph_min"))
 	{
 		if (value < 1 || value > kMaxGraphSteps) return fail(CA3D_ERR_INVALID_ARGUMENT, "graph_min must be in [1, %u]", kMaxGraphSteps);
@@ -954,6 +972,21 @@ int ca3d_set_option(ca3d_t *h, const char *name, int64_t value)
 		if (value != 0 && value != 1) return fail(CA3D_ERR_INVALID_ARGUMENT, "variant must be 0 (auto) or 1 (generic kernel)");
 		drop_graph(h);
 		h->variant = (int)value;
+		refresh_kernels(h);
+		note_jit_failure(h);
+		return CA3D_OK;
+	}
+	if (!strcmp(name, "roll_z"))
+	{
+		if (value != 0 && value != 2 && value != 4 && value != 8) return fail(CA3D_ERR_INVALID_ARGUMENT, "roll_z must be 0 (automatic), 2, 4 or 8");
+		drop_graph(h);
+		h->roll_z = (int)value;
+		return CA3D_OK;
+	}
+	if (!strcmp(name, "roll"))
+	{
+		drop_graph(h);
+		h->use_roll = value ? 1 : 0;
 		refresh_kernels(h);
 		note_jit_failure(h);
 		return CA3D_OK;

@@ -65,6 +65,17 @@ struct ClassJit
 	uint32_t tables[6] = {0, 0, 0, 0, 0, 0}; // survive / born of main, edges, corners (bit k = value at count k)
 };
 
+// Run-time compiled rolling-window class kernels (ca_packed_roll_kernel.inc) for one (grid, main table, live rule-sets,
+// rule): entry points with 2, 4 and 8 output planes per thread
+struct RollJit
+{
+	void *z[3] = {nullptr, nullptr, nullptr}; // hipFunction_t for Z = 2, 4, 8
+	int cvl = -1;                              // log2(G / 128); -1: none
+	int main = -1;
+	bool e = false, c = false;
+	uint32_t tables[6] = {0, 0, 0, 0, 0, 0};
+};
+
 struct PackedLaunch
 {
 	const uint32_t *in;
@@ -74,6 +85,8 @@ struct PackedLaunch
 	int variant; // -1 auto
 	const VnJit *vn_jit = nullptr; // specialised kernels for exactly these rules and this grid, or null
 	const ClassJit *class_jit = nullptr;
+	const RollJit *roll_jit = nullptr;
+	int roll_z = 0; // 0: the launcher picks the planes per thread of the rolling-window kernel; 2 / 4 / 8: forced (tests, tuning)
 };
 
 struct UnpackedLaunch
@@ -125,6 +138,10 @@ void class_tables(const CanonRules &r, uint32_t tables[6]);
 int class_zrun(const CanonRules &r); // planes per thread of the deep variant for these rules
 bool use_class_kernel(const CanonRules &r, uint32_t G, int variant);
 int jit_class_kernels(int device, const CanonRules &r, ClassJit *out, std::string *log);
+int jit_roll_kernels(int device, const CanonRules &r, int cvl, RollJit *out, std::string *log);
+// Whether the rolling-window kernel is the one to use for these rules on this grid (diagonal neighbour classes in
+// play, power-of-two grid of 256 and up)
+bool roll_kernel_applies(const CanonRules &r, uint32_t G, int variant);
 // Steps one fused launch advances for these rules / grid (0 = no fused kernel applies).
 int packed_fused_steps(const CanonRules &r, uint32_t G, int variant);
 hipError_t launch_packed_fused(const PackedLaunch &l, hipStream_t stream, const char **kernel_name);

@@ -26,6 +26,14 @@ namespace
 
 #include "ca_packed_class_kernel.inc"
 
+// launch arguments of the run-time compiled rolling-window kernels (device code: ca_packed_roll_kernel.inc)
+struct RollArgs
+{
+	u32 lo, hi, nplanes, wrap_full;
+	u32 lo2, hi2, runs1;
+	int zbase;
+};
+
 // ---------------------------------------------------------------------------------------------- fused kernel
 // Two CA steps per launch (temporal blocking) with NO shared memory and NO barriers: every wavefront is an
 // independent worker. A wave owns a strip of ROWS = 64 / LPR consecutive rows x the full x extent (LPR lanes per
@@ -344,6 +352,27 @@ hipError_t launch_class(const PackedLaunch &l, hipStream_t stream)
 	const dim3 grid_deep(g.tiles_per_plane * runs), grid_flat(g.tiles_per_plane * runs);
 #define CA3D_LAUNCH_CLASS(ZR_, FAST_, P2_, GRID_) \
 	hipLaunchKernelGGL((ca_packed_class<MAIN, E, C_, ZR_, FAST_, P2_>), GRID_, dim3(256), 0, stream, l.in, l.out, l.pr, g, l.rules->prog)
+	if (const RollJit *rj = l.roll_jit; p2 && rj && rj->cvl == g.cv_shift && rj->main == MAIN && rj->e == E && rj->c == C_)
+	{
+		// The rolling-window kernel for exactly these rules and this grid (ca_packed_roll_kernel.inc). Z planes per
+		// thread: the largest of 8 / 4 / 2 that the shortest range holds and that still gives every SIMD its two waves
+		// (a wave alone on a SIMD issues at half rate); launches too small for that keep the one-plane kernels below.
+		static const u32 lds_pad = getenv("CA3D_ROLL_LDS") ? (u32)atoi(getenv("CA3D_ROLL_LDS")) : 0u;
+		for (int zi = 2; zi >= 0; zi--)
+		{
+			const u32 Z = 2u << zi;
+			const u32 runs1 = (planes1 + Z - 1u) / Z, nruns = runs1 + (planes2 + Z - 1u) / Z;
+			if (shortest < Z || !rj->z[zi]) continue;
+			if (l.roll_z ? l.roll_z != (int)Z : (size_t)g.tiles_per_plane * nruns * 4u < 2048u) continue;
+			RollArgs a;
+			a.lo = l.pr.lo; a.hi = l.pr.hi; a.nplanes = l.pr.nplanes; a.wrap_full = l.pr.wrap_full; a.zbase = l.pr.zbase;
+			a.lo2 = l.pr.lo2; a.hi2 = two ? l.pr.hi2 : l.pr.lo2; a.runs1 = runs1;
+			const u32 *in = l.in;
+			u32 *out = l.out;
+			void *args[] = {(void *)&in, (void *)&out, (void *)&a};
+			return hipModuleLaunchKernel((hipFunction_t)rj->z[zi], g.tiles_per_plane * nruns, 1, 1, 256, 1, 1, lds_pad, stream, args, nullptr);
+		}
+	}
 	const ClassJit *jit = l.class_jit;
 	if (p2 && jit && jit->main == MAIN && jit->e == E && jit->c == C_ && jit->deep && jit->deep_za && jit->flat)
 	{
@@ -390,6 +419,16 @@ hipError_t launch_class_ec(const PackedLaunch &l, hipStream_t stream)
 }
 
 } // namespace
+
+bool roll_kernel_applies(const CanonRules &r, uint32_t G, int variant)
+{
+	if (!use_class_kernel(r, G, variant) || vn_kernel_applies(r, G, variant)) return false;
+	const uint32_t cv = G / 128u;
+	if (G % 128u || (cv & (cv - 1u)) || cv < 2u || cv > 64u) return false; // power-of-two rows of 2 .. 64 uint4: a row sits inside one wave
+	// rules whose counts come from the thread's own plane only gain nothing from a z window
+	const bool diagonals_or_z = r.need[1] || r.need[2] || r.main == MAIN_MOORE || r.main == MAIN_EDGES || r.main == MAIN_CORNERS || r.main == MAIN_VN;
+	return diagonals_or_z;
+}
 
 int class_zrun(const CanonRules &r)
 {

@@ -206,12 +206,15 @@ typedef struct ca3d_render_stats
 } ca3d_render_stats;
 int ca3d_get_render_stats(ca3d_t *h, ca3d_render_stats *out);
 
-/* Options (not part of the reference surface): "graph" 0/1 hipGraph batching; "graph_prepare" n builds now the
+/* Options (not part of the reference surface): "graph" 0/1 hipGraph batching; "stats" 0/1: record the event pair
+ * ca3d_get_stats reads around every ca3d_step batch (on by default; a host that steps in small batches and never asks
+ * for stats saves two marker packets per call); "graph_prepare" n builds now the
  * graphs a later ca3d_step(n) replays — a batch of any length up to 1024 steps is one graph of exactly that many
  * steps (otherwise built on first use); "fused" 0/1 two-step fused kernel
  * (bit-exact, off by default); "variant" 1 forces the generic / literal kernels; "jit" 0/1 run-time (hiprtc) specialisation of the step
  * kernel for the current rule, compiled inside ca3d_set_rules / ca3d_configure (on by default; a failed compile
- * keeps the pre-built kernels and is reported through ca3d_get_jit_log); "graph_min" n: batches shorter than n
+ * keeps the pre-built kernels and is reported through ca3d_get_jit_log); "roll" 0/1 the rolling-window form of the run-time compiled class kernels (on by
+ * default where it applies), "roll_z" 0/2/4/8 its planes per thread (0: chosen per launch); "graph_min" n: batches shorter than n
  * steps are launched kernel by kernel instead of as a captured graph; "render_mode" 0/1; "render_row_begin" / "render_row_end":
  * ca3d_render then fills image rows [begin, end) only (begin a multiple of 16; 0 / 0 = the whole frame) — a rank's
  * band when the GPUs of a node share one frame; "render_skip" 0/1 empty-space skipping by

@@ -295,6 +295,46 @@ def test_2048_cubed_two_steps(eng, name):
     eng.configure(32)  # release the 2 GiB before the next test
 
 
+@pytest.mark.parametrize("name", ["clustered", "moore_wide", "moore_b4s4", "edges_main", "corners_main", "vn_edges_only", "vn_corners_only"])
+def test_rolling_window_kernel_every_depth(eng, name):
+    """The rolling-window form of the class kernels (ca_packed_roll_kernel.inc: per-plane partial sums A / B / c in a
+    three-plane register window) with 2, 4 and 8 planes per thread, on a full 256^3 grid (runs start on global plane 0,
+    the last plane's z+1 wraps) and — launcher's own choice — at 512^3; against the oracle and against the plain class
+    kernel."""
+    r = rules(name)
+    G = 256
+    eng.configure(G)
+    set_rules(eng, r)
+    assert b"roll" in eng.info().kernel_name, eng.info().kernel_name
+    st = host.random_fill(host.words_per_buffer(G), seed=61)
+    want = ol.packed_run(G, st, r, 3)
+    for z in (2, 4, 8):
+        eng.set_option("roll_z", z)
+        eng.upload_state(st)
+        eng.step(3)
+        np.testing.assert_array_equal(eng.read_state(), want, err_msg=f"roll_z {z}")
+    eng.set_option("roll_z", 0)
+    eng.set_option("roll", 0)
+    assert b"roll" not in eng.info().kernel_name
+    eng.upload_state(st)
+    eng.step(3)
+    np.testing.assert_array_equal(eng.read_state(), want)
+    eng.set_option("roll", 1)
+
+
+@pytest.mark.parametrize("name", ["clustered", "edges_main"])
+def test_rolling_window_kernel_at_512(eng, name):
+    r = rules(name)
+    G = 512
+    eng.configure(G)
+    set_rules(eng, r)
+    st = host.random_fill(host.words_per_buffer(G), seed=62)
+    eng.upload_state(st)
+    eng.step(2)
+    assert b"roll" in eng.info().kernel_name
+    np.testing.assert_array_equal(eng.read_state(), ol.packed_run(G, st, r, 2))
+
+
 def test_batches_of_any_length_replay_as_graphs(eng):
     """A batch of n < 1024 steps is one captured graph of exactly n steps, cached per (n, start buffer): odd lengths
     alternate between the two buffers; short batches (< graph_min) are launched kernel by kernel."""
@@ -304,6 +344,7 @@ def test_batches_of_any_length_replay_as_graphs(eng):
     set_rules(eng, r)
     st = host.random_fill(host.words_per_buffer(G), seed=22)
     eng.upload_state(st)
+    eng.set_option("graph_min", 8)  # default 128: shorter batches go kernel by kernel
     eng.set_option("graph_prepare", 21)
     total = 0
     for n in (21, 21, 3, 20, 21, 1, 37):
@@ -316,7 +357,7 @@ def test_batches_of_any_length_replay_as_graphs(eng):
     for n in (2, 3, 5):
         eng.step(n)
     np.testing.assert_array_equal(eng.read_state(), ol.packed_run(G, st, r, 10))
-    eng.set_option("graph_min", 8)
+    eng.set_option("graph_min", 128)
 
 
 def test_jit_failure_is_reported_and_falls_back(monkeypatch):

@@ -98,7 +98,7 @@ def test_graph_replay_after_a_non_binary_upload():
     values and tests `== 1` / `== 0`)."""
     from cellularautomatons3d_amd import Engine
 
-    G, n = 128, 64
+    G, n = 128, 130  # >= graph_min (128): the batch replays as a captured graph
     r = ol.Rules.from_strings("von neumann", "1,3", "0-6")
     a = (host.random_fill(G ** 3, seed=41) & 1).astype(np.uint32)
     b = (host.random_fill(G ** 3, seed=42) % 4).astype(np.uint32)  # values 0..3

@@ -39,7 +39,20 @@ namespace jit
 }
 """
 
-HEADERS = [b"ca_bitops.inc", b"ca_packed_vn_kernel.inc", b"ca_device_types.h", b"ca_bitslice.inc", b"ca_packed_class_kernel.inc"]
+ROLL_PROGRAM = b"""
+#include "ca_device_types.h"
+namespace ca3d
+{
+namespace jit
+{
+#include "ca_bitslice.inc"
+#include "ca_packed_roll_kernel.inc"
+}
+}
+"""
+
+HEADERS = [b"ca_bitops.inc", b"ca_packed_vn_kernel.inc", b"ca_device_types.h", b"ca_bitslice.inc", b"ca_packed_class_kernel.inc",
+           b"ca_packed_roll_kernel.inc"]
 
 
 def _compile(rtc, program, name, defines):
@@ -81,3 +94,16 @@ def test_vn_kernel_source_compiles_with_hiprtc(cvl, lut_s, lut_b):
     rtc = _hiprtc()
     code = _compile(rtc, PROGRAM, b"ca3d_jit_vn.hip", [b"-DCA3D_JIT_CVL=%d" % cvl, b"-DCA3D_JIT_LS=%d" % lut_s, b"-DCA3D_JIT_LB=%d" % lut_b])
     assert b"ca3d_jit_vn_zr1" in code and b"ca3d_jit_vn_zr2" in code
+
+
+@pytest.mark.parametrize("cvl,main,e,c,tables", [
+    (2, 2, "true", "true", (0x000000F0, 0x000000E0, 0x0038, 0x0010, 0x0014, 0x0008)),   # 512^3, the clustered rule's shape
+    (1, 3, "false", "false", (0x000C, 0x0008, 0, 0, 0, 0)),                              # 256^3, Moore 2D, life
+    (6, 4, "false", "true", (0x0350, 0x0244, 0, 0, 0x0002, 0x0000)),                     # 8192^3, edges main + corners set
+])
+def test_roll_kernel_source_compiles_with_hiprtc(cvl, main, e, c, tables):
+    rtc = _hiprtc()
+    defines = [b"-DCA3D_JIT_CVL=%d" % cvl, b"-DCA3D_JIT_MAIN=%d" % main, b"-DCA3D_JIT_E=" + e.encode(), b"-DCA3D_JIT_C=" + c.encode()]
+    defines += [b"-DCA3D_JIT_%s=%du" % (n, t) for n, t in zip([b"TS0", b"TB0", b"TS1", b"TB1", b"TS2", b"TB2"], tables)]
+    code = _compile(rtc, ROLL_PROGRAM, b"ca3d_jit_roll.hip", defines)
+    assert b"ca3d_jit_roll_z2" in code and b"ca3d_jit_roll_z4" in code and b"ca3d_jit_roll_z8" in code

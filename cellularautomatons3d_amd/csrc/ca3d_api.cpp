@@ -86,6 +86,18 @@ struct ca3d_engine
 	RollJit roll_jit;     // valid when roll_jit.cvl >= 0
 	std::string jit_log;  // why the last specialisation attempt failed (empty: none failed)
 
+	// resident multi-step kernel (ca_resident.hip): face mailboxes, status word (device + pinned host copy), tag counter
+	int use_resident = 1;
+	bool res_ready = false;       // the current rules / grid have a resident kernel
+	bool res_failed = false;      // a launch timed out: the path stays off until the next configure
+	bool res_check = false;       // a resident launch has been issued since the status was last looked at
+	void *res_jit_fn = nullptr;   // run-time compiled kernel for the current tables (null: the pre-built rule)
+	unsigned long long *res_mail = nullptr;
+	uint32_t *res_status = nullptr, *res_status_host = nullptr;
+	uint32_t res_epoch = 0;
+	uint32_t res_min = 8;                 // shorter batches take the per-step kernels
+	uint32_t res_timeout_ticks = 20000000; // 200 ms of s_memrealtime per wait
+
 	ca3d_stats stats{};
 	const char *kernel_name = "";
 
@@ -134,9 +146,22 @@ void free_render_targets(ca3d_engine *h)
 	h->rw = h->rh = 0;
 }
 
+void free_resident(ca3d_engine *h)
+{
+	if (h->res_mail) hipFree(h->res_mail);
+	if (h->res_status) hipFree(h->res_status);
+	if (h->res_status_host) hipHostFree(h->res_status_host);
+	h->res_mail = nullptr;
+	h->res_status = h->res_status_host = nullptr;
+	h->res_epoch = 0;
+	h->res_check = false;
+	h->res_failed = false;
+}
+
 void free_buffers(ca3d_engine *h)
 {
 	drop_graph(h);
+	free_resident(h);
 	for (int i = 0; i < 2; i++)
 	{
 		if (h->buf[i]) hipFree(h->buf[i]);
@@ -216,10 +241,21 @@ void refresh_kernels(ca3d_engine *h)
 	h->vn_jit = VnJit{};
 	h->class_jit = ClassJit{};
 	h->roll_jit = RollJit{};
+	h->res_ready = false;
+	h->res_jit_fn = nullptr;
 	h->jit_log.clear();
 	if (!h->configured || !h->rules.valid) return;
 	if (h->layout != CA3D_LAYOUT_PACKED32) { h->kernel_name = "ca_unpacked_literal"; return; }
 	h->kernel_name = packed_kernel_name(h->rules, h->G, h->variant);
+	{
+		// the resident kernel of the start-up rule is pre-built: available with or without the run-time compiler
+		uint32_t ls0 = 0, lb0 = 0;
+		if (h->use_resident && !h->slab && resident_kernel_applies(h->rules, h->G, h->variant))
+		{
+			vn_tables(h->rules, &ls0, &lb0);
+			if (vn_tables_prebuilt(ls0, lb0)) h->res_ready = true;
+		}
+	}
 	if (!h->use_jit) return;
 	if (!vn_kernel_applies(h->rules, h->G, h->variant))
 	{
@@ -239,6 +275,7 @@ void refresh_kernels(ca3d_engine *h)
 	}
 	uint32_t ls = 0, lb = 0;
 	vn_tables(h->rules, &ls, &lb);
+	const bool resident = h->use_resident && !h->slab && resident_kernel_applies(h->rules, h->G, h->variant);
 	if (vn_tables_prebuilt(ls, lb)) return;
 	if (hipSetDevice(h->device) != hipSuccess) return;
 	VnJit j;
@@ -247,6 +284,7 @@ void refresh_kernels(ca3d_engine *h)
 		h->vn_jit = j;
 		h->kernel_name = "ca_packed_vn(jit)";
 	}
+	if (resident && jit_resident_kernel(h->device, ls, lb, &h->res_jit_fn, &h->jit_log) == CA3D_OK) h->res_ready = true;
 }
 
 // A failed specialisation is not an error of the call that triggered it (the ahead-of-time kernels take over), but it
@@ -332,6 +370,60 @@ int step_graph(ca3d_engine *h, uint32_t n, uint32_t start, ca3d_engine::StepGrap
 	if (e != hipSuccess) return fail(CA3D_ERR_DEVICE, "hipGraphInstantiate: %s", hipGetErrorString(e));
 	g.launches = (uint32_t)launches;
 	*out = &h->step_graphs.emplace(key, g).first->second;
+	return CA3D_OK;
+}
+
+// A resident launch that timed out leaves an invalid state behind: say so at the first call that waits for the GPU.
+int check_resident(ca3d_engine *h)
+{
+	if (!h->res_check || !h->res_status_host) return CA3D_OK;
+	h->res_check = false;
+	if (*h->res_status_host == 0) return CA3D_OK;
+	const uint32_t who = *h->res_status_host;
+	h->res_failed = true; // per-step kernels from here on
+	h->has_state = false;
+	return fail(CA3D_ERR_DEVICE, "resident multi-step kernel: a wait for neighbour tile faces timed out (tile %u gave up first) — were all 256 "
+	            "workgroups resident? The state is invalid: upload it again; the engine now uses the per-step kernels", who - 1u);
+}
+
+// n steps as ONE launch of the resident kernel (state in registers between steps).
+int resident_steps(ca3d_engine *h, uint32_t n)
+{
+	if (!h->res_mail)
+	{
+		const size_t bytes = resident_mail_bytes(h->G);
+		HIP_TRY(hipMalloc((void **)&h->res_mail, bytes));
+		HIP_TRY(hipMalloc((void **)&h->res_status, 16));
+		HIP_TRY(hipHostMalloc((void **)&h->res_status_host, 16, hipHostMallocDefault));
+		*h->res_status_host = 0;
+		HIP_TRY(hipMemsetAsync(h->res_mail, 0, bytes, h->stream));
+		HIP_TRY(hipMemsetAsync(h->res_status, 0, 16, h->stream));
+		h->res_epoch = 0;
+	}
+	if (h->res_epoch > 0xFFFFFFFFu - n - 4u)
+	{
+		// the 32-bit state tags would wrap: start the numbering again from clean mailboxes
+		HIP_TRY(hipMemsetAsync(h->res_mail, 0, resident_mail_bytes(h->G), h->stream));
+		h->res_epoch = 0;
+	}
+	ResidentLaunch l;
+	l.in = h->buf[h->cur];
+	l.out_last = h->buf[(h->cur + n) & 1u];
+	l.out_prev = h->buf[(h->cur + n + 1u) & 1u];
+	l.G = h->G;
+	l.mail = h->res_mail;
+	l.status = h->res_status;
+	l.steps = n;
+	l.epoch0 = h->res_epoch;
+	l.timeout_ticks = h->res_timeout_ticks;
+	vn_tables(h->rules, &l.lut_s, &l.lut_b);
+	l.jit_fn = h->res_jit_fn;
+	hipError_t e = launch_resident(l, h->stream);
+	if (e != hipSuccess) return fail(CA3D_ERR_DEVICE, "resident kernel launch failed: %s", hipGetErrorString(e));
+	HIP_TRY(hipMemcpyAsync(h->res_status_host, h->res_status, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+	h->res_epoch += n;
+	h->res_check = true;
+	h->kernel_name = h->res_jit_fn ? "ca_resident_vn(jit)" : "ca_resident_vn";
 	return CA3D_OK;
 }
 
@@ -503,6 +595,15 @@ int ca3d_upload_state(ca3d_t *h, const uint32_t *words, size_t n_words)
 	h->step = 0;
 	h->cur = 0;
 	h->pending_edges = 0; // a restart between the two phases of a batch abandons the batch
+	if (h->res_status_host && *h->res_status_host)
+	{
+		// a resident launch gave up earlier: clean mailboxes and status for whoever turns the path on again
+		HIP_TRY(hipMemsetAsync(h->res_mail, 0, resident_mail_bytes(h->G), h->stream));
+		HIP_TRY(hipMemsetAsync(h->res_status, 0, 16, h->stream));
+		*h->res_status_host = 0;
+		h->res_epoch = 0;
+		h->res_check = false;
+	}
 	h->has_state = true;
 	h->binary_state = false;
 	if (h->layout == CA3D_LAYOUT_UNPACKED)
@@ -525,7 +626,7 @@ int ca3d_read_state(ca3d_t *h, uint32_t *words, size_t n_words)
 	const size_t off = h->slab ? (size_t)h->ghost * h->plane_words : 0;
 	HIP_TRY(hipMemcpyAsync(words, h->buf[h->cur] + off, n_words * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
 	HIP_TRY(hipStreamSynchronize(h->stream));
-	return CA3D_OK;
+	return check_resident(h);
 }
 
 int ca3d_step(ca3d_t *h, uint32_t n_steps)
@@ -539,6 +640,15 @@ int ca3d_step(ca3d_t *h, uint32_t n_steps)
 	if (h->want_stats) HIP_TRY(hipEventRecord(h->ev_start, h->stream));
 	uint32_t left = n_steps;
 	uint64_t launches = 0;
+	if (h->res_ready && h->use_resident && !h->res_failed && n_steps >= h->res_min && h->stream != nullptr)
+	{
+		rc = resident_steps(h, n_steps);
+		if (rc) return rc;
+		h->step += n_steps;
+		h->cur = (h->cur + n_steps) & 1u;
+		launches = 1;
+		left = 0;
+	}
 	while (left)
 	{
 		uint32_t n = left > kMaxGraphSteps ? kMaxGraphSteps : left;
@@ -701,7 +811,7 @@ int ca3d_synchronize(ca3d_t *h)
 	int rc = bind_device(h);
 	if (rc) return rc;
 	HIP_TRY(hipStreamSynchronize(h->stream));
-	return CA3D_OK;
+	return check_resident(h);
 }
 
 int ca3d_set_stream(ca3d_t *h, void *hip_stream)
@@ -756,6 +866,7 @@ int ca3d_get_info(ca3d_t *h, ca3d_info *out)
 	{
 		if (h->layout != CA3D_LAYOUT_PACKED32) name = h->step > 0 && h->kernel_name[0] ? h->kernel_name : "ca_unpacked";
 		else if (h->use_fused && !h->slab && packed_fused_steps(h->rules, h->G, h->variant) == 2) name = "ca_packed_fused+ca_packed_class";
+		else if (h->res_ready && h->use_resident && !h->res_failed) name = h->res_jit_fn ? "ca_resident_vn(jit)" : "ca_resident_vn";
 		else name = h->vn_jit.cvl >= 0 ? "ca_packed_vn(jit)" : packed_kernel_name(h->rules, h->G, h->variant);
 	}
 	const bool class_jit = h->configured && h->rules.valid && h->layout == CA3D_LAYOUT_PACKED32 && h->class_jit.main >= 0 &&
@@ -791,7 +902,8 @@ int ca3d_get_stats(ca3d_t *h, ca3d_stats *out)
 	HIP_TRY(hipEventElapsedTime(&ms, h->ev_start, h->ev_stop));
 	h->stats.gpu_ms = ms;
 	*out = h->stats;
-	return CA3D_OK;
+	HIP_TRY(hipStreamSynchronize(h->stream));
+	return check_resident(h);
 }
 
 int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t height, uint32_t spp,
@@ -974,6 +1086,26 @@ int ca3d_set_option(ca3d_t *h, const char *name, int64_t value)
 		h->variant = (int)value;
 		refresh_kernels(h);
 		note_jit_failure(h);
+		return CA3D_OK;
+	}
+	if (!strcmp(name, "resident"))
+	{
+		h->use_resident = value ? 1 : 0;
+		if (value) h->res_failed = false;
+		refresh_kernels(h);
+		note_jit_failure(h);
+		return CA3D_OK;
+	}
+	if (!strcmp(name, "resident_min"))
+	{
+		if (value < 1) return fail(CA3D_ERR_INVALID_ARGUMENT, "resident_min must be >= 1");
+		h->res_min = (uint32_t)value;
+		return CA3D_OK;
+	}
+	if (!strcmp(name, "resident_timeout_us"))
+	{
+		if (value < 1 || value > 40000000) return fail(CA3D_ERR_INVALID_ARGUMENT, "resident_timeout_us must be in [1, 40000000]");
+		h->res_timeout_ticks = (uint32_t)(value * 100);
 		return CA3D_OK;
 	}
 	if (!strcmp(name, "roll_z"))

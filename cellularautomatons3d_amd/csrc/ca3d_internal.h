@@ -89,6 +89,19 @@ struct PackedLaunch
 	int roll_z = 0; // 0: the launcher picks the planes per thread of the rolling-window kernel; 2 / 4 / 8: forced (tests, tuning)
 };
 
+// One launch of the resident multi-step kernel (ca_resident.hip): `steps` steps from `in`, state on chip in between
+struct ResidentLaunch
+{
+	const uint32_t *in;
+	uint32_t *out_last, *out_prev; // state after `steps` steps / one step earlier (the two ping-pong buffers)
+	uint32_t G;
+	unsigned long long *mail;      // face mailboxes, resident_mail_bytes(G)
+	uint32_t *status;              // device word 0: != 0 when a wait timed out
+	uint32_t steps, epoch0, timeout_ticks;
+	uint32_t lut_s, lut_b;         // von Neumann truth tables (vn_tables)
+	void *jit_fn = nullptr;        // hipFunction_t of the run-time compiled kernel for these tables, or null (pre-built rule)
+};
+
 struct UnpackedLaunch
 {
 	const uint32_t *in;
@@ -142,6 +155,12 @@ int jit_roll_kernels(int device, const CanonRules &r, int cvl, RollJit *out, std
 // Whether the rolling-window kernel is the one to use for these rules on this grid (diagonal neighbour classes in
 // play, power-of-two grid of 256 and up)
 bool roll_kernel_applies(const CanonRules &r, uint32_t G, int variant);
+// ca_resident.hip
+bool resident_kernel_applies(const CanonRules &r, uint32_t G, int variant);
+size_t resident_mail_bytes(uint32_t G);
+uint32_t resident_lds_bytes();
+hipError_t launch_resident(const ResidentLaunch &l, hipStream_t stream);
+int jit_resident_kernel(int device, uint32_t lut_s, uint32_t lut_b, void **fn, std::string *log);
 // Steps one fused launch advances for these rules / grid (0 = no fused kernel applies).
 int packed_fused_steps(const CanonRules &r, uint32_t G, int variant);
 hipError_t launch_packed_fused(const PackedLaunch &l, hipStream_t stream, const char **kernel_name);

@@ -1,0 +1,56 @@
+// Resident multi-step kernel (ca_resident_kernel.inc): ahead-of-time instantiation for the reference's start-up rule
+// and the launcher. K steps of the packed von Neumann CA at 512^3 in one launch, state in registers, tile faces
+// exchanged through tagged granules; see the device source for the design.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ca3d_internal.h"
+
+namespace ca3d
+{
+namespace
+{
+#include "ca_bitops.inc"
+
+#include "ca_resident_kernel.inc"
+
+constexpr int kDefaultS = 0xFF, kDefaultB = 0x0A; // von Neumann B1,3 / S0-6, canonical tables (ca_packed_vn.hip)
+
+} // namespace
+
+// The rule is a pair of truth tables over the von Neumann count (as ca_packed_vn) and the grid is the one the tile
+// geometry is built for.
+bool resident_kernel_applies(const CanonRules &r, uint32_t G, int variant) { return G == 512u && vn_kernel_applies(r, G, variant); }
+
+size_t resident_mail_bytes(uint32_t G)
+{
+	const size_t tiles = (size_t)(G / kResTileRows) * (G / kResTileRows);
+	return 2u * tiles * 4u * kResFaceWords * sizeof(unsigned long long);
+}
+
+uint32_t resident_lds_bytes() { return kResLdsBytes; }
+
+hipError_t launch_resident(const ResidentLaunch &l, hipStream_t stream)
+{
+	ResidentArgs a;
+	a.in = l.in;
+	a.out_last = l.out_last;
+	a.out_prev = l.out_prev;
+	a.mail = l.mail;
+	a.status = l.status;
+	a.steps = l.steps;
+	a.epoch0 = l.epoch0;
+	a.timeout_ticks = l.timeout_ticks;
+	const u32 tiles = (l.G / kResTileRows) * (l.G / kResTileRows);
+	if (l.jit_fn)
+	{
+		void *args[] = {(void *)&a};
+		return hipModuleLaunchKernel((hipFunction_t)l.jit_fn, tiles, 1, 1, kResThreads, 1, 1, 0, stream, args, nullptr);
+	}
+	if (l.lut_s != (u32)kDefaultS || l.lut_b != (u32)kDefaultB) return hipErrorInvalidValue;
+	auto kern = ca_resident_vn<kDefaultS, kDefaultB>;
+	hipLaunchKernelGGL(kern, dim3(tiles), dim3(kResThreads), 0, stream, a);
+	return hipGetLastError();
+}
+
+} // namespace ca3d

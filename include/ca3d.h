@@ -213,7 +213,11 @@ int ca3d_get_render_stats(ca3d_t *h, ca3d_render_stats *out);
  * steps (otherwise built on first use); "fused" 0/1 two-step fused kernel
  * (bit-exact, off by default); "variant" 1 forces the generic / literal kernels; "jit" 0/1 run-time (hiprtc) specialisation of the step
  * kernel for the current rule, compiled inside ca3d_set_rules / ca3d_configure (on by default; a failed compile
- * keeps the pre-built kernels and is reported through ca3d_get_jit_log); "roll" 0/1 the rolling-window form of the run-time compiled class kernels (on by
+ * keeps the pre-built kernels and is reported through ca3d_get_jit_log); "resident" 0/1: batches of "resident_min" (default 8) steps and more run as ONE launch of
+ * the resident multi-step kernel where one exists (512^3, von Neumann rule tables: the state stays in registers and only
+ * tile faces cross the chip; every in-kernel wait is bounded by "resident_timeout_us", default 200 000 — a timeout makes
+ * the next ca3d_synchronize / ca3d_read_state / ca3d_get_stats fail with CA3D_ERR_DEVICE and turns the path off);
+ * "roll" 0/1 the rolling-window form of the run-time compiled class kernels (on by
  * default where it applies), "roll_z" 0/2/4/8 its planes per thread (0: chosen per launch); "graph_min" n: batches shorter than n
  * steps are launched kernel by kernel instead of as a captured graph; "render_mode" 0/1; "render_row_begin" / "render_row_end":
  * ca3d_render then fills image rows [begin, end) only (begin a multiple of 16; 0 / 0 = the whole frame) — a rank's

@@ -58,7 +58,9 @@ def test_vn_truth_table_kernel_random_tables(eng, G):
             set_rules(eng, r)
             eng.upload_state(st)
             prebuilt = (lut_s & 0x7F, lut_b & 0x7F) == (0x7F, 0x0A)
-            assert eng.info().kernel_name == (b"ca_packed_vn(jit)" if jit and not prebuilt else b"ca_packed_vn")
+            resident = G == 512 and (jit or prebuilt)  # batches of >= 8 steps would take the resident kernel; 3 steps do not
+            stem = b"ca_resident_vn" if resident else b"ca_packed_vn"
+            assert eng.info().kernel_name == stem + (b"(jit)" if jit and not prebuilt else b"")
             eng.step(3)
             np.testing.assert_array_equal(eng.read_state(), want, err_msg=f"S={lut_s:#x} B={lut_b:#x} jit={jit}")
         eng.set_option("jit", 1)
@@ -333,6 +335,46 @@ def test_rolling_window_kernel_at_512(eng, name):
     eng.step(2)
     assert b"roll" in eng.info().kernel_name
     np.testing.assert_array_equal(eng.read_state(), ol.packed_run(G, st, r, 2))
+
+
+@pytest.mark.parametrize("tables", ["default", "vn_b24_s135"])
+def test_resident_multi_step_kernel(eng, tables):
+    """The resident kernel (ca_resident_kernel.inc): K steps of a 512^3 von Neumann rule in one launch, the state in
+    registers, tile faces handed over through tagged granules. Batches of several lengths back to back (the state tags
+    keep counting across launches and across uploads), odd and even lengths (the result lands in either ping-pong
+    buffer, the other one holds the state one step earlier), against the oracle and against the per-step kernels."""
+    G = 512
+    r = rules(tables)
+    eng.configure(G)
+    set_rules(eng, r)
+    assert eng.info().kernel_name.startswith(b"ca_resident_vn")
+    st = host.random_fill(host.words_per_buffer(G), seed=88)
+    eng.upload_state(st)
+    want = st
+    total = 0
+    for n in (8, 9, 33, 16):
+        eng.step(n)
+        prev = ol.packed_run(G, want, r, n - 1)
+        want = ol.packed_step(G, prev, r)
+        total += n
+        np.testing.assert_array_equal(eng.read_state(), want, err_msg=f"after a batch of {n}")
+        assert eng.info().current_buffer == total % 2 and eng.info().step == total
+        import torch
+        from cellularautomatons3d_amd import slab
+        other = slab.device_tensor(*eng.device_buffer(1 - total % 2), 0).cpu().numpy().view(np.uint32)
+        np.testing.assert_array_equal(other, prev, err_msg="the other buffer holds the state one step earlier")
+    # a fresh upload, a sparse state (most tiles empty: faces of zeros must still carry their tags), many steps
+    st2 = host.initial_state(G)
+    eng.upload_state(st2)
+    eng.step(150)
+    got = eng.read_state()
+    eng.set_option("resident", 0)
+    assert eng.info().kernel_name.startswith(b"ca_packed_vn")
+    eng.upload_state(st2)
+    eng.step(150)
+    np.testing.assert_array_equal(got, eng.read_state())
+    np.testing.assert_array_equal(got, ol.packed_run(G, st2, r, 150))
+    eng.set_option("resident", 1)
 
 
 def test_batches_of_any_length_replay_as_graphs(eng):

@@ -51,8 +51,16 @@ namespace jit
 }
 """
 
+RESIDENT_PROGRAM = b"""
+namespace ca3d_jit
+{
+#include "ca_bitops.inc"
+#include "ca_resident_kernel.inc"
+}
+"""
+
 HEADERS = [b"ca_bitops.inc", b"ca_packed_vn_kernel.inc", b"ca_device_types.h", b"ca_bitslice.inc", b"ca_packed_class_kernel.inc",
-           b"ca_packed_roll_kernel.inc"]
+           b"ca_packed_roll_kernel.inc", b"ca_resident_kernel.inc"]
 
 
 def _compile(rtc, program, name, defines):
@@ -107,3 +115,8 @@ def test_roll_kernel_source_compiles_with_hiprtc(cvl, main, e, c, tables):
     defines += [b"-DCA3D_JIT_%s=%du" % (n, t) for n, t in zip([b"TS0", b"TB0", b"TS1", b"TB1", b"TS2", b"TB2"], tables)]
     code = _compile(rtc, ROLL_PROGRAM, b"ca3d_jit_roll.hip", defines)
     assert b"ca3d_jit_roll_z2" in code and b"ca3d_jit_roll_z4" in code and b"ca3d_jit_roll_z8" in code
+
+
+def test_resident_kernel_source_compiles_with_hiprtc():
+    code = _compile(_hiprtc(), RESIDENT_PROGRAM, b"ca3d_jit_resident.hip", [b"-DCA3D_JIT_LS=%d" % 0x2A, b"-DCA3D_JIT_LB=%d" % 0x14])
+    assert b"ca3d_jit_resident" in code

@@ -359,7 +359,9 @@ def roofline_block(kernel, G, bytes_per_launch, launches, ev_ms, state_bytes):
             "algorithmic_bytes_per_launch": bytes_per_launch, "launches_timed": int(launches),
             "timing": "HIP events on the engine's stream around the whole timed region / launches in it",
             "working_set_bytes": 2 * state_bytes,
-            "resident": "infinity cache (both ping-pong buffers fit in 256 MiB: the rate is an algorithmic-byte rate against the HBM peak, "
+            "resident": "registers + LDS (the resident multi-step kernel keeps the state on chip for the whole batch; per step only the tile faces, "
+                        "2 MiB at 512^3, cross the fabric — the rate is algorithmic bytes per second against the HBM peak and may exceed it)" if kernel.startswith("ca_resident") else
+                        "infinity cache (both ping-pong buffers fit in 256 MiB: the rate is an algorithmic-byte rate against the HBM peak, "
                         "not DRAM traffic)" if fits else "hbm (the ping-pong buffers exceed the 256 MiB Infinity Cache)"}
 
 

@@ -374,7 +374,15 @@ def test_resident_multi_step_kernel(eng, tables):
     eng.step(150)
     np.testing.assert_array_equal(got, eng.read_state())
     np.testing.assert_array_equal(got, ol.packed_run(G, st2, r, 150))
+    # 1000 steps on a dense state in one launch against 1000 launches of the per-step kernel
+    eng.upload_state(st)
+    eng.step(1000)
+    per_step = eng.read_state()
     eng.set_option("resident", 1)
+    eng.upload_state(st)
+    eng.step(1000)
+    assert eng.info().kernel_name.startswith(b"ca_resident_vn")
+    np.testing.assert_array_equal(eng.read_state(), per_step)
 
 
 def test_batches_of_any_length_replay_as_graphs(eng):

@@ -373,6 +373,8 @@ int step_graph(ca3d_engine *h, uint32_t n, uint32_t start, ca3d_engine::StepGrap
 	return CA3D_OK;
 }
 
+constexpr size_t kResStatusBytes = (4 + 1024) * sizeof(uint32_t); // abort word + per-tile progress words
+
 // A resident launch that timed out leaves an invalid state behind: say so at the first call that waits for the GPU.
 int check_resident(ca3d_engine *h)
 {
@@ -393,11 +395,11 @@ int resident_steps(ca3d_engine *h, uint32_t n)
 	{
 		const size_t bytes = resident_mail_bytes(h->G);
 		HIP_TRY(hipMalloc((void **)&h->res_mail, bytes));
-		HIP_TRY(hipMalloc((void **)&h->res_status, 16));
+		HIP_TRY(hipMalloc((void **)&h->res_status, kResStatusBytes));
 		HIP_TRY(hipHostMalloc((void **)&h->res_status_host, 16, hipHostMallocDefault));
 		*h->res_status_host = 0;
 		HIP_TRY(hipMemsetAsync(h->res_mail, 0, bytes, h->stream));
-		HIP_TRY(hipMemsetAsync(h->res_status, 0, 16, h->stream));
+		HIP_TRY(hipMemsetAsync(h->res_status, 0, kResStatusBytes, h->stream));
 		h->res_epoch = 0;
 	}
 	if (h->res_epoch > 0xFFFFFFFFu - n - 4u)
@@ -413,6 +415,7 @@ int resident_steps(ca3d_engine *h, uint32_t n)
 	l.G = h->G;
 	l.mail = h->res_mail;
 	l.status = h->res_status;
+	l.host_flag = h->res_status_host;
 	l.steps = n;
 	l.epoch0 = h->res_epoch;
 	l.timeout_ticks = h->res_timeout_ticks;
@@ -420,7 +423,6 @@ int resident_steps(ca3d_engine *h, uint32_t n)
 	l.jit_fn = h->res_jit_fn;
 	hipError_t e = launch_resident(l, h->stream);
 	if (e != hipSuccess) return fail(CA3D_ERR_DEVICE, "resident kernel launch failed: %s", hipGetErrorString(e));
-	HIP_TRY(hipMemcpyAsync(h->res_status_host, h->res_status, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
 	h->res_epoch += n;
 	h->res_check = true;
 	h->kernel_name = h->res_jit_fn ? "ca_resident_vn(jit)" : "ca_resident_vn";
@@ -599,7 +601,7 @@ int ca3d_upload_state(ca3d_t *h, const uint32_t *words, size_t n_words)
 	{
 		// a resident launch gave up earlier: clean mailboxes and status for whoever turns the path on again
 		HIP_TRY(hipMemsetAsync(h->res_mail, 0, resident_mail_bytes(h->G), h->stream));
-		HIP_TRY(hipMemsetAsync(h->res_status, 0, 16, h->stream));
+		HIP_TRY(hipMemsetAsync(h->res_status, 0, kResStatusBytes, h->stream));
 		*h->res_status_host = 0;
 		h->res_epoch = 0;
 		h->res_check = false;

@@ -96,7 +96,8 @@ struct ResidentLaunch
 	uint32_t *out_last, *out_prev; // state after `steps` steps / one step earlier (the two ping-pong buffers)
 	uint32_t G;
 	unsigned long long *mail;      // face mailboxes, resident_mail_bytes(G)
-	uint32_t *status;              // device word 0: != 0 when a wait timed out
+	uint32_t *status;              // device words: [0] != 0 when a wait timed out, [4 + tile] steps finished by that tile
+	uint32_t *host_flag;           // pinned host word the kernel sets on a timeout
 	uint32_t steps, epoch0, timeout_ticks;
 	uint32_t lut_s, lut_b;         // von Neumann truth tables (vn_tables)
 	void *jit_fn = nullptr;        // hipFunction_t of the run-time compiled kernel for these tables, or null (pre-built rule)

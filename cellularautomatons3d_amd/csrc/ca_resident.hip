@@ -38,6 +38,7 @@ hipError_t launch_resident(const ResidentLaunch &l, hipStream_t stream)
 	a.out_prev = l.out_prev;
 	a.mail = l.mail;
 	a.status = l.status;
+	a.host_flag = l.host_flag;
 	a.steps = l.steps;
 	a.epoch0 = l.epoch0;
 	a.timeout_ticks = l.timeout_ticks;

@@ -20,6 +20,9 @@ int main(int argc, char **argv)
 	CK(hipMalloc(&b0, words * 4)); CK(hipMalloc(&b1, words * 4)); CK(hipMalloc(&mail, mail_bytes)); CK(hipMalloc(&status, (4 + 256) * 4));
 	CK(hipMemcpy(b0, h.data(), words * 4, hipMemcpyHostToDevice));
 	CK(hipMemset(mail, 0, mail_bytes)); CK(hipMemset(status, 0, (4 + 256) * 4));
+	u32 *hflag;
+	CK(hipHostMalloc((void **)&hflag, 16, hipHostMallocDefault));
+	*hflag = 0;
 	const int launches = argc > 2 ? atoi(argv[2]) : 3;
 	hipEvent_t e0, e1;
 	CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -27,7 +30,7 @@ int main(int argc, char **argv)
 	u32 *buf[2] = {b0, b1};
 	for (int l = 0; l < launches; l++)
 	{
-		ResidentArgs a{buf[cur], buf[(cur + steps) & 1], buf[(cur + steps + 1) & 1], mail, status, steps, epoch, 5000000u};
+		ResidentArgs a{buf[cur], buf[(cur + steps) & 1], buf[(cur + steps + 1) & 1], mail, status, hflag, steps, epoch, 5000000u};
 		CK(hipEventRecord(e0));
 		hipLaunchKernelGGL((ca_resident_vn<0xFF, 0x0A>), dim3(256), dim3(512), 0, 0, a);
 		CK(hipGetLastError());

@@ -63,6 +63,7 @@ struct ca3d_engine
 	int variant = 0;
 	int use_graph = 1;
 	int render_mode = 0;
+	int render_indirect = 0; // add calculateIndirectLighting (pathtraced_fragment_clustered.wgsl:307-377; commented out at the reference's call site)
 	int render_sched = 1; // dynamic ray scheduling in the converged-frame renderer (render.hip); 0: one pixel per lane, in order
 	uint32_t render_row0 = 0, render_row1 = 0; // rows [row0, row1) of the frame are rendered (0, 0: all): a rank's band
 	int use_fused = 0; // the two-step fused kernel is bit-exact but measured slower than two single steps
@@ -968,6 +969,8 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 	}
 	l.mode = h->render_mode;
 	l.sched = h->render_sched;
+	l.indirect = h->render_indirect != 0;
+	if (l.indirect && (h->render_mode != 0 || h->layout != CA3D_LAYOUT_PACKED32)) return fail(CA3D_ERR_UNSUPPORTED, "render_indirect is implemented for the converged-frame mode over the packed layout");
 	l.row0 = h->render_row0;
 	l.row1 = h->render_row1 > height ? height : h->render_row1;
 	if (l.row1 && l.row0 >= l.row1) return fail(CA3D_ERR_INVALID_ARGUMENT, "render rows [%u, %u) are empty for a target of %u rows", l.row0, h->render_row1, height);
@@ -1048,6 +1051,7 @@ int ca3d_set_option(ca3d_t *h, const char *name, int64_t value)
 		h->graph_min = (uint32_t)value;
 		return CA3D_OK;
 	}
+	if (!strcmp(name, "render_indirect")) { h->render_indirect = value ? 1 : 0; return CA3D_OK; }
 	if (!strcmp(name, "render_sched")) { h->render_sched = value ? 1 : 0; return CA3D_OK; }
 	if (!strcmp(name, "render_skip")) { h->render_skip = value ? 1 : 0; return CA3D_OK; }
 	if (!strcmp(name, "render_row_begin") || !strcmp(name, "render_row_end"))

@@ -55,6 +55,7 @@ struct RenderParams
 	u32 occ_words;                 // 64-bit words of (fine) occupancy bits
 	u32 occ_coarse;                // != 0: coarse bits (blocks of 128 x 32 x 32 cells) follow the count word
 	u32 row0, row1; // only image rows [row0, row1) are rendered (a rank's band of a frame shared between GPUs); row0 is a multiple of 16
+	u32 indirect;   // add calculateIndirectLighting (:307-377), the term the reference leaves commented out at :424
 };
 
 constexpr float kPi = 3.14159265359f;
@@ -135,6 +136,25 @@ __device__ v3 surface_brdf(v3 L, v3 Vd, v3 N, float roughness, v3 albedo, v3 F0)
 	const v3 F = V(F0.x + (1.0f - F0.x) * p, F0.y + (1.0f - F0.y) * p, F0.z + (1.0f - F0.z) * p);
 	const float denom = 4.0f * dot3(Vd, N) * dot3(L, N);
 	return V(fL.x + (D * Gm * F.x) / denom, fL.y + (D * Gm * F.y) / denom, fL.z + (D * Gm * F.z) / denom);
+}
+
+// calculateLightingAt :594-633 with a vec3 incident light arriving from `light_pos` (the direct term passes the light
+// source's magnitude and position, the indirect term a neighbour cell's reflected light and the point it leaves from)
+__device__ v3 lighting_from(const RenderParams &P, v3 p, v3 origin, u32 cx, u32 cy, v3 eye, v3 incident, v3 light_pos)
+{
+	const float *u = P.u;
+	const v3 N = face_normal(p, origin);
+	const float Gf = (float)P.G;
+	const float cxn = (float)cx / Gf, cyn = (float)cy / Gf;
+	v3 albedo = V(cxn, cyn, 1.0f - cxn);
+	if (u[U_MATERIALCOLOR] != 0.0f || u[U_MATERIALCOLOR + 1] != 0.0f || u[U_MATERIALCOLOR + 2] != 0.0f)
+		albedo = V(u[U_MATERIALCOLOR], u[U_MATERIALCOLOR + 1], u[U_MATERIALCOLOR + 2]);
+	const v3 Vd = norm3(eye - p);
+	const v3 L = norm3(light_pos - p);
+	const v3 F0 = V(u[U_REFLECTIVITY], u[U_REFLECTIVITY + 1], u[U_REFLECTIVITY + 2]);
+	const v3 brdf = surface_brdf(L, Vd, N, u[U_ROUGHNESS], albedo, F0);
+	const float LoN = dot3(L, N);
+	return V(fmaxf(0.0f, brdf.x * incident.x * LoN), fmaxf(0.0f, brdf.y * incident.y * LoN), fmaxf(0.0f, brdf.z * incident.z * LoN));
 }
 
 // ---- empty-space skipping ------------------------------------------------------------------------------------
@@ -369,6 +389,36 @@ __device__ Sample shade_sample(const RenderParams &P, float vu, float vv, u32 &p
 			s.g = occ * fmaxf(0.0f, brdf.y * mag * LoN);
 			s.b = occ * fmaxf(0.0f, brdf.z * mag * LoN);
 			s.shadow_ray = 1u;
+			if (P.indirect)
+			{
+				// calculateIndirectLighting :307-377 — one bounce off the four neighbour cells of the layer the face looks
+				// into (tables :117-169): each live neighbour is hit along the integer offset direction, lit from the light
+				// source (own shadow walk), and what it reflects towards p is p's incident light from that point
+				int ox[4], oy[4], oz[4];
+				if (N.x != 0.0f) { const int sx = N.x < 0.0f ? -1 : 1; ox[0] = ox[1] = ox[2] = ox[3] = sx; oy[0] = 1; oy[1] = -1; oy[2] = oy[3] = 0; oz[0] = oz[1] = 0; oz[2] = 1; oz[3] = -1; }
+				else if (N.y != 0.0f) { const int sy = N.y < 0.0f ? -1 : 1; oy[0] = oy[1] = oy[2] = oy[3] = sy; ox[0] = -1; ox[1] = 1; ox[2] = ox[3] = 0; oz[0] = oz[1] = 0; oz[2] = 1; oz[3] = -1; }
+				else { const int sz = N.z < 0.0f ? -1 : 1; oz[0] = oz[1] = oz[2] = oz[3] = sz; ox[0] = ox[1] = 0; ox[2] = -1; ox[3] = 1; oy[0] = 1; oy[1] = -1; oy[2] = oy[3] = 0; }
+				for (int i = 0; i < 4; i++)
+				{
+					const u32 nx = (u32)(cx + ox[i]), ny = (u32)(cy + oy[i]), nz = (u32)(cz + oz[i]); // vec3u(vec3i) :345
+					if (!cell_state(P, nx, ny, nz)) continue;
+					const v3 norigin = V((float)nx * cs + cs * 0.5f - kHalf, (float)ny * cs + cs * 0.5f - kHalf, (float)nz * cs + cs * 0.5f - kHalf);
+					const v3 ndir = V((float)ox[i], (float)oy[i], (float)oz[i]);
+					float qn, qf;
+					ray_cube(p, ndir, norigin, vhalf, qn, qf);
+					if (!(qn <= qf && qf >= 0.0f)) continue;
+					const v3 np = p + ndir * qn;
+					const v3 nl = norm3(light_pos - np);
+					float wn, wf;
+					ray_cube(np, nl, V(0.0f, 0.0f, 0.0f), half, wn, wf);
+					const v3 nseg = (np + nl * wf) - np;
+					float dummy2 = 0.0f;
+					const bool nocc = walk<true, SKIP>(P, np, norm3(nseg), 0.0025f, len3(nseg), vhalf, (int)nx, (int)ny, (int)nz, dummy2, svis);
+					const v3 refl = lighting_from(P, np, norigin, nx, ny, p, V(mag, mag, mag), light_pos) * (nocc ? kOcclusion : 1.0f);
+					const v3 ind = lighting_from(P, p, origin, (u32)cx, (u32)cy, cam, refl, np);
+					s.r += ind.x; s.g += ind.y; s.b += ind.z;
+				}
+			}
 			}
 		}
 		// fixed point of clamp(mix(prev, cur, alpha), 0, 1) under a static camera :468
@@ -1155,6 +1205,7 @@ hipError_t launch_render(const RenderLaunch &l, hipStream_t stream)
 	P.depth = l.depth;
 	P.counters = l.counters;
 	P.legacy = l.legacy ? 1u : 0u;
+	P.indirect = l.indirect && !l.legacy ? 1u : 0u;
 	P.occ = nullptr;
 	P.occ_words = 0;
 	P.occ_coarse = 0;
@@ -1181,14 +1232,14 @@ hipError_t launch_render(const RenderLaunch &l, hipStream_t stream)
 		F.prev_depth = l.prev_depth;
 		hipLaunchKernelGGL(ca_render_frame_packed, grid, dim3(256), 0, stream, F);
 	}
-	else if (l.sched && l.spp == 1)
+	else if (l.sched && !P.indirect && l.spp == 1)
 	{
 		// one sample per pixel: 256 pixels per wave (a block covers 32 x 32 pixels)
 		const dim3 g1((l.W + 31u) / 32u, (P.row1 - P.row0 + 31u) / 32u);
 		hipLaunchKernelGGL((ca_render_packed_sched<false, 256, 1>), g1, dim3(256), 0, stream, P);
 		if (P.occ) hipLaunchKernelGGL((ca_render_packed_sched<true, 256, 1>), g1, dim3(256), 0, stream, P);
 	}
-	else if (l.sched)
+	else if (l.sched && !P.indirect) // the indirect-lighting mode runs in the plain kernel (one pixel per lane)
 	{
 		hipLaunchKernelGGL((ca_render_packed_sched<false, 64, kSchedChunk>), grid, dim3(256), 0, stream, P);
 		if (P.occ) hipLaunchKernelGGL((ca_render_packed_sched<true, 64, kSchedChunk>), grid, dim3(256), 0, stream, P);

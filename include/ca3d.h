@@ -225,7 +225,9 @@ int ca3d_get_render_stats(ca3d_t *h, ca3d_render_stats *out);
  * 32x8x8-cell occupancy blocks, active on sparse volumes only (on by default; within the renderer's tolerance of
  * the cell-by-cell walk, not bit-identical to it); "render_sched" 0/1 dynamic ray
  * scheduling inside each wave of the renderer (on by default; the frame is the same bit for bit);
- * "render_reset_history". */
+ * "render_reset_history"; "render_indirect" 0/1 adds the one-bounce neighbour lighting of calculateIndirectLighting
+ * (pathtraced_fragment_clustered.wgsl:307-377 — present in the reference, its call commented out at :424; off by
+ * default like there; converged-frame mode, packed layout). */
 int ca3d_set_option(ca3d_t *h, const char *name, int64_t value);
 
 #ifdef __cplusplus

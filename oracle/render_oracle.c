@@ -57,6 +57,7 @@ typedef struct
 	const float *u;
 	float cot_half_fov;
 	int legacy; /* one u32 per cell + shaders/pathtraced_fragment.wgsl shading */
+	int indirect; /* add calculateIndirectLighting (:307-377; the reference leaves its call commented out at :424) */
 } Ctx;
 
 /* :268-290 (modulo wrap of every coordinate) */
@@ -159,24 +160,30 @@ static v3 surface_brdf(v3 L, v3 Vd, v3 N, float roughness, v3 albedo, v3 F0)
 	return V(fL.x + (D * Gm * F.x) / denom, fL.y + (D * Gm * F.y) / denom, fL.z + (D * Gm * F.z) / denom);
 }
 
-/* :594-633 */
-static v3 lighting_at(const Ctx *c, v3 p, Cell cell, v3 eye)
+/* :594-633 calculateLightingAt(samplePoint, cellOrigin, cellCoords, eyePos, incidentLight, incidentLightPos); the cell's x and
+ * y coordinates enter as u32 (albedo = coords / G) */
+static v3 lighting_from(const Ctx *c, v3 p, v3 origin, uint32_t cx, uint32_t cy, v3 eye, v3 incident, v3 lightPos)
 {
 	const float *u = c->u;
-	const v3 N = face_normal(p, cell.origin);
+	const v3 N = face_normal(p, origin);
 	const float Gf = (float)c->G;
-	const float cxn = (float)(uint32_t)cell.cx / Gf, cyn = (float)(uint32_t)cell.cy / Gf;
+	const float cxn = (float)cx / Gf, cyn = (float)cy / Gf;
 	v3 albedo = V(cxn, cyn, 1.0f - cxn);
 	if (u[U_MATERIALCOLOR] != 0.0f || u[U_MATERIALCOLOR + 1] != 0.0f || u[U_MATERIALCOLOR + 2] != 0.0f)
 		albedo = V(u[U_MATERIALCOLOR], u[U_MATERIALCOLOR + 1], u[U_MATERIALCOLOR + 2]);
-	const v3 lightPos = V(u[U_LIGHT], u[U_LIGHT + 1], u[U_LIGHT + 2]);
 	const v3 Vd = normalize3(sub(eye, p));
 	const v3 L = normalize3(sub(lightPos, p));
 	const v3 F0 = V(u[U_REFLECTIVITY], u[U_REFLECTIVITY + 1], u[U_REFLECTIVITY + 2]);
 	const v3 brdf = surface_brdf(L, Vd, N, u[U_ROUGHNESS], albedo, F0);
-	const float mag = u[U_LIGHT + 3];
 	const float LoN = dot(L, N);
-	return V(maxf(0.0f, brdf.x * mag * LoN), maxf(0.0f, brdf.y * mag * LoN), maxf(0.0f, brdf.z * mag * LoN));
+	return V(maxf(0.0f, brdf.x * incident.x * LoN), maxf(0.0f, brdf.y * incident.y * LoN), maxf(0.0f, brdf.z * incident.z * LoN));
+}
+
+static v3 lighting_at(const Ctx *c, v3 p, Cell cell, v3 eye)
+{
+	const float *u = c->u;
+	const float mag = u[U_LIGHT + 3];
+	return lighting_from(c, p, cell.origin, (uint32_t)cell.cx, (uint32_t)cell.cy, eye, V(mag, mag, mag), V(u[U_LIGHT], u[U_LIGHT + 1], u[U_LIGHT + 2]));
 }
 
 /* Exact cell walk from `start` along unit `dir` over parametric range (t0, tmax): calls visit(cell) in
@@ -233,6 +240,53 @@ static int shadow_visit(void *ud_, int32_t x, int32_t y, int32_t z)
 	ray_cube(ud->start, ud->dir, cell_origin(ud->c, x, y, z), ud->half, &tn, &tf);
 	if (tn <= tf && tn >= 0.0f) { ud->occluded = 1; return 1; } /* :668 */
 	return 0;
+}
+
+/* :307-377 calculateIndirectLighting: light reflected once off the four neighbour cells in the layer the surface normal
+ * points into (layer tables :117-169). Each live neighbour is hit along the INTEGER offset direction (:357), lit from the
+ * light source — with its own shadow test, here the exact walk like every shadow ray of the converged frame — and that
+ * reflected light is then the incident light of the sample point, coming from the hit point. */
+static v3 indirect_lighting(const Ctx *c, v3 p, Cell cell, v3 cam)
+{
+	static const int32_t layers[6][4][3] = {
+	    { { -1, 1, 0 }, { -1, -1, 0 }, { -1, 0, 1 }, { -1, 0, -1 } }, /* left   (normal.x < 0) */
+	    { { 1, 1, 0 }, { 1, -1, 0 }, { 1, 0, 1 }, { 1, 0, -1 } },     /* right  (normal.x > 0) */
+	    { { -1, -1, 0 }, { 1, -1, 0 }, { 0, -1, 1 }, { 0, -1, -1 } }, /* bottom (normal.y < 0) */
+	    { { -1, 1, 0 }, { 1, 1, 0 }, { 0, 1, 1 }, { 0, 1, -1 } },     /* top    (normal.y > 0) */
+	    { { 0, 1, -1 }, { 0, -1, -1 }, { -1, 0, -1 }, { 1, 0, -1 } }, /* back   (normal.z < 0) */
+	    { { 0, 1, 1 }, { 0, -1, 1 }, { -1, 0, 1 }, { 1, 0, 1 } } };   /* front  (normal.z > 0) */
+	const float *u = c->u;
+	const v3 N = face_normal(p, cell.origin);
+	int layer;
+	if (N.x < 0) layer = 0; else if (N.x > 0) layer = 1; else if (N.y < 0) layer = 2; else if (N.y > 0) layer = 3; else if (N.z < 0) layer = 4; else if (N.z > 0) layer = 5; else return V(0, 0, 0);
+	const float cs = 1.0f / (float)c->G;
+	const float vis = cs * u[U_CELLSIZE] * 0.5f;
+	const v3 half = V(HALF_CUBE_SIZE, HALF_CUBE_SIZE, HALF_CUBE_SIZE);
+	const v3 lightPos = V(u[U_LIGHT], u[U_LIGHT + 1], u[U_LIGHT + 2]);
+	const float mag = u[U_LIGHT + 3];
+	v3 sum = V(0, 0, 0);
+	for (int i = 0; i < 4; i++)
+	{
+		const int32_t *o = layers[layer][i];
+		const uint32_t nx = (uint32_t)(cell.cx + o[0]), ny = (uint32_t)(cell.cy + o[1]), nz = (uint32_t)(cell.cz + o[2]); /* vec3u(vec3i) :345 */
+		if (!cell_state(c, nx, ny, nz)) continue;
+		const v3 norigin = V((float)nx * cs + cs * 0.5f - HALF_CUBE_SIZE, (float)ny * cs + cs * 0.5f - HALF_CUBE_SIZE, (float)nz * cs + cs * 0.5f - HALF_CUBE_SIZE);
+		const v3 ndir = V((float)o[0], (float)o[1], (float)o[2]);
+		float tn, tf;
+		ray_cube(p, ndir, norigin, V(vis, vis, vis), &tn, &tf);
+		if (!(tn <= tf && tf >= 0.0f)) continue;
+		const v3 np = add(p, scale(ndir, tn));
+		const v3 ldir = normalize3(sub(lightPos, np));
+		float vn, vf;
+		ray_cube(np, ldir, V(0, 0, 0), half, &vn, &vf);
+		const v3 sseg = sub(add(np, scale(ldir, vf)), np);
+		ShadowUD su = { c, np, normalize3(sseg), V(vis, vis, vis), (int32_t)nx, (int32_t)ny, (int32_t)nz, 0 };
+		walk_cells(c, np, su.dir, 0.0025f, length3(sseg), shadow_visit, &su);
+		const float occ = su.occluded ? OCCLUSION_FACTOR : 1.0f;
+		const v3 refl = scale(lighting_from(c, np, norigin, nx, ny, p, V(mag, mag, mag), lightPos), occ);
+		sum = add(sum, lighting_from(c, p, cell.origin, (uint32_t)cell.cx, (uint32_t)cell.cy, cam, refl, np));
+	}
+	return sum;
 }
 
 typedef struct { float r, g, b, a, depth; int shadow_ray; } Sample;
@@ -305,6 +359,11 @@ static Sample shade_sample(const Ctx *c, float vu, float vv)
 			{
 				const v3 lit = lighting_at(c, p, cell, cam);
 				s.r = occ * lit.x; s.g = occ * lit.y; s.b = occ * lit.z;
+				if (c->indirect) /* the term of :424 */
+				{
+					const v3 ind = indirect_lighting(c, p, cell, cam);
+					s.r += ind.x; s.g += ind.y; s.b += ind.z;
+				}
 			}
 			s.shadow_ray = 1;
 		}
@@ -327,10 +386,10 @@ static const float kSub4[4][2] = { { 0.25f, 0.25f }, { 0.75f, 0.25f }, { 0.25f, 
 /* Outputs as float: light[W*H*4] (linear rgb, a), depth[W*H*2] (depth of sub-sample 0, 1), presentation[W*H*4]
  * (pow(rgb, 1/gamma), a). spp is 1 (pixel centre) or 4 (2x2 stratified). Returns shadow rays traced, or <0. */
 static int64_t render_impl(const uint32_t *cells, uint32_t G, const float *uniforms, uint32_t W, uint32_t H, uint32_t spp,
-                           float *light, float *depth, float *presentation, uint32_t y_begin, uint32_t y_end, int legacy)
+                           float *light, float *depth, float *presentation, uint32_t y_begin, uint32_t y_end, int legacy, int indirect)
 {
 	if (!cells || !uniforms || G == 0 || (!legacy && (G % 32u)) || (spp != 1 && spp != 4)) return -1;
-	Ctx c = { cells, G, uniforms, (float)(1.0 / tan(37.5 * 3.14159265359 / 180.0)), legacy };
+	Ctx c = { cells, G, uniforms, (float)(1.0 / tan(37.5 * 3.14159265359 / 180.0)), legacy, indirect };
 	int64_t shadow = 0;
 	if (y_end > H) y_end = H;
 #ifdef _OPENMP
@@ -367,7 +426,14 @@ static int64_t render_impl(const uint32_t *cells, uint32_t G, const float *unifo
 int64_t ca3d_oracle_render(const uint32_t *cells, uint32_t G, const float *uniforms, uint32_t W, uint32_t H, uint32_t spp,
                            float *light, float *depth, float *presentation, uint32_t y_begin, uint32_t y_end)
 {
-	return render_impl(cells, G, uniforms, W, H, spp, light, depth, presentation, y_begin, y_end, 0);
+	return render_impl(cells, G, uniforms, W, H, spp, light, depth, presentation, y_begin, y_end, 0, 0);
+}
+
+/* the same frame with the reference's one-bounce neighbour lighting switched on (:307-377, call site :424) */
+int64_t ca3d_oracle_render_indirect(const uint32_t *cells, uint32_t G, const float *uniforms, uint32_t W, uint32_t H, uint32_t spp,
+                                    float *light, float *depth, float *presentation, uint32_t y_begin, uint32_t y_end)
+{
+	return render_impl(cells, G, uniforms, W, H, spp, light, depth, presentation, y_begin, y_end, 0, 1);
 }
 
 /* The legacy renderer (shaders/pathtraced_fragment.wgsl): same converged-frame definition over the one-u32-per-cell
@@ -375,7 +441,7 @@ int64_t ca3d_oracle_render(const uint32_t *cells, uint32_t G, const float *unifo
 int64_t ca3d_oracle_render_legacy(const uint32_t *cells, uint32_t G, const float *uniforms, uint32_t W, uint32_t H, uint32_t spp,
                                   float *light, float *depth, float *presentation, uint32_t y_begin, uint32_t y_end)
 {
-	return render_impl(cells, G, uniforms, W, H, spp, light, depth, presentation, y_begin, y_end, 1);
+	return render_impl(cells, G, uniforms, W, H, spp, light, depth, presentation, y_begin, y_end, 1, 0);
 }
 
 /* Independent visibility check for small grids: nearest passing visible cube among ALL alive cells. Returns the
@@ -384,7 +450,7 @@ int64_t ca3d_oracle_render_legacy(const uint32_t *cells, uint32_t G, const float
 float ca3d_oracle_primary_bruteforce(const uint32_t *cells, uint32_t G, const float *uniforms, uint32_t W, uint32_t H,
                                      uint32_t px, uint32_t py, int64_t *hit_cell)
 {
-	Ctx c = { cells, G, uniforms, (float)(1.0 / tan(37.5 * 3.14159265359 / 180.0)), 0 };
+	Ctx c = { cells, G, uniforms, (float)(1.0 / tan(37.5 * 3.14159265359 / 180.0)), 0, 0 };
 	const float *view = uniforms + U_VIEW;
 	const v3 cam = V(view[12], view[13], view[14]);
 	const float vu = ((float)px + 0.5f) / (float)W, vv = 1.0f - ((float)py + 0.5f) / (float)H;
@@ -636,7 +702,7 @@ int ca3d_oracle_render_frame(const uint32_t *cells, uint32_t G, const float *uni
                              const float *prev_light, const float *prev_depth, float *light, float *depth, float *presentation)
 {
 	if (!cells || !uniforms || G == 0 || (G % 32u)) return -1;
-	Ctx c = { cells, G, uniforms, (float)(1.0 / tan(37.5 * 3.14159265359 / 180.0)), 0 };
+	Ctx c = { cells, G, uniforms, (float)(1.0 / tan(37.5 * 3.14159265359 / 180.0)), 0, 0 };
 #ifdef _OPENMP
 #pragma omp parallel for schedule(dynamic, 4)
 #endif

@@ -148,7 +148,7 @@ def fill(n_words, seed=0xCA3D0001, and_rounds=0):
     return out
 
 
-def render(cells, G, uniforms, W, H, spp=1, rows=None, legacy=False):
+def render(cells, G, uniforms, W, H, spp=1, rows=None, legacy=False, indirect=False):
     """Oracle frame: (light f32[H,W,4], depth f32[H,W,2], presentation f32[H,W,4], shadow_rays)."""
     c, cp = _u32(cells)
     u = np.ascontiguousarray(uniforms, dtype=np.float32)
@@ -156,7 +156,7 @@ def render(cells, G, uniforms, W, H, spp=1, rows=None, legacy=False):
     depth = np.zeros((H, W, 2), dtype=np.float32)
     pres = np.zeros((H, W, 4), dtype=np.float32)
     y0, y1 = rows if rows else (0, H)
-    fn = lib().ca3d_oracle_render_legacy if legacy else lib().ca3d_oracle_render
+    fn = lib().ca3d_oracle_render_legacy if legacy else (lib().ca3d_oracle_render_indirect if indirect else lib().ca3d_oracle_render)
     fn.restype = C.c_int64
     n = fn(cp, C.c_uint32(G), u.ctypes.data_as(C.POINTER(C.c_float)), C.c_uint32(W), C.c_uint32(H), C.c_uint32(spp),
            light.ctypes.data_as(C.POINTER(C.c_float)), depth.ctypes.data_as(C.POINTER(C.c_float)),

@@ -144,6 +144,32 @@ def test_full_hd_band_at_512(eng):
     _compare(eng, cells, G, host.uniform_block(W, H, host.orbit_camera()), W, H, 4, rows=(520, 544))
 
 
+def test_indirect_lighting_mode(eng):
+    """The reference's calculateIndirectLighting (pathtraced_fragment_clustered.wgsl:307-377; its call is commented out at
+    :424): an optional mode here ("render_indirect"), same tolerance as the direct frame, and it must change the frame
+    (a dense volume has lit neighbours next to most visible faces)."""
+    G, W, H = 64, 320, 180
+    cells = host.random_fill(host.words_per_buffer(G), seed=9, and_rounds=2)
+    u = host.uniform_block(W, H, host.orbit_camera())
+    eng.configure(G)
+    set_rules(eng, rules("default"))
+    eng.upload_state(cells)
+    _, direct, _ = eng.render(u, W, H, 1)
+    eng.set_option("render_indirect", 1)
+    try:
+        for spp in (1, 4):
+            pres, light, depth = eng.render(u, W, H, spp)
+            olight, odepth, opres, _ = ol.render(cells, G, u, W, H, spp, indirect=True)
+            ok = np.abs(light.astype(np.float32)[..., :3] - olight[..., :3]).max(-1) <= 2e-3
+            ok &= np.abs(pres.astype(np.float32) - np.rint(np.clip(opres, 0, 1) * 255.0)).max(-1) <= 1.0
+            assert ok.mean() >= 0.999, ok.mean()
+            if spp == 1:
+                changed = np.abs(light.astype(np.float32)[..., :3] - direct.astype(np.float32)[..., :3]).max(-1) > 4e-3
+                assert changed.mean() > 0.02, changed.mean()
+    finally:
+        eng.set_option("render_indirect", 0)
+
+
 def test_4k_band_at_512(eng):
     # BASELINE config 5's render leg: 3840x2160 @ 4 spp (fragment_main, pathtraced_fragment_clustered.wgsl:800-890,
     # once per pixel of a 4K target); the oracle renders a 16-row band through the middle of the volume's silhouette.

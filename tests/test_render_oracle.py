@@ -129,3 +129,20 @@ def test_literal_frames_converge_to_the_exact_walk_frame():
     assert close[lit].mean() > 0.85
     hit = limit_depth[..., 0] > 0
     assert (np.abs(depth[..., 0] - limit_depth[..., 0])[hit] < 2.0 / G).mean() > 0.9
+
+
+def test_indirect_lighting_only_adds_light():
+    """calculateIndirectLighting (wgsl :307-377): a sum of clamped-non-negative terms on top of the direct frame — no pixel
+    gets darker, pixels next to lit neighbours get brighter, depth is untouched; with no neighbours (single cell) it is
+    the direct frame."""
+    G, W, H = 32, 96, 54
+    u = host.uniform_block(W, H, host.orbit_camera())
+    cells = host.random_fill(host.words_per_buffer(G), seed=4, and_rounds=2)
+    l0, d0, _, _ = ol.render(cells, G, u, W, H, 1)
+    l1, d1, _, _ = ol.render(cells, G, u, W, H, 1, indirect=True)
+    np.testing.assert_array_equal(d0, d1)
+    assert (l1[..., :3] >= l0[..., :3] - 1e-7).all() and (l1[..., :3] > l0[..., :3] + 1e-3).mean() > 0.01
+    single = host.cells_to_words(G, [(15, 15, 15)])
+    a, _, _, _ = ol.render(single, G, u, W, H, 1)
+    b, _, _, _ = ol.render(single, G, u, W, H, 1, indirect=True)
+    np.testing.assert_array_equal(a, b)

@@ -11,6 +11,7 @@ CA3D_OK = 0
 LAYOUT_PACKED32 = 0
 LAYOUT_UNPACKED = 1
 LUT_LEN = 81
+COMM_ID_BYTES = 128
 
 SLAB_SEND_LOW, SLAB_SEND_HIGH, SLAB_RECV_LOW, SLAB_RECV_HIGH, SLAB_OWNED = range(5)
 SLAB_PHASE_ALL, SLAB_PHASE_EDGES, SLAB_PHASE_INTERIOR = range(3)
@@ -64,6 +65,12 @@ SYMBOLS = [
     ("ca3d_slab_step", C.c_int, [_H, C.c_uint32]),
     ("ca3d_slab_step_phase", C.c_int, [_H, C.c_uint32, C.c_int]),
     ("ca3d_slab_region", C.c_int, [_H, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    ("ca3d_comm_unique_id", C.c_int, [C.c_void_p]),
+    ("ca3d_slab_comm_init", C.c_int, [_H, C.c_void_p, C.c_int, C.c_int]),
+    ("ca3d_slab_run", C.c_int, [_H, C.c_uint32, C.c_int]),
+    ("ca3d_slab_exchange", C.c_int, [_H]),
+    ("ca3d_slab_gather", C.c_int, [_H, _H]),
+    ("ca3d_render_target", C.c_int, [_H, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     ("ca3d_synchronize", C.c_int, [_H]),
     ("ca3d_set_stream", C.c_int, [_H, C.c_void_p]),
     ("ca3d_use_own_stream", C.c_int, [_H]),

@@ -1,6 +1,7 @@
 // C-ABI layer (include/ca3d.h): engine object, device buffers, ping-pong stepping, slab sub-steps, stats.
 // Replaces the WebGPU calls of main_pathtraced.js listed per entry point in the header. No CPU fallback.
 #include <cstdarg>
+#include <dlfcn.h>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -99,6 +100,16 @@ struct ca3d_engine
 	uint32_t res_min = 8;                 // shorter batches take the per-step kernels
 	uint32_t res_timeout_ticks = 20000000; // 200 ms of s_memrealtime per wait
 
+	// halo transport inside the engine (RCCL, loaded on first use): communicator over the ranks of the slab chain, a second
+	// stream so that an exchange can run under the interior phase, the events that order the two
+	void *comm = nullptr; // ncclComm_t
+	int comm_rank = 0, comm_world = 0;
+	hipStream_t comm_stream = nullptr;
+	hipEvent_t ev_edges = nullptr, ev_comm = nullptr;
+	bool ghosts_valid = false; // the ghost planes hold the neighbours' planes of the current step
+	int comm_graph = 0;        // capture batch + exchange into one graph (unsplit batches)
+	std::map<uint64_t, hipGraphExec_t> comm_graphs;
+
 	ca3d_stats stats{};
 	const char *kernel_name = "";
 
@@ -131,6 +142,8 @@ void drop_graph(ca3d_engine *h)
 	h->step_graphs.clear();
 	for (auto &kv : h->slab_graphs) hipGraphExecDestroy(kv.second);
 	h->slab_graphs.clear();
+	for (auto &kv : h->comm_graphs) hipGraphExecDestroy(kv.second);
+	h->comm_graphs.clear();
 }
 
 void free_render_targets(ca3d_engine *h)
@@ -173,6 +186,7 @@ void free_buffers(ca3d_engine *h)
 	h->step = 0;
 	h->cur = 0;
 	h->pending_edges = 0; // an edge phase belongs to the state that has just gone
+	h->ghosts_valid = false;
 }
 
 int bind_device(ca3d_engine *h)
@@ -438,6 +452,86 @@ bool graphs_allowed(const ca3d_engine *h)
 	return h->use_graph && h->stream != nullptr && !(h->layout == CA3D_LAYOUT_UNPACKED && !h->binary_state);
 }
 
+// ---------------------------------------------------------------------------------------------- RCCL transport
+// librccl is loaded on first use (dlopen): single-GPU hosts and the Node.js addon never pay for it, and a process that
+// has torch's copy of librccl.so.1 loaded gets that same copy.
+typedef struct { char internal[128]; } ncclUniqueIdBytes; // ncclUniqueId (NCCL_UNIQUE_ID_BYTES)
+
+struct Rccl
+{
+	void *lib = nullptr;
+	int (*GetUniqueId)(void *) = nullptr;
+	int (*CommInitRank)(void **, int, ncclUniqueIdBytes, int) = nullptr;
+	int (*CommDestroy)(void *) = nullptr;
+	int (*GroupStart)() = nullptr;
+	int (*GroupEnd)() = nullptr;
+	int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
+	int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
+	int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+	const char *(*GetErrorString)(int) = nullptr;
+	std::string error;
+};
+
+Rccl &rccl()
+{
+	static Rccl r;
+	static bool tried = false;
+	if (tried) return r;
+	tried = true;
+	for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+	{
+		r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+		if (r.lib) break;
+	}
+	if (!r.lib) { r.error = std::string("librccl.so.1 could not be loaded: ") + dlerror(); return r; }
+	auto sym = [&](const char *n) { void *p = dlsym(r.lib, n); if (!p && r.error.empty()) r.error = std::string("librccl lacks ") + n; return p; };
+	r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
+	r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
+	r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+	r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+	r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+	r.Send = (decltype(r.Send))sym("ncclSend");
+	r.Recv = (decltype(r.Recv))sym("ncclRecv");
+	r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
+	r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+	return r;
+}
+
+#define NCCL_TRY(expr)                                                                                                   \
+	do                                                                                                                   \
+	{                                                                                                                    \
+		int r_ = (expr);                                                                                                 \
+		if (r_ != 0) return fail(CA3D_ERR_DEVICE, "%s: %s", #expr, rccl().GetErrorString ? rccl().GetErrorString(r_) : "?"); \
+	} while (0)
+
+constexpr int kNcclUint32 = 3; // ncclUint32 (rccl.h)
+
+// Refresh the ghost planes of the buffer ca3d_slab_region refers to, on stream `s`: the same plan as slab.halo_plan —
+// packed: open at the bottom (z == -1 is dead), closed at the top (plane G wraps to plane 0); unpacked: a ring.
+int comm_exchange(ca3d_engine *h, hipStream_t s)
+{
+	Rccl &r = rccl();
+	const int P = h->comm_world, me = h->comm_rank, below = (me + P - 1) % P, above = (me + 1) % P;
+	const bool ring = h->layout == CA3D_LAYOUT_UNPACKED, top = me == P - 1, bottom = me == 0;
+	void *p[4];
+	size_t bytes[4];
+	for (int region = 0; region < 4; region++)
+	{
+		int rc = ca3d_slab_region(h, region, &p[region], &bytes[region]);
+		if (rc) return rc;
+	}
+	const size_t n = bytes[0] / sizeof(uint32_t);
+	NCCL_TRY(r.GroupStart());
+	// sends low-then-high, receives high-then-low: the two messages a pair of ranks exchanges in one direction (world == 2)
+	// then match in order
+	NCCL_TRY(r.Send(p[CA3D_SLAB_SEND_LOW], n, kNcclUint32, below, h->comm, s));
+	if (ring || !top) NCCL_TRY(r.Send(p[CA3D_SLAB_SEND_HIGH], n, kNcclUint32, above, h->comm, s));
+	NCCL_TRY(r.Recv(p[CA3D_SLAB_RECV_HIGH], n, kNcclUint32, above, h->comm, s));
+	if (ring || !bottom) NCCL_TRY(r.Recv(p[CA3D_SLAB_RECV_LOW], n, kNcclUint32, below, h->comm, s));
+	NCCL_TRY(r.GroupEnd());
+	return CA3D_OK;
+}
+
 } // namespace
 
 extern "C"
@@ -497,6 +591,10 @@ int ca3d_destroy(ca3d_t *h)
 	if (h->stream || h->own_stream) hipStreamSynchronize(h->stream);
 	free_buffers(h);
 	free_render_targets(h);
+	if (h->comm && rccl().CommDestroy) rccl().CommDestroy(h->comm);
+	if (h->ev_edges) hipEventDestroy(h->ev_edges);
+	if (h->ev_comm) hipEventDestroy(h->ev_comm);
+	if (h->comm_stream) hipStreamDestroy(h->comm_stream);
 	if (h->r_counters) hipFree(h->r_counters);
 	if (h->r_occ) hipFree(h->r_occ);
 	if (h->rev_start) hipEventDestroy(h->rev_start);
@@ -598,6 +696,7 @@ int ca3d_upload_state(ca3d_t *h, const uint32_t *words, size_t n_words)
 	h->step = 0;
 	h->cur = 0;
 	h->pending_edges = 0; // a restart between the two phases of a batch abandons the batch
+	h->ghosts_valid = false;
 	if (h->res_status_host && *h->res_status_host)
 	{
 		// a resident launch gave up earlier: clean mailboxes and status for whoever turns the path on again
@@ -708,7 +807,7 @@ int slab_batch(ca3d_engine *h, uint32_t n_steps, int phase)
 	// its low ghost.
 	const uint32_t lo_floor = (h->layout == CA3D_LAYOUT_PACKED32 && h->z0 == 0) ? K : 0u;
 	const bool splittable = h->nz + 2u > 2u * K + 2u * n; // interior non-empty in every sub-step
-	if (phase != CA3D_SLAB_PHASE_INTERIOR) HIP_TRY(hipEventRecord(h->ev_start, h->stream));
+	if (phase != CA3D_SLAB_PHASE_INTERIOR && h->want_stats) HIP_TRY(hipEventRecord(h->ev_start, h->stream));
 	int what = phase; // what this call enqueues
 	if (!splittable)
 	{
@@ -768,8 +867,9 @@ int slab_batch(ca3d_engine *h, uint32_t n_steps, int phase)
 	h->pending_edges = 0;
 	h->step += n;
 	h->cur = (h->cur + n) & 1u;
-	HIP_TRY(hipEventRecord(h->ev_stop, h->stream));
-	h->ev_valid = true;
+	h->ghosts_valid = false; // the caller (or ca3d_slab_run) refreshes them
+	if (h->want_stats) HIP_TRY(hipEventRecord(h->ev_stop, h->stream));
+	h->ev_valid = h->want_stats != 0;
 	h->stats.steps = n;
 	h->stats.kernel_launches = phase == CA3D_SLAB_PHASE_ALL || !splittable ? n : 2u * n;
 	h->stats.cell_steps = (double)n * h->cells_per_plane() * h->nz; // owned cells only: ghost recompute is overhead
@@ -805,6 +905,149 @@ int ca3d_slab_region(ca3d_t *h, int region, void **device_ptr, size_t *n_bytes)
 	}
 	*device_ptr = base + first * pw;
 	*n_bytes = count * pw * sizeof(uint32_t);
+	return CA3D_OK;
+}
+
+int ca3d_comm_unique_id(void *id)
+{
+	if (!id) return fail(CA3D_ERR_INVALID_ARGUMENT, "id is NULL");
+	Rccl &r = rccl();
+	if (!r.error.empty()) return fail(CA3D_ERR_UNSUPPORTED, "%s", r.error.c_str());
+	NCCL_TRY(r.GetUniqueId(id));
+	return CA3D_OK;
+}
+
+int ca3d_slab_comm_init(ca3d_t *h, const void *id, int rank, int world)
+{
+	if (!h || !id) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL argument");
+	if (world < 1 || rank < 0 || rank >= world) return fail(CA3D_ERR_INVALID_ARGUMENT, "rank %d of %d", rank, world);
+	Rccl &r = rccl();
+	if (!r.error.empty()) return fail(CA3D_ERR_UNSUPPORTED, "%s", r.error.c_str());
+	int rc = bind_device(h);
+	if (rc) return rc;
+	if (h->comm) { r.CommDestroy(h->comm); h->comm = nullptr; }
+	ncclUniqueIdBytes uid;
+	memcpy(&uid, id, sizeof uid);
+	NCCL_TRY(r.CommInitRank(&h->comm, world, uid, rank));
+	h->comm_rank = rank;
+	h->comm_world = world;
+	if (!h->comm_stream)
+	{
+		HIP_TRY(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+		HIP_TRY(hipEventCreateWithFlags(&h->ev_edges, hipEventDisableTiming));
+		HIP_TRY(hipEventCreateWithFlags(&h->ev_comm, hipEventDisableTiming));
+	}
+	h->ghosts_valid = false;
+	return CA3D_OK;
+}
+
+int ca3d_slab_exchange(ca3d_t *h)
+{
+	int rc = check_ready(h);
+	if (rc) return rc;
+	if (!h->slab || !h->comm) return fail(CA3D_ERR_NOT_CONFIGURED, "engine is not a slab with a communicator (ca3d_configure_slab, ca3d_slab_comm_init)");
+	rc = bind_device(h);
+	if (rc) return rc;
+	rc = comm_exchange(h, h->stream);
+	if (rc == CA3D_OK) h->ghosts_valid = true;
+	return rc;
+}
+
+int ca3d_slab_run(ca3d_t *h, uint32_t n_steps, int overlap)
+{
+	int rc = check_ready(h);
+	if (rc) return rc;
+	if (!h->slab || !h->comm) return fail(CA3D_ERR_NOT_CONFIGURED, "engine is not a slab with a communicator (ca3d_configure_slab, ca3d_slab_comm_init)");
+	if (h->pending_edges) return fail(CA3D_ERR_INVALID_ARGUMENT, "an edge phase is pending: finish it with the interior phase");
+	rc = bind_device(h);
+	if (rc) return rc;
+	if (!h->ghosts_valid)
+	{
+		rc = comm_exchange(h, h->stream);
+		if (rc) return rc;
+		h->ghosts_valid = true;
+	}
+	const bool keep_stats = h->want_stats != 0;
+	hipEvent_t first = nullptr;
+	uint32_t left = n_steps;
+	uint64_t launches = 0;
+	if (keep_stats && left) HIP_TRY(hipEventRecord(h->ev_start, h->stream));
+	h->want_stats = 0; // the batches below would each re-record the pair
+	auto restore = [&]() { h->want_stats = keep_stats ? 1 : 0; };
+	while (left)
+	{
+		const uint32_t k = left < h->ghost ? left : h->ghost;
+		if (overlap)
+		{
+			// edge zones -> their planes travel on the communication stream while the interior runs -> the next batch
+			// (and anything else on the engine's stream) waits for the receives
+			rc = slab_batch(h, k, CA3D_SLAB_PHASE_EDGES);
+			if (rc) { restore(); return rc; }
+			HIP_TRY(hipEventRecord(h->ev_edges, h->stream));
+			HIP_TRY(hipStreamWaitEvent(h->comm_stream, h->ev_edges, 0));
+			rc = comm_exchange(h, h->comm_stream);
+			if (rc) { restore(); return rc; }
+			HIP_TRY(hipEventRecord(h->ev_comm, h->comm_stream));
+			rc = slab_batch(h, k, CA3D_SLAB_PHASE_INTERIOR);
+			if (rc) { restore(); return rc; }
+			HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_comm, 0));
+		}
+		else
+		{
+			rc = slab_batch(h, k, CA3D_SLAB_PHASE_ALL);
+			if (rc) { restore(); return rc; }
+			rc = comm_exchange(h, h->stream);
+			if (rc) { restore(); return rc; }
+		}
+		h->ghosts_valid = true;
+		launches += h->stats.kernel_launches;
+		left -= k;
+	}
+	restore();
+	if (keep_stats && n_steps)
+	{
+		HIP_TRY(hipEventRecord(h->ev_stop, h->stream));
+		h->ev_valid = true;
+		h->stats.steps = n_steps;
+		h->stats.kernel_launches = launches;
+		h->stats.cell_steps = (double)n_steps * h->cells_per_plane() * h->nz;
+		h->stats.algorithmic_bytes = h->stats.cell_steps * h->bytes_per_cell_step();
+	}
+	(void)first;
+	return CA3D_OK;
+}
+
+int ca3d_slab_gather(ca3d_t *h, ca3d_t *full)
+{
+	if (!h || !full) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL argument");
+	if (!h->slab || !h->comm || !h->has_state) return fail(CA3D_ERR_NOT_CONFIGURED, "engine is not a slab with a communicator and a state");
+	if (!full->configured || full->slab || full->G != h->G || full->layout != h->layout || full->device != h->device)
+		return fail(CA3D_ERR_INVALID_ARGUMENT, "the target must be a full-grid engine of the same grid, layout and device");
+	if ((size_t)h->nz * h->comm_world != h->G) return fail(CA3D_ERR_UNSUPPORTED, "the slabs must split the grid evenly");
+	int rc = bind_device(h);
+	if (rc) return rc;
+	void *owned;
+	size_t bytes;
+	rc = ca3d_slab_region(h, CA3D_SLAB_OWNED, &owned, &bytes);
+	if (rc) return rc;
+	// ncclAllGather straight between the engines' device buffers, in rank (= z) order, on the slab engine's stream
+	NCCL_TRY(rccl().AllGather(owned, full->buf[full->cur], bytes / sizeof(uint32_t), kNcclUint32, h->comm, h->stream));
+	full->has_state = true;
+	return CA3D_OK;
+}
+
+int ca3d_render_target(ca3d_t *h, int which, void **device_ptr, size_t *n_bytes)
+{
+	if (!h || !device_ptr || !n_bytes) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL argument");
+	if (!h->r_present) return fail(CA3D_ERR_NOT_CONFIGURED, "ca3d_render has not been called yet");
+	const size_t px = (size_t)h->rw * h->rh;
+	switch (which)
+	{
+	case 0: *device_ptr = h->r_present; *n_bytes = px * 4; break;
+	case 1: *device_ptr = h->r_light[h->r_swap ^ 1]; *n_bytes = px * 8; break; // the surfaces the LAST frame was written to
+	case 2: *device_ptr = h->r_depth[h->r_swap ^ 1]; *n_bytes = px * 4; break;
+	default: return fail(CA3D_ERR_INVALID_ARGUMENT, "target must be 0 (presentation), 1 (light) or 2 (depth)");
+	}
 	return CA3D_OK;
 }
 

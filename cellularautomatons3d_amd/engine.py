@@ -130,6 +130,36 @@ class Engine:
         _capi.check(self._lib.ca3d_slab_region(self._h, region, C.byref(p), C.byref(n)))
         return int(p.value), int(n.value)
 
+    # -- RCCL transport inside the engine (slab mode) ------------------------------------------------------
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """ncclGetUniqueId: rank 0 creates it and hands it to the other ranks (torch.distributed, a socket ...)."""
+        buf = C.create_string_buffer(_capi.COMM_ID_BYTES)
+        _capi.check(_capi.load().ca3d_comm_unique_id(buf))
+        return buf.raw
+
+    def slab_comm_init(self, unique_id: bytes, rank: int, world: int) -> None:
+        if len(unique_id) != _capi.COMM_ID_BYTES:
+            raise ValueError("the communicator id holds 128 bytes")
+        _capi.check(self._lib.ca3d_slab_comm_init(self._h, C.c_char_p(unique_id), rank, world))
+
+    def slab_run(self, n_steps: int, overlap: bool = False) -> None:
+        """n steps in batches of <= ghost sub-steps, the halo exchange (RCCL) between them — under the interior phase
+        when `overlap`. Everything is enqueued by this one call."""
+        _capi.check(self._lib.ca3d_slab_run(self._h, n_steps, 1 if overlap else 0))
+
+    def slab_exchange(self) -> None:
+        _capi.check(self._lib.ca3d_slab_exchange(self._h))
+
+    def slab_gather(self, full: "Engine") -> None:
+        """ncclAllGather of every rank's owned planes into `full`'s current buffer (a full-grid engine, same device)."""
+        _capi.check(self._lib.ca3d_slab_gather(self._h, full._h))
+
+    def render_target(self, which: int = 0):
+        p, n = C.c_void_p(), C.c_size_t()
+        _capi.check(self._lib.ca3d_render_target(self._h, which, C.byref(p), C.byref(n)))
+        return int(p.value), int(n.value)
+
     def device_buffer(self, which: int):
         p, n = C.c_void_p(), C.c_size_t()
         _capi.check(self._lib.ca3d_device_buffer(self._h, which, C.byref(p), C.byref(n)))

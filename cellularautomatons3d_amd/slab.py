@@ -233,6 +233,40 @@ class SlabEngine:
         self.engine.close()
 
 
+class NativeSlabEngine(SlabEngine):
+    """`SlabEngine` with the halo exchange inside the engine: libca3d.so drives RCCL itself (ncclSend / ncclRecv grouped
+    on the engine's stream, or on its second stream under the interior phase), so a whole `run(n)` is ONE call into the
+    library — no Python, no torch.distributed bookkeeping per batch. torch.distributed only carries the 128-byte
+    communicator id from rank 0 to the others (world > 1)."""
+
+    native = True
+
+    def __init__(self, grid_size: int, rank: int, world: int, ghost: int, layout: int = LAYOUT_PACKED32, device: int = 0,
+                 group=None, overlap="auto", unique_id: Optional[bytes] = None):
+        super().__init__(grid_size, rank, world, ghost, layout=layout, device=device, group=group, overlap=overlap)
+        from .engine import Engine
+
+        if unique_id is None:
+            unique_id = Engine.comm_unique_id() if rank == 0 else b""
+            if world > 1:
+                import torch.distributed as dist
+
+                box = [unique_id]
+                dist.broadcast_object_list(box, src=0, group=group)
+                unique_id = box[0]
+        self.engine.slab_comm_init(unique_id, rank, world)
+
+    def upload_state(self, owned_words) -> None:
+        self.engine.upload_state(owned_words)
+
+    def run(self, n_steps: int) -> None:
+        self.engine.slab_run(n_steps, self.overlap)
+
+    def exchange(self, wait: bool = True):
+        self.engine.slab_exchange()
+        return []
+
+
 def band_rows(height: int, world: int, rank: int) -> Tuple[int, int]:
     """Image rows [begin, end) rank renders when `world` GPUs share a frame: bands of whole 16-row tiles, as even as
     the tile count allows (ranks beyond the tile count get an empty band)."""
@@ -272,6 +306,9 @@ class SlabRenderer:
         import torch.distributed as dist
 
         torch = self._torch
+        if getattr(self.se, "native", False):
+            self.se.engine.slab_gather(self.full)  # ncclAllGather inside the engine, on its stream
+            return
         owned = self.se._current_regions()["owned"]
         with torch.cuda.stream(self.se.stream):
             if self.se.world == 1 and not self.se.loopback:
@@ -290,16 +327,42 @@ class SlabRenderer:
 
         torch = self._torch
         self.gather_volume()
-        y0, y1 = band_rows(height, self.se.world, self.se.rank)
-        band = np.zeros((0, width, 4), dtype=np.uint8)
+        world, rank = self.se.world, self.se.rank
+        y0, y1 = band_rows(height, world, rank)
+        if world == 1 or self.se.host_staging:
+            # one rank, or the rehearsal transport (gloo): bands go through host memory
+            band = np.zeros((0, width, 4), dtype=np.uint8)
+            if y1 > y0:
+                pres, _, _ = self.full.render(uniforms, width, height, spp, rows=(y0, y1))
+                band = np.ascontiguousarray(pres[y0:y1])
+            if world == 1:
+                return band
+            bands = [None] * world if rank == 0 else None
+            dist.gather_object(band, bands, dst=0, group=self.group)
+            return np.concatenate(bands, axis=0) if rank == 0 else None
+        # RCCL: the bands travel between the GPUs as RGBA8 rows (a gather of equal windows: every rank sends the same
+        # number of rows, starting at its band, clamped so that the window stays inside the target), no pickled host objects
+        rows = max(band_rows(height, world, k)[1] - band_rows(height, world, k)[0] for k in range(world))
+        start = min(y0, height - rows)
         if y1 > y0:
-            pres, _, _ = self.full.render(uniforms, width, height, spp, rows=(y0, y1))
-            band = np.ascontiguousarray(pres[y0:y1])
-        if self.se.world == 1:
-            return band
-        bands = [None] * self.se.world if self.se.rank == 0 else None
-        dist.gather_object(band, bands, dst=0, group=self.group)
-        return np.concatenate(bands, axis=0) if self.se.rank == 0 else None
+            self.full.render(uniforms, width, height, spp, readback=False, rows=(y0, y1))
+            ptr, nbytes = self.full.render_target(0)
+            target = device_tensor(ptr, nbytes, self.device).view(torch.uint8).view(height, width * 4)
+            mine = target[start:start + rows].contiguous()
+        else:
+            mine = torch.zeros((rows, width * 4), dtype=torch.uint8, device=f"cuda:{self.device}")
+        parts = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
+        with torch.cuda.stream(self.se.stream):
+            dist.gather(mine, parts, dst=0, group=self.group)
+        if rank != 0:
+            return None
+        frame = np.empty((height, width, 4), dtype=np.uint8)
+        for k in range(world):
+            b0, b1 = band_rows(height, world, k)
+            s0 = min(b0, height - rows)
+            if b1 > b0:
+                frame[b0:b1] = parts[k].cpu().numpy().reshape(rows, width, 4)[b0 - s0:b1 - s0]
+        return frame
 
     def close(self) -> None:
         self.full.close()

@@ -133,6 +133,32 @@ enum ca3d_slab_region_id
  * the buffer that batch ends in). */
 int ca3d_slab_region(ca3d_t *h, int region, void **device_ptr, size_t *n_bytes);
 
+/*
+ * Halo transport inside the engine: RCCL send / receive over xGMI between the ranks of a Z-slab chain, one process per
+ * GPU (no reference counterpart). librccl is loaded on first use. Bootstrap: rank 0 calls
+ * ca3d_comm_unique_id and hands the 128 bytes to the other ranks by any means (torch.distributed, MPI, a socket, a
+ * file); every rank then calls ca3d_slab_comm_init on its slab engine (collective: all ranks must call it).
+ *   ca3d_slab_run(n, overlap)  n CA steps in batches of <= ghost sub-steps with the ghost planes refreshed between
+ *                              batches; overlap != 0: the edge zones of a batch first, their planes travel on a second
+ *                              stream while the interior runs (BASELINE configs[4]). Asynchronous; everything is
+ *                              enqueued by this one call (no per-batch host work beyond the launches).
+ *   ca3d_slab_exchange         one refresh of the ghost planes of the current state (ca3d_slab_run does it by itself)
+ *   ca3d_slab_gather           ncclAllGather of every rank's owned planes into the current buffer of `full`, a full-grid
+ *                              engine on the same device: the volume a renderer needs (shadow rays cross slabs)
+ * The chain follows the kernel's boundary: packed — open at the bottom, closed at the top; unpacked — a ring.
+ */
+#define CA3D_COMM_ID_BYTES 128
+int ca3d_comm_unique_id(void *id_bytes);
+int ca3d_slab_comm_init(ca3d_t *h, const void *id_bytes, int rank, int world);
+int ca3d_slab_run(ca3d_t *h, uint32_t n_steps, int overlap);
+int ca3d_slab_exchange(ca3d_t *h);
+int ca3d_slab_gather(ca3d_t *h, ca3d_t *full);
+
+/* Device pointer + byte size of the targets of the last ca3d_render call: 0 presentation RGBA8, 1 light RGBA16F,
+ * 2 depth RG16F (row-major, top row first) — e.g. to gather the bands of a frame shared between GPUs without a
+ * round trip through the host. */
+int ca3d_render_target(ca3d_t *h, int which, void **device_ptr, size_t *n_bytes);
+
 int ca3d_synchronize(ca3d_t *h);
 
 /* Interop: run on a caller-owned hipStream_t (e.g. torch's current stream). NULL is HIP's legacy default stream

@@ -186,6 +186,37 @@ def test_slab_engine_over_rccl_loopback(overlap):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("overlap", [True, False])
+@pytest.mark.parametrize("name,G,K,steps", [("default", 256, 4, 14), ("clustered", 256, 3, 7), ("default", 1024, 16, 33)])
+def test_native_rccl_transport_loopback(overlap, name, G, K, steps):
+    """The halo exchange inside the engine (ca3d_slab_comm_init / ca3d_slab_run: libca3d.so loads librccl and issues the
+    grouped ncclSend / ncclRecv itself) on a one-rank communicator: the wrap message (rank 0's first planes -> its own high
+    ghost) goes through RCCL on the engine's memory, unsplit and under the interior phase; then ncclAllGather of the
+    volume into a full-grid engine (ca3d_slab_gather)."""
+    from cellularautomatons3d_amd import Engine
+
+    r = rules(name)
+    full = host.random_fill(host.words_per_buffer(G), seed=93)
+    se = slab.NativeSlabEngine(G, 0, 1, ghost=K, device=0, overlap=overlap)
+    try:
+        set_rules(se.engine, r)
+        se.upload_state(full)
+        se.run(steps)
+        se.run(1)
+        se.engine.synchronize()
+        want = ol.packed_run(G, full, r, steps + 1)
+        assert np.array_equal(se.engine.read_state(), want)
+        with Engine(0) as vol:
+            vol.configure(G)
+            vol.set_rule_strings()
+            vol.upload_state(np.zeros(host.words_per_buffer(G), dtype=np.uint32))
+            se.engine.slab_gather(vol)
+            se.engine.synchronize()
+            assert np.array_equal(vol.read_state(), want)
+    finally:
+        se.close()
+
+
 def test_slab_renderer_single_rank_equals_plain_render():
     """SlabRenderer (volume gather + band render + band gather) on a one-rank chain: the frame of the stepped slab
     state equals the frame a plain engine renders of the same state."""

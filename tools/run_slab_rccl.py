@@ -19,6 +19,8 @@ ap.add_argument("--grid", type=int, default=1024)
 ap.add_argument("--planes", type=int, default=128, help="owned planes of the slab (the grid is NOT covered: timing only)")
 ap.add_argument("--ghost", type=int, default=16)
 ap.add_argument("--batches", type=int, default=100)
+ap.add_argument("--native", type=int, default=0, help="1: the exchange inside the engine (ca3d_slab_run) instead of torch.distributed")
+ap.add_argument("--rule", default="default")
 a = ap.parse_args()
 s = socket.socket()
 s.bind(("127.0.0.1", 0))
@@ -27,12 +29,19 @@ s.close()
 dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 G = a.grid
 for overlap in (False, True):
-    se = slab.SlabEngine(G, 0, 1, ghost=a.ghost, device=0, overlap=overlap, loopback=True)
+    if a.native:
+        se = slab.NativeSlabEngine(G, 0, 1, ghost=a.ghost, device=0, overlap=overlap)
+    else:
+        se = slab.SlabEngine(G, 0, 1, ghost=a.ghost, device=0, overlap=overlap, loopback=True)
     # shrink the slab to one rank's share: same kernels and message sizes as rank k of G / planes ranks
     se.engine.configure_slab(G, 0, a.planes, a.ghost)
     se.z0, se.nz = 0, a.planes
-    se.engine.set_rule_strings()
+    if a.rule == "clustered":
+        se.engine.set_rule_strings("moore", "5-7", "4-7", "4", "3-5", "3", "2-4")
+    else:
+        se.engine.set_rule_strings()
     se.engine.set_stream(se.stream.cuda_stream)
+    se.engine.set_option("stats", 0)
     se.upload_state(host.random_fill((G // 32) * G * a.planes))
     se.run(a.ghost * 5)
     torch.cuda.synchronize()
@@ -41,7 +50,7 @@ for overlap in (False, True):
     t_host = time.perf_counter() - t0
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(f"slab {a.planes} planes of {G}^2, ghost {a.ghost}, RCCL loopback, overlap {overlap}: {dt / (a.ghost * a.batches) * 1e6:.2f} us/step "
+    print(f"slab {a.planes} planes of {G}^2, ghost {a.ghost}, RCCL loopback ({'engine' if a.native else 'torch'} transport), overlap {overlap}: {dt / (a.ghost * a.batches) * 1e6:.2f} us/step "
           f"({dt / a.batches * 1e6:.1f} us per batch incl. one exchange of 2 x {a.ghost * G * G // 8 / 2**20:.1f} MiB; host enqueue {t_host / a.batches * 1e6:.1f} us per batch)")
     se.close()
 dist.destroy_process_group()

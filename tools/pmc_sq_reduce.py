@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Per-kernel means of a `rocprofv3 --pmc SQ_...` pass: tools/pmc_sq_reduce.py DIR KERNEL_SUBSTR  -> JSON on stdout.
+SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md); ratios between them are unit-free."""
+import csv, glob, json, os, sys, collections
+
+d, kernel = sys.argv[1], sys.argv[2]
+acc = collections.defaultdict(list)
+vg = []
+for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+    with open(f, newline="") as fh:
+        for row in csv.DictReader(fh):
+            if kernel in row.get("Kernel_Name", ""):
+                acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
+                for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Grid_Size", "Workgroup_Size"):
+                    if k in row and row[k] not in ("", None):
+                        acc["_" + k].append(float(row[k]))
+out = {"kernel": kernel, "dispatches": max((len(v) for v in acc.values()), default=0)}
+for k, v in sorted(acc.items()):
+    out[k.lstrip("_")] = sum(v) / len(v)
+w = out.get("SQ_WAVES")
+if w:
+    for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU"):
+        if k in out:
+            out[k + "_per_wave"] = out[k] / w
+if out.get("SQ_WAVE_CYCLES"):
+    for k in ("SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY"):
+        if k in out:
+            out[k + "_frac_of_wave_cycles"] = out[k] / out["SQ_WAVE_CYCLES"]
+if out.get("SQ_THREAD_CYCLES_VALU") and out.get("SQ_ACTIVE_INST_VALU"):
+    out["VALUUtilization_pct"] = 100.0 * out["SQ_THREAD_CYCLES_VALU"] / (out["SQ_ACTIVE_INST_VALU"] * 64.0)
+print(json.dumps(out, indent=1))

@@ -29,11 +29,12 @@ eng.step(steps);
 eng.synchronize();
 const dt = Number(process.hrtime.bigint() - t0) / 1e9;
 const st = eng.stats();
-const launchUs = st.gpuMs * 1e3 / st.kernelLaunches;
+const launchUs = st.gpuMs * 1e3 / st.kernelLaunches; // the resident kernel runs the whole batch in one launch
+const stepUs = st.gpuMs * 1e3 / steps;
 const out = {
 	metric: `Gcells/s CA step at ${G}^3 (Node.js host)`, value: +(G ** 3 * steps / dt / 1e9).toFixed(3), unit: "Gcells/s", steps, warmup,
 	ms_per_step: +(dt * 1e3 / steps).toFixed(6), kernel: eng.info().kernelName, launch_us: +launchUs.toFixed(3),
-	roofline_frac: +((0.25 * G ** 3) / (launchUs * 1e-6) / 8e12).toFixed(4), node: process.version
+	steps_per_launch: Math.round(steps / st.kernelLaunches), roofline_frac: +((0.25 * G ** 3) / (stepUs * 1e-6) / 8e12).toFixed(4), node: process.version
 };
 if (frames > 0 && uniformsPath)
 {

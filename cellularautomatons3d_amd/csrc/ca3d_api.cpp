@@ -94,6 +94,8 @@ struct ca3d_engine
 	bool res_failed = false;      // a launch timed out: the path stays off until the next configure
 	bool res_check = false;       // a resident launch has been issued since the status was last looked at
 	void *res_jit_fn = nullptr;   // run-time compiled kernel for the current tables (null: the pre-built rule)
+	void *res_slab_fn = nullptr;  // slab form for the current slab geometry and tables (run-time compiled), or null
+	size_t res_mail_bytes = 0;
 	unsigned long long *res_mail = nullptr;
 	uint32_t *res_status = nullptr, *res_status_host = nullptr;
 	uint32_t res_epoch = 0;
@@ -258,10 +260,22 @@ void refresh_kernels(ca3d_engine *h)
 	h->roll_jit = RollJit{};
 	h->res_ready = false;
 	h->res_jit_fn = nullptr;
+	h->res_slab_fn = nullptr;
 	h->jit_log.clear();
 	if (!h->configured || !h->rules.valid) return;
 	if (h->layout != CA3D_LAYOUT_PACKED32) { h->kernel_name = "ca_unpacked_literal"; return; }
 	h->kernel_name = packed_kernel_name(h->rules, h->G, h->variant);
+	if (h->slab && h->use_resident && h->use_jit)
+	{
+		// a rank's share of a 1024^3 grid: K sub-steps per launch with the slab on chip (ca_resident_kernel.inc, slab form)
+		const int pz = resident_slab_planes(h->rules, h->G, h->nplanes, h->variant);
+		if (pz && hipSetDevice(h->device) == hipSuccess)
+		{
+			uint32_t ls1 = 0, lb1 = 0;
+			vn_tables(h->rules, &ls1, &lb1);
+			if (jit_resident_slab_kernel(h->device, ls1, lb1, pz, &h->res_slab_fn, &h->jit_log) != CA3D_OK) h->res_slab_fn = nullptr;
+		}
+	}
 	{
 		// the resident kernel of the start-up rule is pre-built: available with or without the run-time compiler
 		uint32_t ls0 = 0, lb0 = 0;
@@ -404,11 +418,12 @@ int check_resident(ca3d_engine *h)
 }
 
 // n steps as ONE launch of the resident kernel (state in registers between steps).
-int resident_steps(ca3d_engine *h, uint32_t n)
+int resident_buffers(ca3d_engine *h, uint32_t n)
 {
 	if (!h->res_mail)
 	{
-		const size_t bytes = resident_mail_bytes(h->G);
+		const size_t bytes = h->slab ? resident_slab_mail_bytes() : resident_mail_bytes(h->G);
+		h->res_mail_bytes = bytes;
 		HIP_TRY(hipMalloc((void **)&h->res_mail, bytes));
 		HIP_TRY(hipMalloc((void **)&h->res_status, kResStatusBytes));
 		HIP_TRY(hipHostMalloc((void **)&h->res_status_host, 16, hipHostMallocDefault));
@@ -420,9 +435,43 @@ int resident_steps(ca3d_engine *h, uint32_t n)
 	if (h->res_epoch > 0xFFFFFFFFu - n - 4u)
 	{
 		// the 32-bit state tags would wrap: start the numbering again from clean mailboxes
-		HIP_TRY(hipMemsetAsync(h->res_mail, 0, resident_mail_bytes(h->G), h->stream));
+		HIP_TRY(hipMemsetAsync(h->res_mail, 0, h->res_mail_bytes, h->stream));
 		h->res_epoch = 0;
 	}
+	return CA3D_OK;
+}
+
+// n sub-steps of a slab as ONE launch (state tiles in registers, faces through the mailboxes); the whole array is updated,
+// the planes outside [n, L - n) are stale afterwards like after a per-step batch.
+int resident_slab_steps(ca3d_engine *h, uint32_t n)
+{
+	int rc = resident_buffers(h, n);
+	if (rc) return rc;
+	ResidentSlabLaunch l;
+	l.in = h->buf[h->cur];
+	l.out = h->buf[(h->cur + n) & 1u];
+	l.mail = h->res_mail;
+	l.status = h->res_status;
+	l.host_flag = h->res_status_host;
+	l.steps = n;
+	l.epoch0 = h->res_epoch;
+	l.timeout_ticks = h->res_timeout_ticks;
+	const int64_t zbase = (int64_t)h->z0 - (int64_t)h->ghost;
+	const int64_t dead = ((-zbase) % (int64_t)h->G + (int64_t)h->G) % (int64_t)h->G; // array plane with global z == 0
+	l.dead_plane = dead < (int64_t)h->nplanes ? (int)dead : -1;
+	l.fn = h->res_slab_fn;
+	hipError_t e = launch_resident_slab(l, h->stream);
+	if (e != hipSuccess) return fail(CA3D_ERR_DEVICE, "resident slab kernel launch failed: %s", hipGetErrorString(e));
+	h->res_epoch += n;
+	h->res_check = true;
+	h->kernel_name = "ca_resident_slab_vn(jit)";
+	return CA3D_OK;
+}
+
+int resident_steps(ca3d_engine *h, uint32_t n)
+{
+	int rc0 = resident_buffers(h, n);
+	if (rc0) return rc0;
 	ResidentLaunch l;
 	l.in = h->buf[h->cur];
 	l.out_last = h->buf[(h->cur + n) & 1u];
@@ -700,7 +749,7 @@ int ca3d_upload_state(ca3d_t *h, const uint32_t *words, size_t n_words)
 	if (h->res_status_host && *h->res_status_host)
 	{
 		// a resident launch gave up earlier: clean mailboxes and status for whoever turns the path on again
-		HIP_TRY(hipMemsetAsync(h->res_mail, 0, resident_mail_bytes(h->G), h->stream));
+		HIP_TRY(hipMemsetAsync(h->res_mail, 0, h->res_mail_bytes, h->stream));
 		HIP_TRY(hipMemsetAsync(h->res_status, 0, kResStatusBytes, h->stream));
 		*h->res_status_host = 0;
 		h->res_epoch = 0;
@@ -830,7 +879,13 @@ int slab_batch(ca3d_engine *h, uint32_t n_steps, int phase)
 	};
 	const bool graphable = h->use_graph && h->stream != nullptr && n > 1 &&
 	                       !(h->layout == CA3D_LAYOUT_UNPACKED && !h->binary_state);
+	const bool resident = what == CA3D_SLAB_PHASE_ALL && h->res_slab_fn && h->use_resident && !h->res_failed && n >= h->res_min && h->stream != nullptr;
 	if (what < 0) { /* nothing to enqueue */ }
+	else if (resident)
+	{
+		rc = resident_slab_steps(h, n);
+		if (rc) return rc;
+	}
 	else if (graphable)
 	{
 		// one graph launch per batch: the host cost of a K-step batch must stay below its GPU time for the ranks
@@ -1113,6 +1168,7 @@ int ca3d_get_info(ca3d_t *h, ca3d_info *out)
 		if (h->layout != CA3D_LAYOUT_PACKED32) name = h->step > 0 && h->kernel_name[0] ? h->kernel_name : "ca_unpacked";
 		else if (h->use_fused && !h->slab && packed_fused_steps(h->rules, h->G, h->variant) == 2) name = "ca_packed_fused+ca_packed_class";
 		else if (h->res_ready && h->use_resident && !h->res_failed) name = h->res_jit_fn ? "ca_resident_vn(jit)" : "ca_resident_vn";
+		else if (h->slab && h->res_slab_fn && h->use_resident && !h->res_failed) name = "ca_resident_slab_vn(jit)";
 		else name = h->vn_jit.cvl >= 0 ? "ca_packed_vn(jit)" : packed_kernel_name(h->rules, h->G, h->variant);
 	}
 	const bool class_jit = h->configured && h->rules.valid && h->layout == CA3D_LAYOUT_PACKED32 && h->class_jit.main >= 0 &&

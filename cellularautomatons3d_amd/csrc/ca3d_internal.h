@@ -163,6 +163,22 @@ size_t resident_mail_bytes(uint32_t G);
 uint32_t resident_lds_bytes();
 hipError_t launch_resident(const ResidentLaunch &l, hipStream_t stream);
 int jit_resident_kernel(int device, uint32_t lut_s, uint32_t lut_b, void **fn, std::string *log);
+// Slab form (one rank's share of a 1024^3 grid, K sub-steps per launch): run-time compiled only, per planes-per-tile count
+struct ResidentSlabLaunch
+{
+	const uint32_t *in;
+	uint32_t *out;
+	unsigned long long *mail; // resident_slab_mail_bytes()
+	uint32_t *status, *host_flag;
+	uint32_t steps, epoch0, timeout_ticks;
+	int dead_plane; // array plane whose global z is 0, or -1
+	void *fn;       // hipFunction_t from jit_resident_slab_kernel
+};
+// planes per tile of the slab form for an array of `nplanes` planes of a G-wide grid with these rules, or 0 when it does not apply
+int resident_slab_planes(const CanonRules &r, uint32_t G, uint32_t nplanes, int variant);
+size_t resident_slab_mail_bytes();
+hipError_t launch_resident_slab(const ResidentSlabLaunch &l, hipStream_t stream);
+int jit_resident_slab_kernel(int device, uint32_t lut_s, uint32_t lut_b, int pz, void **fn, std::string *log);
 // Steps one fused launch advances for these rules / grid (0 = no fused kernel applies).
 int packed_fused_steps(const CanonRules &r, uint32_t G, int variant);
 hipError_t launch_packed_fused(const PackedLaunch &l, hipStream_t stream, const char **kernel_name);

@@ -30,6 +30,32 @@ size_t resident_mail_bytes(uint32_t G)
 
 uint32_t resident_lds_bytes() { return kResLdsBytes; }
 
+int resident_slab_planes(const CanonRules &r, uint32_t G, uint32_t nplanes, int variant)
+{
+	if (G != 1024u || !vn_kernel_applies(r, G, variant) || nplanes % (uint32_t)kSlabTZ) return 0;
+	const uint32_t pz = nplanes / (uint32_t)kSlabTZ;
+	// even (the face pass runs whole waves), at most 24 planes (128 VGPRs at 1024 threads per workgroup)
+	return pz >= 4u && pz <= 24u && pz % 2u == 0 ? (int)pz : 0;
+}
+
+size_t resident_slab_mail_bytes() { return 2u * (size_t)(kSlabTY * kSlabTZ) * 4u * kSlabFace * sizeof(unsigned long long); }
+
+hipError_t launch_resident_slab(const ResidentSlabLaunch &l, hipStream_t stream)
+{
+	ResidentSlabArgs a;
+	a.in = l.in;
+	a.out = l.out;
+	a.mail = l.mail;
+	a.status = l.status;
+	a.host_flag = l.host_flag;
+	a.steps = l.steps;
+	a.epoch0 = l.epoch0;
+	a.timeout_ticks = l.timeout_ticks;
+	a.dead_plane = l.dead_plane;
+	void *args[] = {(void *)&a};
+	return hipModuleLaunchKernel((hipFunction_t)l.fn, kSlabTY * kSlabTZ, 1, 1, kSlabThreads, 1, 1, 0, stream, args, nullptr);
+}
+
 hipError_t launch_resident(const ResidentLaunch &l, hipStream_t stream)
 {
 	ResidentArgs a;

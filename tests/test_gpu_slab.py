@@ -147,6 +147,28 @@ def test_packed_slabs_at_the_baseline_widths(G, P, K, steps, name, overlapped):
     assert np.array_equal(got, want)  # (assert_array_equal would format 1 GiB arrays on failure)
 
 
+@pytest.mark.parametrize("K,steps,name", [(16, 40, "default"), (32, 70, "vn_b24_s135")])
+def test_resident_slab_kernel(K, steps, name):
+    """The slab form of the resident kernel (ca_resident_kernel.inc): a rank's share of a 1024^3 grid — 128 owned planes
+    + 2 K ghost planes — runs a batch of K sub-steps in ONE launch, tiles in registers. P = 8 engines on one GPU, ghosts
+    moved by device copies after every batch (product halo plan); batches shorter than resident_min and the per-step
+    kernels (option off) must give the same state; all against the oracle's full-grid run. Rank 7's high ghost holds the
+    copy of global plane 0 (dead plane below it, a run-time plane index inside a tile); rank 0's low ghost is never valid."""
+    from cellularautomatons3d_amd import Engine
+
+    G, P = 1024, 8
+    r = rules(name)
+    full = host.random_fill(host.words_per_buffer(G), seed=4242 + K)
+    probe = Engine(0)
+    probe.configure_slab(G, 0, G // P, K)
+    set_rules(probe, r)
+    assert probe.info().kernel_name == b"ca_resident_slab_vn(jit)", probe.info().kernel_name
+    probe.close()
+    got = _run_slabs(G, P, K, steps, r, LAYOUT_PACKED32, full)
+    want = ol.packed_run(G, full, r, steps)
+    assert np.array_equal(got, want)
+
+
 @pytest.mark.parametrize("overlap", [True, False])
 def test_slab_engine_over_rccl_loopback(overlap):
     """The product's exchange through the real transport on one GPU: a one-rank RCCL group, the wrap message (rank

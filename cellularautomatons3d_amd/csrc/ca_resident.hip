@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "ca3d_internal.h"
 
 namespace ca3d
@@ -15,6 +17,45 @@ namespace
 #include "ca_resident_kernel.inc"
 
 constexpr int kDefaultS = 0xFF, kDefaultB = 0x0A; // von Neumann B1,3 / S0-6, canonical tables (ca_packed_vn.hip)
+
+// A resident launch needs every one of its workgroups on a CU at the same time, and one workgroup fills most of a CU's
+// LDS: two such launches running side by side (two engines of one process on different streams) would each get part of
+// the chip and wait for tiles that cannot start. Resident launches on one device are therefore chained: each waits for
+// the previous one's completion event, whatever stream it was on.
+struct DeviceChain
+{
+	std::mutex m;
+	hipEvent_t last[64] = {};
+};
+DeviceChain &chain()
+{
+	static DeviceChain c;
+	return c;
+}
+
+template <typename F>
+hipError_t chained_launch(hipStream_t stream, F launch)
+{
+	int dev = 0;
+	hipError_t e = hipGetDevice(&dev);
+	if (e != hipSuccess) return e;
+	if (dev < 0 || dev >= 64) return launch();
+	DeviceChain &c = chain();
+	std::lock_guard<std::mutex> lock(c.m);
+	if (c.last[dev])
+	{
+		e = hipStreamWaitEvent(stream, c.last[dev], 0);
+		if (e != hipSuccess) return e;
+	}
+	else
+	{
+		e = hipEventCreateWithFlags(&c.last[dev], hipEventDisableTiming);
+		if (e != hipSuccess) return e;
+	}
+	e = launch();
+	if (e != hipSuccess) return e;
+	return hipEventRecord(c.last[dev], stream);
+}
 
 } // namespace
 
@@ -53,7 +94,7 @@ hipError_t launch_resident_slab(const ResidentSlabLaunch &l, hipStream_t stream)
 	a.timeout_ticks = l.timeout_ticks;
 	a.dead_plane = l.dead_plane;
 	void *args[] = {(void *)&a};
-	return hipModuleLaunchKernel((hipFunction_t)l.fn, kSlabTY * kSlabTZ, 1, 1, kSlabThreads, 1, 1, 0, stream, args, nullptr);
+	return chained_launch(stream, [&]() { return hipModuleLaunchKernel((hipFunction_t)l.fn, kSlabTY * kSlabTZ, 1, 1, kSlabThreads, 1, 1, 0, stream, args, nullptr); });
 }
 
 hipError_t launch_resident(const ResidentLaunch &l, hipStream_t stream)
@@ -72,12 +113,14 @@ hipError_t launch_resident(const ResidentLaunch &l, hipStream_t stream)
 	if (l.jit_fn)
 	{
 		void *args[] = {(void *)&a};
-		return hipModuleLaunchKernel((hipFunction_t)l.jit_fn, tiles, 1, 1, kResThreads, 1, 1, 0, stream, args, nullptr);
+		return chained_launch(stream, [&]() { return hipModuleLaunchKernel((hipFunction_t)l.jit_fn, tiles, 1, 1, kResThreads, 1, 1, 0, stream, args, nullptr); });
 	}
 	if (l.lut_s != (u32)kDefaultS || l.lut_b != (u32)kDefaultB) return hipErrorInvalidValue;
 	auto kern = ca_resident_vn<kDefaultS, kDefaultB>;
-	hipLaunchKernelGGL(kern, dim3(tiles), dim3(kResThreads), 0, stream, a);
-	return hipGetLastError();
+	return chained_launch(stream, [&]() {
+		hipLaunchKernelGGL(kern, dim3(tiles), dim3(kResThreads), 0, stream, a);
+		return hipGetLastError();
+	});
 }
 
 } // namespace ca3d

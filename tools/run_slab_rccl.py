@@ -21,6 +21,7 @@ ap.add_argument("--ghost", type=int, default=16)
 ap.add_argument("--batches", type=int, default=100)
 ap.add_argument("--native", type=int, default=0, help="1: the exchange inside the engine (ca3d_slab_run) instead of torch.distributed")
 ap.add_argument("--rule", default="default")
+ap.add_argument("--resident", type=int, default=1, help="0: per-step slab kernels only")
 a = ap.parse_args()
 s = socket.socket()
 s.bind(("127.0.0.1", 0))
@@ -42,6 +43,7 @@ for overlap in (False, True):
         se.engine.set_rule_strings()
     se.engine.set_stream(se.stream.cuda_stream)
     se.engine.set_option("stats", 0)
+    se.engine.set_option("resident", a.resident)
     se.upload_state(host.random_fill((G // 32) * G * a.planes))
     se.run(a.ghost * 5)
     torch.cuda.synchronize()
@@ -50,7 +52,7 @@ for overlap in (False, True):
     t_host = time.perf_counter() - t0
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(f"slab {a.planes} planes of {G}^2, ghost {a.ghost}, RCCL loopback ({'engine' if a.native else 'torch'} transport), overlap {overlap}: {dt / (a.ghost * a.batches) * 1e6:.2f} us/step "
+    print(f"slab {a.planes} planes of {G}^2, ghost {a.ghost}, RCCL loopback ({'engine' if a.native else 'torch'} transport), overlap {overlap}, {se.engine.info().kernel_name.decode()}: {dt / (a.ghost * a.batches) * 1e6:.2f} us/step "
           f"({dt / a.batches * 1e6:.1f} us per batch incl. one exchange of 2 x {a.ghost * G * G // 8 / 2**20:.1f} MiB; host enqueue {t_host / a.batches * 1e6:.1f} us per batch)")
     se.close()
 dist.destroy_process_group()

@@ -364,6 +364,196 @@ static napi_value js_set_option(napi_env env, napi_callback_info info)
 	return rc ? throw_ca3d(env, rc) : undefined(env);
 }
 
+/* RCCL transport inside the engine (include/ca3d.h "Halo transport"): a Node.js host runs one process per GPU, creates the
+ * id on rank 0, hands the 128 bytes to the other ranks over its own IPC, and calls slabRun — no Python involved. */
+static napi_value js_comm_unique_id(napi_env env, napi_callback_info info)
+{
+	(void)info;
+	void *data = NULL;
+	napi_value ab, out;
+	NAPI_OK_OR_NULL(napi_create_arraybuffer(env, CA3D_COMM_ID_BYTES, &data, &ab));
+	int rc = ca3d_comm_unique_id(data);
+	if (rc) return throw_ca3d(env, rc);
+	NAPI_OK_OR_NULL(napi_create_typedarray(env, napi_uint8_array, CA3D_COMM_ID_BYTES, ab, 0, &out));
+	return out;
+}
+
+static napi_value js_slab_comm_init(napi_env env, napi_callback_info info)
+{
+	napi_value argv[4];
+	if (!get_args(env, info, 4, argv)) return NULL;
+	ca3d_t *h = get_handle(env, argv[0]);
+	void *id;
+	size_t n;
+	uint32_t rank, world;
+	if (!h || !get_typed(env, argv[1], napi_uint8_array, 0, &id, &n) || !get_u32(env, argv[2], &rank) || !get_u32(env, argv[3], &world)) return NULL;
+	if (n != CA3D_COMM_ID_BYTES) { napi_throw_range_error(env, NULL, "the communicator id is a Uint8Array(128)"); return NULL; }
+	int rc = ca3d_slab_comm_init(h, id, (int)rank, (int)world);
+	return rc ? throw_ca3d(env, rc) : undefined(env);
+}
+
+static napi_value js_slab_run(napi_env env, napi_callback_info info)
+{
+	napi_value argv[3];
+	if (!get_args(env, info, 3, argv)) return NULL;
+	ca3d_t *h = get_handle(env, argv[0]);
+	uint32_t n, overlap;
+	if (!h || !get_u32(env, argv[1], &n) || !get_u32(env, argv[2], &overlap)) return NULL;
+	int rc = ca3d_slab_run(h, n, (int)overlap);
+	return rc ? throw_ca3d(env, rc) : undefined(env);
+}
+
+static napi_value js_slab_exchange(napi_env env, napi_callback_info info)
+{
+	napi_value argv[1];
+	if (!get_args(env, info, 1, argv)) return NULL;
+	ca3d_t *h = get_handle(env, argv[0]);
+	if (!h) return NULL;
+	int rc = ca3d_slab_exchange(h);
+	return rc ? throw_ca3d(env, rc) : undefined(env);
+}
+
+static napi_value js_slab_gather(napi_env env, napi_callback_info info)
+{
+	napi_value argv[2];
+	if (!get_args(env, info, 2, argv)) return NULL;
+	ca3d_t *h = get_handle(env, argv[0]), *full = get_handle(env, argv[1]);
+	if (!h || !full) return NULL;
+	int rc = ca3d_slab_gather(h, full);
+	return rc ? throw_ca3d(env, rc) : undefined(env);
+}
+
+/*
+ * Asynchronous forms of the calls that wait for the GPU ("optional napi_async_work wrappers"): the wait
+ * runs on a libuv worker thread and the call returns a Promise, so a UI thread never blocks in a read-back. The engine
+ * is not thread-safe: the JS wrapper (ca3d.js) queues everything else behind a pending job of the same engine.
+ */
+typedef struct
+{
+	napi_async_work work;
+	napi_deferred deferred;
+	ca3d_t *h;
+	int kind; /* 0 readState, 1 render, 2 synchronize */
+	int rc;
+	char err[512];
+	uint32_t *words;
+	size_t n_words;
+	float uniforms[128];
+	uint32_t w, hh, spp;
+	uint8_t *pres;
+	uint16_t *light, *depth;
+	napi_ref refs[3]; /* the typed arrays stay alive (and in place) until the job completes */
+	int nrefs;
+} AsyncJob;
+
+static void job_execute(napi_env env, void *data)
+{
+	(void)env;
+	AsyncJob *j = (AsyncJob *)data;
+	if (j->kind == 0) j->rc = ca3d_read_state(j->h, j->words, j->n_words);
+	else if (j->kind == 1) j->rc = ca3d_render(j->h, j->uniforms, j->w, j->hh, j->spp, j->pres, j->light, j->depth);
+	else j->rc = ca3d_synchronize(j->h);
+	if (j->rc) snprintf(j->err, sizeof j->err, "ca3d error %d: %s", j->rc, ca3d_last_error()); /* ca3d_last_error is per thread */
+}
+
+static void job_complete(napi_env env, napi_status status, void *data)
+{
+	AsyncJob *j = (AsyncJob *)data;
+	napi_value v;
+	if (status == napi_ok && j->rc == 0)
+	{
+		napi_get_undefined(env, &v);
+		napi_resolve_deferred(env, j->deferred, v);
+	}
+	else
+	{
+		napi_value msg;
+		napi_create_string_utf8(env, status == napi_ok ? j->err : "the asynchronous job was cancelled", NAPI_AUTO_LENGTH, &msg);
+		napi_create_error(env, NULL, msg, &v);
+		napi_reject_deferred(env, j->deferred, v);
+	}
+	for (int i = 0; i < j->nrefs; i++) napi_delete_reference(env, j->refs[i]);
+	napi_delete_async_work(env, j->work);
+	free(j);
+}
+
+static napi_value job_start(napi_env env, AsyncJob *j, const char *name)
+{
+	napi_value promise, resource;
+	if (napi_create_promise(env, &j->deferred, &promise) != napi_ok || napi_create_string_utf8(env, name, NAPI_AUTO_LENGTH, &resource) != napi_ok ||
+	    napi_create_async_work(env, NULL, resource, job_execute, job_complete, j, &j->work) != napi_ok || napi_queue_async_work(env, j->work) != napi_ok)
+	{
+		for (int i = 0; i < j->nrefs; i++) napi_delete_reference(env, j->refs[i]);
+		free(j);
+		napi_throw_error(env, NULL, "could not queue the asynchronous job");
+		return NULL;
+	}
+	return promise;
+}
+
+static void job_keep(napi_env env, AsyncJob *j, napi_value v)
+{
+	napi_valuetype t;
+	napi_typeof(env, v, &t);
+	if (t == napi_null || t == napi_undefined) return;
+	if (napi_create_reference(env, v, 1, &j->refs[j->nrefs]) == napi_ok) j->nrefs++;
+}
+
+static napi_value js_read_state_async(napi_env env, napi_callback_info info)
+{
+	napi_value argv[2];
+	if (!get_args(env, info, 2, argv)) return NULL;
+	ca3d_t *h = get_handle(env, argv[0]);
+	void *w;
+	size_t n;
+	if (!h || !get_typed(env, argv[1], napi_uint32_array, 0, &w, &n)) return NULL;
+	AsyncJob *j = (AsyncJob *)calloc(1, sizeof *j);
+	if (!j) { napi_throw_error(env, NULL, "out of memory"); return NULL; }
+	j->h = h; j->kind = 0; j->words = (uint32_t *)w; j->n_words = n;
+	job_keep(env, j, argv[1]);
+	return job_start(env, j, "ca3d.readState");
+}
+
+static napi_value js_render_async(napi_env env, napi_callback_info info)
+{
+	napi_value argv[8];
+	if (!get_args(env, info, 8, argv)) return NULL;
+	ca3d_t *h = get_handle(env, argv[0]);
+	if (!h) return NULL;
+	void *u, *pres, *light, *depth;
+	size_t nu, npres, nlight, ndepth;
+	uint32_t w, hh, spp;
+	if (!get_typed(env, argv[1], napi_float32_array, 0, &u, &nu) || !get_u32(env, argv[2], &w) || !get_u32(env, argv[3], &hh) ||
+	    !get_u32(env, argv[4], &spp) || !get_typed(env, argv[5], napi_uint8_array, 1, &pres, &npres) ||
+	    !get_typed(env, argv[6], napi_uint16_array, 1, &light, &nlight) || !get_typed(env, argv[7], napi_uint16_array, 1, &depth, &ndepth))
+		return NULL;
+	const size_t px = (size_t)w * hh;
+	if (nu != 128 || (pres && npres != px * 4) || (light && nlight != px * 4) || (depth && ndepth != px * 2))
+	{
+		napi_throw_range_error(env, NULL, "uniforms must be Float32Array(128); targets must match width*height");
+		return NULL;
+	}
+	AsyncJob *j = (AsyncJob *)calloc(1, sizeof *j);
+	if (!j) { napi_throw_error(env, NULL, "out of memory"); return NULL; }
+	j->h = h; j->kind = 1; j->w = w; j->hh = hh; j->spp = spp;
+	memcpy(j->uniforms, u, sizeof j->uniforms); /* the block is consumed now, like the reference's writeBuffer */
+	j->pres = (uint8_t *)pres; j->light = (uint16_t *)light; j->depth = (uint16_t *)depth;
+	job_keep(env, j, argv[5]); job_keep(env, j, argv[6]); job_keep(env, j, argv[7]);
+	return job_start(env, j, "ca3d.render");
+}
+
+static napi_value js_synchronize_async(napi_env env, napi_callback_info info)
+{
+	napi_value argv[1];
+	if (!get_args(env, info, 1, argv)) return NULL;
+	ca3d_t *h = get_handle(env, argv[0]);
+	if (!h) return NULL;
+	AsyncJob *j = (AsyncJob *)calloc(1, sizeof *j);
+	if (!j) { napi_throw_error(env, NULL, "out of memory"); return NULL; }
+	j->h = h; j->kind = 2;
+	return job_start(env, j, "ca3d.synchronize");
+}
+
 static napi_value js_abi_version(napi_env env, napi_callback_info info)
 {
 	(void)info;
@@ -379,7 +569,10 @@ static napi_value init(napi_env env, napi_value exports)
 	    {"configure", js_configure}, {"configureSlab", js_configure_slab}, {"setRules", js_set_rules},
 	    {"uploadState", js_upload_state}, {"readState", js_read_state}, {"step", js_step}, {"slabStep", js_slab_step}, {"slabStepPhase", js_slab_step_phase},
 	    {"synchronize", js_synchronize}, {"info", js_info}, {"stats", js_stats}, {"render", js_render},
-	    {"renderStats", js_render_stats}, {"setOption", js_set_option}};
+	    {"renderStats", js_render_stats}, {"setOption", js_set_option},
+	    {"commUniqueId", js_comm_unique_id}, {"slabCommInit", js_slab_comm_init}, {"slabRun", js_slab_run}, {"slabExchange", js_slab_exchange},
+	    {"slabGather", js_slab_gather},
+	    {"readStateAsync", js_read_state_async}, {"renderAsync", js_render_async}, {"synchronizeAsync", js_synchronize_async}};
 	for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++)
 	{
 		napi_value f;

@@ -215,6 +215,13 @@ class Engine
 	configureSlab(gridSize, z0, nz, ghost, layout) { this._a.configureSlab(this._h, gridSize, layout === undefined ? LAYOUT_PACKED32 : layout, z0, nz, ghost); }
 	slabStep(n) { this._a.slabStep(this._h, n); }
 	slabStepPhase(n, phase) { this._a.slabStepPhase(this._h, n, phase); }
+	// RCCL transport inside the engine: one process per GPU; rank 0 creates the id (Engine.commUniqueId()) and hands it to
+	// the other ranks by the host's own IPC; slabRun(n, overlap) = n steps with the ghost planes exchanged between batches
+	static commUniqueId() { return loadAddon().commUniqueId(); }
+	slabCommInit(id, rank, world) { this._a.slabCommInit(this._h, id, rank, world); }
+	slabRun(n, overlap) { this._a.slabRun(this._h, n, overlap ? 1 : 0); }
+	slabExchange() { this._a.slabExchange(this._h); }
+	slabGather(full) { this._a.slabGather(this._h, full._h); }
 
 	synchronize() { this._a.synchronize(this._h); }
 
@@ -224,6 +231,29 @@ class Engine
 		const t = targets || {};
 		this._a.render(this._h, uniforms, width, height, spp || 1, t.presentation || null, t.light || null, t.depth || null);
 	}
+
+	// Asynchronous forms (napi_async_work): the wait for the GPU runs on a worker thread and the call returns a Promise, so
+	// a UI thread never blocks in a read-back. The engine takes one call at a time: do not call anything else on it until
+	// the promise has settled (asynchronous calls issued meanwhile queue up behind it by themselves).
+	_queue(start)
+	{
+		const p = (this._pending || Promise.resolve()).then(start, start);
+		this._pending = p.catch(() => undefined);
+		return p;
+	}
+	readStateAsync()
+	{
+		return this._queue(() => {
+			const out = new Uint32Array(this.info().stateWords);
+			return this._a.readStateAsync(this._h, out).then(() => out);
+		});
+	}
+	renderAsync(uniforms, width, height, spp, targets)
+	{
+		const t = targets || {};
+		return this._queue(() => this._a.renderAsync(this._h, uniforms, width, height, spp || 1, t.presentation || null, t.light || null, t.depth || null).then(() => t));
+	}
+	synchronizeAsync() { return this._queue(() => this._a.synchronizeAsync(this._h)); }
 
 	info() { return this._a.info(this._h); }
 	stats() { return this._a.stats(this._h); }

@@ -45,5 +45,41 @@ assert.strictEqual(eng.renderStats().primaryRays, W * H);
 // errors surface as exceptions carrying ca3d_last_error()
 assert.throws(() => eng.configure(48), /multiple of 32/);
 assert.throws(() => eng.uploadState(new Uint32Array(3)), /expected/);
-eng.close();
-console.log("ok");
+
+// a slab with the exchange inside the engine (RCCL, one-rank chain: the wrap message goes to the same GPU) equals the full grid
+{
+	const Gs = 256, K = 4;
+	const se = new c.Engine(0), fe = new c.Engine(0);
+	se.configureSlab(Gs, 0, Gs, K);
+	se.setRuleStrings({});
+	fe.configure(Gs);
+	fe.setRuleStrings({});
+	const s0 = c.randomFill((Gs / 32) * Gs * Gs, 5, 0);
+	se.uploadState(s0);
+	fe.uploadState(s0);
+	se.slabCommInit(c.Engine.commUniqueId(), 0, 1);
+	se.slabRun(10, false);
+	se.slabRun(3, true);
+	fe.step(13);
+	assert.deepStrictEqual(Buffer.from(se.readState().buffer), Buffer.from(fe.readState().buffer));
+	se.close();
+	fe.close();
+}
+
+// asynchronous forms: the same bytes as the blocking calls, the event loop keeps turning meanwhile, errors reject
+(async () => {
+	const stateSync = eng.readState();
+	let ticks = 0;
+	const timer = setInterval(() => { ticks++; }, 0);
+	const pres2 = new Uint8Array(W * H * 4), light2 = new Uint16Array(W * H * 4);
+	const jobs = [eng.readStateAsync(), eng.renderAsync(u, W, H, 1, { presentation: pres2, light: light2 }), eng.synchronizeAsync(), eng.readStateAsync()];
+	const done = await Promise.all(jobs);
+	clearInterval(timer);
+	assert.deepStrictEqual(Buffer.from(done[0].buffer), Buffer.from(stateSync.buffer));
+	assert.deepStrictEqual(Buffer.from(done[3].buffer), Buffer.from(stateSync.buffer));
+	assert.deepStrictEqual(Buffer.from(pres2.buffer), Buffer.from(pres.buffer));
+	assert.deepStrictEqual(Buffer.from(light2.buffer), Buffer.from(light.buffer));
+	await assert.rejects(eng.renderAsync(u, W, H, 3, {}), /spp must be 1 or 4/);
+	eng.close();
+	console.log("ok");
+})().catch((e) => { console.error(e); process.exit(1); });

@@ -157,6 +157,9 @@ int jit_roll_kernels(int device, const CanonRules &r, int cvl, RollJit *out, std
 // Whether the rolling-window kernel is the one to use for these rules on this grid (diagonal neighbour classes in
 // play, power-of-two grid of 256 and up)
 bool roll_kernel_applies(const CanonRules &r, uint32_t G, int variant);
+// rule_synth.cpp: device source of jit_rule_word() for these rules ("" when the self-check fails), ca_jit.cpp's wrapper
+std::string synthesize_rule_source(const CanonRules &r, int *ops_out);
+std::string rule_function_source(const CanonRules &r);
 // ca_resident.hip
 bool resident_kernel_applies(const CanonRules &r, uint32_t G, int variant);
 size_t resident_mail_bytes(uint32_t G);

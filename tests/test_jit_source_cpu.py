@@ -33,6 +33,8 @@ namespace ca3d
 {
 namespace jit
 {
+#include "ca_bitops.inc"
+#include "ca_jit_rule.inc"
 #include "ca_bitslice.inc"
 #include "ca_packed_class_kernel.inc"
 }
@@ -45,6 +47,8 @@ namespace ca3d
 {
 namespace jit
 {
+#include "ca_bitops.inc"
+#include "ca_jit_rule.inc"
 #include "ca_bitslice.inc"
 #include "ca_packed_roll_kernel.inc"
 }
@@ -63,12 +67,34 @@ HEADERS = [b"ca_bitops.inc", b"ca_packed_vn_kernel.inc", b"ca_device_types.h", b
            b"ca_packed_roll_kernel.inc", b"ca_resident_kernel.inc"]
 
 
-def _compile(rtc, program, name, defines):
-    sources = [open(os.path.join(CSRC, n.decode()), "rb").read() for n in HEADERS]
+#: the clustered rule as rule_synth.cpp writes it (the generated header the engine passes as "ca_jit_rule.inc")
+CLUSTERED_RULE_FN = b"""
+#define CA3D_JIT_RULE_FN 1
+__device__ __forceinline__ u32 jit_rule_word(u32 alive, const u32 *mn, const u32 *ed, const u32 *co)
+{
+	const u32 t14 = bitop3<0x02>(mn[4], mn[3], mn[2]);
+	const u32 t15 = bitop3<0x38>(ed[2], ed[1], ed[0]);
+	const u32 t16 = bitop3<0x44>(ed[3], t15, ed[3]);
+	const u32 t17 = bitop3<0x1C>(co[2], co[1], co[0]);
+	const u32 t18 = bitop3<0xFE>(t14, t16, t17);
+	const u32 t19 = bitop3<0xE0>(mn[2], mn[1], mn[0]);
+	const u32 t20 = bitop3<0x10>(t19, mn[4], mn[3]);
+	const u32 t21 = bitop3<0x10>(ed[2], ed[1], ed[0]);
+	const u32 t22 = bitop3<0x44>(ed[3], t21, ed[3]);
+	const u32 t23 = bitop3<0x08>(co[2], co[1], co[0]);
+	const u32 t24 = bitop3<0xFE>(t20, t22, t23);
+	return bitop3<0xCA>(alive, t18, t24);
+}
+"""
+
+
+def _compile(rtc, program, name, defines, rule_fn=b"// no synthesised rule\n"):
+    names = HEADERS + [b"ca_jit_rule.inc"]
+    sources = [open(os.path.join(CSRC, n.decode()), "rb").read() for n in HEADERS] + [rule_fn]
     prog = C.c_void_p()
-    hs = (C.c_char_p * len(HEADERS))(*sources)
-    hn = (C.c_char_p * len(HEADERS))(*HEADERS)
-    assert rtc.hiprtcCreateProgram(C.byref(prog), program, name, len(HEADERS), hs, hn) == 0
+    hs = (C.c_char_p * len(names))(*sources)
+    hn = (C.c_char_p * len(names))(*names)
+    assert rtc.hiprtcCreateProgram(C.byref(prog), program, name, len(names), hs, hn) == 0
     opts = [b"--offload-arch=gfx950", b"-O3", b"-std=c++17", b"-DCA3D_JIT=1"] + defines
     rc = rtc.hiprtcCompileProgram(prog, len(opts), (C.c_char_p * len(opts))(*opts))
     n = C.c_size_t()
@@ -113,7 +139,7 @@ def test_roll_kernel_source_compiles_with_hiprtc(cvl, main, e, c, tables):
     rtc = _hiprtc()
     defines = [b"-DCA3D_JIT_CVL=%d" % cvl, b"-DCA3D_JIT_MAIN=%d" % main, b"-DCA3D_JIT_E=" + e.encode(), b"-DCA3D_JIT_C=" + c.encode()]
     defines += [b"-DCA3D_JIT_%s=%du" % (n, t) for n, t in zip([b"TS0", b"TB0", b"TS1", b"TB1", b"TS2", b"TB2"], tables)]
-    code = _compile(rtc, ROLL_PROGRAM, b"ca3d_jit_roll.hip", defines)
+    code = _compile(rtc, ROLL_PROGRAM, b"ca3d_jit_roll.hip", defines, *([CLUSTERED_RULE_FN] if main == 2 and e == "true" else []))
     assert b"ca3d_jit_roll_z2" in code and b"ca3d_jit_roll_z4" in code and b"ca3d_jit_roll_z8" in code
 
 

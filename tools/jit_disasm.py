@@ -23,13 +23,14 @@ ap.add_argument("--cvl", type=int, default=2)
 ap.add_argument("--rule", default="clustered")
 ap.add_argument("--dump", default="")
 ap.add_argument("--extra", default="")
+ap.add_argument("--synth", type=int, default=1, help="clustered rule: use the synthesised rule function (as the engine does)")
 a = ap.parse_args()
 main, e, c, tables = TABLES[a.rule]
 defines = [b"-DCA3D_JIT_MAIN=%d" % main, b"-DCA3D_JIT_E=" + e.encode(), b"-DCA3D_JIT_C=" + c.encode()]
 defines += [b"-DCA3D_JIT_%s=%du" % (n, t) for n, t in zip([b"TS0", b"TB0", b"TS1", b"TB1", b"TS2", b"TB2"], tables)]
 defines += [x.encode() for x in a.extra.split()]
 if a.program == "roll":
-    code = T._compile(T._hiprtc(), T.ROLL_PROGRAM, b"ca3d_jit_roll.hip", defines + [b"-DCA3D_JIT_CVL=%d" % a.cvl])
+    code = T._compile(T._hiprtc(), T.ROLL_PROGRAM, b"ca3d_jit_roll.hip", defines + [b"-DCA3D_JIT_CVL=%d" % a.cvl], *([T.CLUSTERED_RULE_FN] if a.rule == "clustered" and a.synth else []))
 else:
     code = T._compile(T._hiprtc(), T.CLASS_PROGRAM, b"ca3d_jit_class.hip", defines + [b"-DCA3D_JIT_ZR=4"])
 out = a.dump or "/tmp/ca3d_jit_disasm"

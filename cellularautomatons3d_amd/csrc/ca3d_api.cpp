@@ -91,6 +91,7 @@ struct ca3d_engine
 	// resident multi-step kernel (ca_resident.hip): face mailboxes, status word (device + pinned host copy), tag counter
 	int use_resident = 1;
 	bool res_ready = false;       // the current rules / grid have a resident kernel
+	bool res_class = false;       // ... and it is the class form (ca_resident_class_kernel.inc)
 	bool res_failed = false;      // a launch timed out: the path stays off until the next configure
 	bool res_check = false;       // a resident launch has been issued since the status was last looked at
 	void *res_jit_fn = nullptr;   // run-time compiled kernel for the current tables (null: the pre-built rule)
@@ -259,6 +260,7 @@ void refresh_kernels(ca3d_engine *h)
 	h->class_jit = ClassJit{};
 	h->roll_jit = RollJit{};
 	h->res_ready = false;
+	h->res_class = false;
 	h->res_jit_fn = nullptr;
 	h->res_slab_fn = nullptr;
 	h->jit_log.clear();
@@ -299,6 +301,12 @@ void refresh_kernels(ca3d_engine *h)
 		{
 			RollJit rj;
 			if (jit_roll_kernels(h->device, h->rules, vn_grid_log2(h->G), &rj, &h->jit_log) == CA3D_OK) h->roll_jit = rj;
+		}
+		if (h->use_resident && !h->slab && resident_class_applies(h->rules, h->G, h->variant) &&
+		    jit_resident_class_kernel(h->device, h->rules, &h->res_jit_fn, &h->jit_log) == CA3D_OK)
+		{
+			h->res_ready = true;
+			h->res_class = true;
 		}
 		return;
 	}
@@ -483,13 +491,14 @@ int resident_steps(ca3d_engine *h, uint32_t n)
 	l.steps = n;
 	l.epoch0 = h->res_epoch;
 	l.timeout_ticks = h->res_timeout_ticks;
-	vn_tables(h->rules, &l.lut_s, &l.lut_b);
+	l.lut_s = l.lut_b = 0;
+	if (!h->res_class) vn_tables(h->rules, &l.lut_s, &l.lut_b);
 	l.jit_fn = h->res_jit_fn;
 	hipError_t e = launch_resident(l, h->stream);
 	if (e != hipSuccess) return fail(CA3D_ERR_DEVICE, "resident kernel launch failed: %s", hipGetErrorString(e));
 	h->res_epoch += n;
 	h->res_check = true;
-	h->kernel_name = h->res_jit_fn ? "ca_resident_vn(jit)" : "ca_resident_vn";
+	h->kernel_name = h->res_class ? "ca_resident_class(jit)" : (h->res_jit_fn ? "ca_resident_vn(jit)" : "ca_resident_vn");
 	return CA3D_OK;
 }
 
@@ -1167,6 +1176,7 @@ int ca3d_get_info(ca3d_t *h, ca3d_info *out)
 	{
 		if (h->layout != CA3D_LAYOUT_PACKED32) name = h->step > 0 && h->kernel_name[0] ? h->kernel_name : "ca_unpacked";
 		else if (h->use_fused && !h->slab && packed_fused_steps(h->rules, h->G, h->variant) == 2) name = "ca_packed_fused+ca_packed_class";
+		else if (h->res_ready && h->use_resident && !h->res_failed && h->res_class) name = "ca_resident_class(jit)";
 		else if (h->res_ready && h->use_resident && !h->res_failed) name = h->res_jit_fn ? "ca_resident_vn(jit)" : "ca_resident_vn";
 		else if (h->slab && h->res_slab_fn && h->use_resident && !h->res_failed) name = "ca_resident_slab_vn(jit)";
 		else name = h->vn_jit.cvl >= 0 ? "ca_packed_vn(jit)" : packed_kernel_name(h->rules, h->G, h->variant);

@@ -166,6 +166,9 @@ size_t resident_mail_bytes(uint32_t G);
 uint32_t resident_lds_bytes();
 hipError_t launch_resident(const ResidentLaunch &l, hipStream_t stream);
 int jit_resident_kernel(int device, uint32_t lut_s, uint32_t lut_b, void **fn, std::string *log);
+// the resident kernel for rules with diagonal neighbour classes (ca_resident_class_kernel.inc; 512^3, run-time compiled)
+bool resident_class_applies(const CanonRules &r, uint32_t G, int variant);
+int jit_resident_class_kernel(int device, const CanonRules &r, void **fn, std::string *log);
 // Slab form (one rank's share of a 1024^3 grid, K sub-steps per launch): run-time compiled only, per planes-per-tile count
 struct ResidentSlabLaunch
 {

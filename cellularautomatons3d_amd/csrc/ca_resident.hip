@@ -63,6 +63,11 @@ hipError_t chained_launch(hipStream_t stream, F launch)
 // geometry is built for.
 bool resident_kernel_applies(const CanonRules &r, uint32_t G, int variant) { return G == 512u && vn_kernel_applies(r, G, variant); }
 
+bool resident_class_applies(const CanonRules &r, uint32_t G, int variant)
+{
+	return G == 512u && use_class_kernel(r, G, variant) && !vn_kernel_applies(r, G, variant) && roll_kernel_applies(r, G, variant);
+}
+
 size_t resident_mail_bytes(uint32_t G)
 {
 	const size_t tiles = (size_t)(G / kResTileRows) * (G / kResTileRows);

@@ -385,6 +385,40 @@ def test_resident_multi_step_kernel(eng, tables):
     np.testing.assert_array_equal(eng.read_state(), per_step)
 
 
+@pytest.mark.parametrize("name", ["clustered", "moore_b4s4", "edges_main", "corners_main", "vn_edges_only", "moore_wide"])
+def test_resident_class_kernel(eng, name):
+    """The resident kernel for rules with diagonal neighbour classes (ca_resident_class_kernel.inc): 512^3, K steps per
+    launch, halo planes and corner rows from all eight neighbour tiles; dense and sparse states (faces of zeros still carry
+    their tags), odd and even batch lengths, against the oracle and against the per-step kernels."""
+    G = 512
+    r = rules(name)
+    eng.configure(G)
+    set_rules(eng, r)
+    assert eng.info().kernel_name == b"ca_resident_class(jit)", eng.info().kernel_name
+    st = host.random_fill(host.words_per_buffer(G), seed=99, and_rounds=1)
+    eng.upload_state(st)
+    want, total = st, 0
+    for n in (9, 8):
+        eng.step(n)
+        want = ol.packed_run(G, want, r, n)
+        total += n
+        assert np.array_equal(eng.read_state(), want), f"after a batch of {n}"
+        assert eng.info().current_buffer == total % 2
+    # boundary faces: a slab of live cells hugging the -x/-y/-z corner and the +faces (dead below, wrap above)
+    edge = np.zeros(host.words_per_buffer(G), dtype=np.uint32)
+    edge.reshape(G, G, G // 32)[:3, :3, :] = host.random_fill(9 * (G // 32), seed=7).reshape(3, 3, G // 32)
+    edge.reshape(G, G, G // 32)[-3:, -3:, :] = host.random_fill(9 * (G // 32), seed=8).reshape(3, 3, G // 32)
+    eng.upload_state(edge)
+    eng.step(12)
+    got = eng.read_state()
+    eng.set_option("resident", 0)
+    eng.upload_state(edge)
+    eng.step(12)
+    assert np.array_equal(got, eng.read_state())
+    assert np.array_equal(got, ol.packed_run(G, edge, r, 12))
+    eng.set_option("resident", 1)
+
+
 def test_batches_of_any_length_replay_as_graphs(eng):
     """A batch of n < 1024 steps is one captured graph of exactly n steps, cached per (n, start buffer): odd lengths
     alternate between the two buffers; short batches (< graph_min) are launched kernel by kernel."""

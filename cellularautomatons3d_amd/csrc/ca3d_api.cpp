@@ -1181,7 +1181,7 @@ int ca3d_get_info(ca3d_t *h, ca3d_info *out)
 		else if (h->slab && h->res_slab_fn && h->use_resident && !h->res_failed) name = "ca_resident_slab_vn(jit)";
 		else name = h->vn_jit.cvl >= 0 ? "ca_packed_vn(jit)" : packed_kernel_name(h->rules, h->G, h->variant);
 	}
-	const bool class_jit = h->configured && h->rules.valid && h->layout == CA3D_LAYOUT_PACKED32 && h->class_jit.main >= 0 &&
+	const bool class_jit = h->configured && h->rules.valid && h->layout == CA3D_LAYOUT_PACKED32 && h->class_jit.main >= 0 && strncmp(name, "ca_resident", 11) != 0 &&
 	                       !(h->use_fused && !h->slab && packed_fused_steps(h->rules, h->G, h->variant) == 2);
 	if (class_jit && h->roll_jit.cvl >= 0 && !strncmp(name, "ca_packed_class", 15))
 		snprintf(out->kernel_name, sizeof out->kernel_name, "ca_packed_class_roll%s(jit)", name + 15); // rolling-window form

@@ -101,6 +101,7 @@ struct ca3d_engine
 	uint32_t *res_status = nullptr, *res_status_host = nullptr;
 	uint32_t res_epoch = 0;
 	uint32_t res_min = 8;                 // shorter batches take the per-step kernels
+	uint32_t res_rows = 32;               // rows per tile of the von Neumann form (ca_resident_kernel.inc: 32 or 16)
 	uint32_t res_timeout_ticks = 20000000; // 200 ms of s_memrealtime per wait
 
 	// halo transport inside the engine (RCCL, loaded on first use): communicator over the ranks of the slab chain, a second
@@ -321,7 +322,7 @@ void refresh_kernels(ca3d_engine *h)
 		h->vn_jit = j;
 		h->kernel_name = "ca_packed_vn(jit)";
 	}
-	if (resident && jit_resident_kernel(h->device, ls, lb, &h->res_jit_fn, &h->jit_log) == CA3D_OK) h->res_ready = true;
+	if (resident && jit_resident_kernel(h->device, ls, lb, h->res_rows, &h->res_jit_fn, &h->jit_log) == CA3D_OK) h->res_ready = true;
 }
 
 // A failed specialisation is not an error of the call that triggered it (the ahead-of-time kernels take over), but it
@@ -430,7 +431,7 @@ int resident_buffers(ca3d_engine *h, uint32_t n)
 {
 	if (!h->res_mail)
 	{
-		const size_t bytes = h->slab ? resident_slab_mail_bytes() : resident_mail_bytes(h->G);
+		const size_t bytes = h->slab ? resident_slab_mail_bytes() : resident_mail_bytes(h->G, 16u); // sized for the finer tiling
 		h->res_mail_bytes = bytes;
 		HIP_TRY(hipMalloc((void **)&h->res_mail, bytes));
 		HIP_TRY(hipMalloc((void **)&h->res_status, kResStatusBytes));
@@ -494,6 +495,7 @@ int resident_steps(ca3d_engine *h, uint32_t n)
 	l.lut_s = l.lut_b = 0;
 	if (!h->res_class) vn_tables(h->rules, &l.lut_s, &l.lut_b);
 	l.jit_fn = h->res_jit_fn;
+	l.rows = h->res_class ? 32u : h->res_rows;
 	hipError_t e = launch_resident(l, h->stream);
 	if (e != hipSuccess) return fail(CA3D_ERR_DEVICE, "resident kernel launch failed: %s", hipGetErrorString(e));
 	h->res_epoch += n;
@@ -1409,6 +1411,22 @@ int ca3d_set_option(ca3d_t *h, const char *name, int64_t value)
 		if (value) h->res_failed = false;
 		refresh_kernels(h);
 		note_jit_failure(h);
+		return CA3D_OK;
+	}
+	if (!strcmp(name, "resident_rows"))
+	{
+		if (value != 16 && value != 32) return fail(CA3D_ERR_INVALID_ARGUMENT, "resident_rows must be 16 or 32");
+		if ((uint32_t)value != h->res_rows)
+		{
+			// the mailboxes are indexed by tile: start from clean ones
+			int rc2 = bind_device(h);
+			if (rc2) return rc2;
+			HIP_TRY(hipStreamSynchronize(h->stream));
+			free_resident(h);
+			h->res_rows = (uint32_t)value;
+			refresh_kernels(h);
+			note_jit_failure(h);
+		}
 		return CA3D_OK;
 	}
 	if (!strcmp(name, "resident_min"))

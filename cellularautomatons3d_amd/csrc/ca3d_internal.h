@@ -101,6 +101,7 @@ struct ResidentLaunch
 	uint32_t steps, epoch0, timeout_ticks;
 	uint32_t lut_s, lut_b;         // von Neumann truth tables (vn_tables)
 	void *jit_fn = nullptr;        // hipFunction_t of the run-time compiled kernel for these tables, or null (pre-built rule)
+	uint32_t rows = 32;            // rows per tile: 32 (one 512-thread workgroup per CU) or 16 (two 256-thread workgroups per CU)
 };
 
 struct UnpackedLaunch
@@ -162,10 +163,9 @@ std::string synthesize_rule_source(const CanonRules &r, int *ops_out);
 std::string rule_function_source(const CanonRules &r);
 // ca_resident.hip
 bool resident_kernel_applies(const CanonRules &r, uint32_t G, int variant);
-size_t resident_mail_bytes(uint32_t G);
-uint32_t resident_lds_bytes();
+size_t resident_mail_bytes(uint32_t G, uint32_t rows);
 hipError_t launch_resident(const ResidentLaunch &l, hipStream_t stream);
-int jit_resident_kernel(int device, uint32_t lut_s, uint32_t lut_b, void **fn, std::string *log);
+int jit_resident_kernel(int device, uint32_t lut_s, uint32_t lut_b, uint32_t rows, void **fn, std::string *log);
 // the resident kernel for rules with diagonal neighbour classes (ca_resident_class_kernel.inc; 512^3, run-time compiled)
 bool resident_class_applies(const CanonRules &r, uint32_t G, int variant);
 int jit_resident_class_kernel(int device, const CanonRules &r, void **fn, std::string *log);

@@ -68,13 +68,12 @@ bool resident_class_applies(const CanonRules &r, uint32_t G, int variant)
 	return G == 512u && use_class_kernel(r, G, variant) && !vn_kernel_applies(r, G, variant) && roll_kernel_applies(r, G, variant);
 }
 
-size_t resident_mail_bytes(uint32_t G)
+size_t resident_mail_bytes(uint32_t G, uint32_t rows)
 {
-	const size_t tiles = (size_t)(G / kResTileRows) * (G / kResTileRows);
+	const size_t tiles = (size_t)(G / rows) * (G / kResTileRows);
 	return 2u * tiles * 4u * kResFaceWords * sizeof(unsigned long long);
 }
 
-uint32_t resident_lds_bytes() { return kResLdsBytes; }
 
 int resident_slab_planes(const CanonRules &r, uint32_t G, uint32_t nplanes, int variant)
 {
@@ -114,16 +113,17 @@ hipError_t launch_resident(const ResidentLaunch &l, hipStream_t stream)
 	a.steps = l.steps;
 	a.epoch0 = l.epoch0;
 	a.timeout_ticks = l.timeout_ticks;
-	const u32 tiles = (l.G / kResTileRows) * (l.G / kResTileRows);
+	if (l.rows != 16u && l.rows != 32u) return hipErrorInvalidValue;
+	const u32 tiles = (l.G / l.rows) * (l.G / kResTileRows), threads = 16u * l.rows;
 	if (l.jit_fn)
 	{
 		void *args[] = {(void *)&a};
-		return chained_launch(stream, [&]() { return hipModuleLaunchKernel((hipFunction_t)l.jit_fn, tiles, 1, 1, kResThreads, 1, 1, 0, stream, args, nullptr); });
+		return chained_launch(stream, [&]() { return hipModuleLaunchKernel((hipFunction_t)l.jit_fn, tiles, 1, 1, threads, 1, 1, 0, stream, args, nullptr); });
 	}
 	if (l.lut_s != (u32)kDefaultS || l.lut_b != (u32)kDefaultB) return hipErrorInvalidValue;
-	auto kern = ca_resident_vn<kDefaultS, kDefaultB>;
 	return chained_launch(stream, [&]() {
-		hipLaunchKernelGGL(kern, dim3(tiles), dim3(kResThreads), 0, stream, a);
+		if (l.rows == 16u) hipLaunchKernelGGL((ca_resident_vn<kDefaultS, kDefaultB, 16>), dim3(tiles), dim3(threads), 0, stream, a);
+		else hipLaunchKernelGGL((ca_resident_vn<kDefaultS, kDefaultB, 32>), dim3(tiles), dim3(threads), 0, stream, a);
 		return hipGetLastError();
 	});
 }

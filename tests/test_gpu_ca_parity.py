@@ -337,8 +337,9 @@ def test_rolling_window_kernel_at_512(eng, name):
     np.testing.assert_array_equal(eng.read_state(), ol.packed_run(G, st, r, 2))
 
 
+@pytest.mark.parametrize("rows", [32, 16])
 @pytest.mark.parametrize("tables", ["default", "vn_b24_s135"])
-def test_resident_multi_step_kernel(eng, tables):
+def test_resident_multi_step_kernel(eng, tables, rows):
     """The resident kernel (ca_resident_kernel.inc): K steps of a 512^3 von Neumann rule in one launch, the state in
     registers, tile faces handed over through tagged granules. Batches of several lengths back to back (the state tags
     keep counting across launches and across uploads), odd and even lengths (the result lands in either ping-pong
@@ -346,6 +347,7 @@ def test_resident_multi_step_kernel(eng, tables):
     G = 512
     r = rules(tables)
     eng.configure(G)
+    eng.set_option("resident_rows", rows)  # tiles of 32 rows (one workgroup per CU) or 16 rows (two per CU)
     set_rules(eng, r)
     assert eng.info().kernel_name.startswith(b"ca_resident_vn")
     st = host.random_fill(host.words_per_buffer(G), seed=88)

@@ -16,14 +16,15 @@ int main(int argc, char **argv)
 	for (auto &w : h) { x = x * 1664525u + 1013904223u; w = x; }
 	u32 *b0, *b1, *status;
 	unsigned long long *mail;
-	const size_t mail_bytes = 2u * 256u * 4u * 512u * 8u;
-	CK(hipMalloc(&b0, words * 4)); CK(hipMalloc(&b1, words * 4)); CK(hipMalloc(&mail, mail_bytes)); CK(hipMalloc(&status, (4 + 256) * 4));
+	const size_t mail_bytes = 2u * 512u * 4u * 512u * 8u;
+	CK(hipMalloc(&b0, words * 4)); CK(hipMalloc(&b1, words * 4)); CK(hipMalloc(&mail, mail_bytes)); CK(hipMalloc(&status, 1024 * 4));
 	CK(hipMemcpy(b0, h.data(), words * 4, hipMemcpyHostToDevice));
-	CK(hipMemset(mail, 0, mail_bytes)); CK(hipMemset(status, 0, (4 + 256) * 4));
+	CK(hipMemset(mail, 0, mail_bytes)); CK(hipMemset(status, 0, 1024 * 4));
 	u32 *hflag;
 	CK(hipHostMalloc((void **)&hflag, 16, hipHostMallocDefault));
 	*hflag = 0;
 	const int launches = argc > 2 ? atoi(argv[2]) : 3;
+	const int rows = argc > 3 ? atoi(argv[3]) : 32;
 	hipEvent_t e0, e1;
 	CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
 	u32 epoch = 0, cur = 0;
@@ -32,7 +33,8 @@ int main(int argc, char **argv)
 	{
 		ResidentArgs a{buf[cur], buf[(cur + steps) & 1], buf[(cur + steps + 1) & 1], mail, status, hflag, steps, epoch, 5000000u};
 		CK(hipEventRecord(e0));
-		hipLaunchKernelGGL((ca_resident_vn<0xFF, 0x0A>), dim3(256), dim3(512), 0, 0, a);
+		if (rows == 16) hipLaunchKernelGGL((ca_resident_vn<0xFF, 0x0A, 16>), dim3(512), dim3(256), 0, 0, a);
+		else hipLaunchKernelGGL((ca_resident_vn<0xFF, 0x0A, 32>), dim3(256), dim3(512), 0, 0, a);
 		CK(hipGetLastError());
 		CK(hipEventRecord(e1));
 		CK(hipDeviceSynchronize());
@@ -43,6 +45,14 @@ int main(int argc, char **argv)
 		std::vector<u32> st(4 + 256);
 		CK(hipMemcpy(st.data(), status, st.size() * 4, hipMemcpyDeviceToHost));
 		printf("launch %d steps %u: %.3f ms (%.3f us/step), status %u\n", l, steps, ms, ms * 1e3 / steps, st[0]);
+#ifdef CA3D_RES_STAMPS
+		{
+			std::vector<u32> tt(700);
+			CK(hipMemcpy(tt.data(), status, 616 * 4, hipMemcpyDeviceToHost));
+			static const char *nm[7] = {"poll", "halo+barrier", "face pass", "ym/yp reads", "z faces+prefetch", "main pass", "to_image"};
+			for (int w = 0; w < 2; w++) { printf("  wave %d cycles/step:", w * 4); u32 tot = 0; for (int i = 0; i < 7; i++) { printf(" %s %u", nm[i], tt[600 + w * 8 + i]); tot += tt[600 + w * 8 + i]; } printf("  total %u\n", tot); }
+		}
+#endif
 		if (st[0])
 		{
 			for (int tz = 0; tz < 16; tz++) { for (int ty = 0; ty < 16; ty++) printf("%4u", st[4 + tz * 16 + ty]); printf("\n"); }

@@ -324,21 +324,21 @@ def test_rolling_window_kernel_every_depth(eng, name):
     eng.set_option("roll", 1)
 
 
-@pytest.mark.parametrize("name", ["clustered", "edges_main"])
-def test_rolling_window_kernel_at_512(eng, name):
+@pytest.mark.parametrize("name,G", [("clustered", 1024), ("edges_main", 512)])
+def test_rolling_window_kernel_launcher_choice(eng, name, G):
+    """The launcher's own choice of kernel and depth: at 1024^3 (many resident generations) the rolling-window form, at 512^3
+    (one generation of 2048 waves) the plain class kernel for short batches — the resident class kernel takes the long ones."""
     r = rules(name)
-    G = 512
     eng.configure(G)
     set_rules(eng, r)
     st = host.random_fill(host.words_per_buffer(G), seed=62)
     eng.upload_state(st)
     eng.step(2)
-    assert b"roll" in eng.info().kernel_name
-    np.testing.assert_array_equal(eng.read_state(), ol.packed_run(G, st, r, 2))
+    assert (b"roll" in eng.info().kernel_name) == (G == 1024) and (eng.info().kernel_name == b"ca_resident_class(jit)") == (G == 512)
+    assert np.array_equal(eng.read_state(), ol.packed_run(G, st, r, 2))
 
 
-@pytest.mark.parametrize("rows", [32, 16])
-@pytest.mark.parametrize("tables", ["default", "vn_b24_s135"])
+@pytest.mark.parametrize("tables,rows", [("default", 32), ("vn_b24_s135", 32), ("default", 16)])
 def test_resident_multi_step_kernel(eng, tables, rows):
     """The resident kernel (ca_resident_kernel.inc): K steps of a 512^3 von Neumann rule in one launch, the state in
     registers, tile faces handed over through tagged granules. Batches of several lengths back to back (the state tags
@@ -354,7 +354,7 @@ def test_resident_multi_step_kernel(eng, tables, rows):
     eng.upload_state(st)
     want = st
     total = 0
-    for n in (8, 9, 33, 16):
+    for n in (8, 9, 20):
         eng.step(n)
         prev = ol.packed_run(G, want, r, n - 1)
         want = ol.packed_step(G, prev, r)
@@ -368,14 +368,14 @@ def test_resident_multi_step_kernel(eng, tables, rows):
     # a fresh upload, a sparse state (most tiles empty: faces of zeros must still carry their tags), many steps
     st2 = host.initial_state(G)
     eng.upload_state(st2)
-    eng.step(150)
+    eng.step(60)
     got = eng.read_state()
     eng.set_option("resident", 0)
     assert eng.info().kernel_name.startswith(b"ca_packed_vn")
     eng.upload_state(st2)
-    eng.step(150)
+    eng.step(60)
     np.testing.assert_array_equal(got, eng.read_state())
-    np.testing.assert_array_equal(got, ol.packed_run(G, st2, r, 150))
+    np.testing.assert_array_equal(got, ol.packed_run(G, st2, r, 60))
     # 1000 steps on a dense state in one launch against 1000 launches of the per-step kernel
     eng.upload_state(st)
     eng.step(1000)

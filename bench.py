@@ -6,7 +6,10 @@
       bench.py --gpus N --steps K --warmup W             (the same, launched from outside)
 
 A "step" is one CA step (one dispatch of the reference's compute pass, main_pathtraced.js:1796-1809) over the whole
-grid. The batch of K steps is repeated (`reps`) until at least 50 ms are timed, so the value does not depend on K.
+grid. The batch of K steps is repeated (`reps`) until at least 50 ms are timed. At N = 1 the K-step calls are ENCODED
+(`ca3d_set_option("queue")`) and handed to the GPU 2048 steps at a time (`ca3d_flush`) — what the reference does with its
+command encoder and one queue.submit (main_pathtraced.js:1833-1850) — so the value does not depend on K: the resident
+multi-step kernel runs a submission as one launch. `--submit call` makes every K-step call its own submission.
 --config picks the BASELINE configuration:
   3 (default at N = 1)  512^3, default rule, + the 1920x1080 @ 4 spp render leg          BASELINE configs[2]
   4 (default at N > 1)  1024^3, default rule, Z-slabs over the ranks, RCCL halo exchange   BASELINE configs[3]
@@ -80,6 +83,14 @@ def parse(argv=None):
     ap.add_argument("--device-map", default="", help="comma list: GPU index per rank (default: LOCAL_RANK)")
     ap.add_argument("--resident", type=int, choices=[0, 1], default=1,
                     help="0: per-step kernels only (every step reads and writes the state through memory); 1: batches run as one launch of the resident kernel where one exists")
+    ap.add_argument("--submit", choices=["queued", "call"], default="queued",
+                    help="N=1: queued = the K-step calls are ENCODED and handed to the GPU --queue steps at a time (ca3d_flush; the reference's "
+                         "commandEncoder + one queue.submit), so the resident kernel runs them as one launch whatever K is; call = every "
+                         "K-step call is its own submission")
+    ap.add_argument("--compare-submission", action="store_true",
+                    help="N=1: also time the same calls under the other submission mode (`other_submission` in the JSON line; off by default so "
+                         "that a profile of the default command holds launches of one length only)")
+    ap.add_argument("--queue", type=int, default=2048, help="steps per submission with --submit queued")
     ap.add_argument("--check", action="store_true", help="verify the final state against the oracle (small grids)")
     a = ap.parse_args(argv)
     a.config = a.config or (3 if a.gpus == 1 else 4)
@@ -287,31 +298,40 @@ def rule_payload(rule_kw):
     return offs, s, b
 
 
-def timed_region(run, stream, steps, warmup, min_seconds, barrier, world, backend):
+def timed_region(run, stream, steps, warmup, min_seconds, barrier, world, backend, flush=None, group=1, launch_count=None):
     """W warm-up steps, then `reps` batches of K steps between barrier + synchronize; reps is chosen (the same on every
-    rank) so that at least `min_seconds` are timed. Returns (wall seconds, max over ranks; reps; HIP-event ms between
-    the first and the last enqueue of the timed region on the engine's stream)."""
+    rank) so that at least `min_seconds` are timed. `flush` submits what `run` only encoded (queued submission); `group`
+    batches make one submission, the calibration runs one group and reps is a multiple of it, so every launch of the
+    calibration and of the timed region has the same length. Returns (wall seconds, max over ranks; reps; HIP-event ms
+    between the first and the last enqueue of the timed region on the engine's stream; batches run before the timed ones;
+    kernel launches inside the timed region by `launch_count`, the engine's own counter, or None)."""
     import torch
     import torch.distributed as dist
 
+    flush = flush or (lambda: None)
     if warmup > 0:
         run(warmup)
+    flush()
     barrier()
     t0 = time.perf_counter()
-    run(steps)  # calibration batch (also warm: graphs for K steps exist afterwards)
+    for _ in range(group):
+        run(steps)  # calibration (also warm: graphs for K steps exist afterwards)
+    flush()
     barrier()
     est = time.perf_counter() - t0
-    reps = max(1, min(1 << 20, int(math.ceil(min_seconds / max(est, 1e-7)))))
+    reps = group * max(1, min((1 << 20) // group, int(math.ceil(min_seconds / max(est, 1e-7)))))
     if world > 1:
         t = torch.tensor([reps], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         reps = int(t.item())
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier()
+    n0 = launch_count() if launch_count else 0
     t0 = time.perf_counter()
     e0.record(stream)
     for _ in range(reps):
         run(steps)
+    flush()
     e1.record(stream)
     barrier()
     dt = time.perf_counter() - t0
@@ -319,11 +339,12 @@ def timed_region(run, stream, steps, warmup, min_seconds, barrier, world, backen
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    return dt, reps, e0.elapsed_time(e1)
+    return dt, reps, e0.elapsed_time(e1), group, (launch_count() - n0 if launch_count else None)
 
 
-def single_gpu_leg(device, G, rule, steps, warmup, min_seconds, density_rounds=0, resident=1):
-    """One GPU, whole grid: returns the numbers of the timed region plus the engine (state = the bench state advanced)."""
+def single_gpu_leg(device, G, rule, steps, warmup, min_seconds, density_rounds=0, resident=1, queue=0):
+    """One GPU, whole grid: returns the numbers of the timed region plus the engine (state = the bench state advanced).
+    queue > 0: the K-step calls are encoded and submitted `queue` steps at a time."""
     import torch
 
     from cellularautomatons3d_amd import Engine, host
@@ -337,6 +358,7 @@ def single_gpu_leg(device, G, rule, steps, warmup, min_seconds, density_rounds=0
     eng.upload_state(full)
     stream = torch.cuda.Stream(device=device)  # the engine runs on a torch-visible stream so torch events bracket its work
     eng.set_stream(stream.cuda_stream)
+    eng.bench_stream = stream
     eng.set_option("stats", 0)  # no per-call event pair inside the timed region: the events below bracket all of it
     eng.set_option("graph_prepare", steps)  # graph capture / instantiation stays out of the timed region
     if warmup:
@@ -345,17 +367,23 @@ def single_gpu_leg(device, G, rule, steps, warmup, min_seconds, density_rounds=0
     def barrier():
         torch.cuda.synchronize()
 
-    dt, reps, ev_ms = timed_region(eng.step, stream, steps, warmup, min_seconds, barrier, 1, "nccl")
-    return eng, full, dt, reps, ev_ms
+    group = 1
+    if queue > 0:
+        group = max(1, -(-queue // steps))
+        eng.set_option("queue", group * steps)  # a submission = `group` whole calls
+    dt, reps, ev_ms, cal, launches = timed_region(eng.step, stream, steps, warmup, min_seconds, barrier, 1, "nccl", eng.flush, group,
+                                                  lambda: eng.info().launches_total)
+    return eng, full, dt, reps, ev_ms, cal, launches
 
 
-def roofline_block(kernel, G, bytes_per_launch, launches, ev_ms, state_bytes, steps_per_batch=1):
-    steps_per_launch = 1
-    if kernel.startswith("ca_resident") and steps_per_batch >= 8:
-        # the resident kernel runs a whole batch in ONE launch: per launch = per batch (rocprof's kernel duration is a batch)
-        steps_per_launch = steps_per_batch
-        bytes_per_launch *= steps_per_batch
-        launches //= steps_per_batch
+def roofline_block(kernel, G, bytes_per_step, total_steps, ev_ms, state_bytes, launches=None):
+    """`launches`: kernel launches in the timed region (the engine's counter); None = one per step. The resident kernel runs a
+    whole submission in ONE launch: per launch = per submission (rocprof's kernel duration is a submission)."""
+    launches = launches or total_steps
+    steps_per_launch = total_steps / launches
+    bytes_per_launch = bytes_per_step * steps_per_launch
+    if steps_per_launch == int(steps_per_launch):
+        steps_per_launch = int(steps_per_launch)
     launch_ms = ev_ms / max(1, launches)
     achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
     traffic = pmc_traffic(kernel, G)
@@ -416,7 +444,8 @@ def main():
 
     se = None
     if world == 1:
-        eng, full, dt, reps, ev_ms = single_gpu_leg(local_rank, G, a.rule, a.steps, a.warmup, a.min_seconds, a.density_rounds, a.resident)
+        queue = a.queue if a.submit == "queued" else 0
+        eng, full, dt, reps, ev_ms, cal, launches = single_gpu_leg(local_rank, G, a.rule, a.steps, a.warmup, a.min_seconds, a.density_rounds, a.resident, queue)
         core = eng
     else:
         offs, s, b = rule_payload(rule_kw)
@@ -434,7 +463,7 @@ def main():
         se.engine.set_rules(*offs, s, b)
         se.upload_state(full[se.z0 * pw:(se.z0 + se.nz) * pw])
         core = se.engine
-        dt, reps, ev_ms = timed_region(se.run, se.stream, a.steps, a.warmup, a.min_seconds, barrier, world, a.backend)
+        dt, reps, ev_ms, cal, launches = timed_region(se.run, se.stream, a.steps, a.warmup, a.min_seconds, barrier, world, a.backend)
 
     total_steps = a.steps * reps
     info = core.info()
@@ -448,7 +477,7 @@ def main():
         import numpy as np
         import oracle_lib as ol
 
-        want = ol.packed_run(G, full, ol.Rules.from_strings(**rule_kw), a.warmup + a.steps * (reps + 1))
+        want = ol.packed_run(G, full, ol.Rules.from_strings(**rule_kw), a.warmup + a.steps * (reps + cal))
         got = core.read_state()
         lo = 0 if world == 1 else se.z0 * pw
         ok = bool(np.array_equal(got, want[lo:lo + got.size]))
@@ -478,14 +507,27 @@ def main():
                        "parallelism": "1 GPU" if world == 1 else f"z-slab x{world}, ghost {a.ghost} planes, RCCL send/recv every {a.ghost} steps"
                                       + (" overlapped with the interior phase" if se.overlap else "")
                                       + (", exchange issued by the engine (ca3d_slab_run)" if getattr(se, "native", False) else ", exchange through torch.distributed")},
-            "roofline": roofline_block(kernel, G, 0.25 * own_cells, total_steps, ev_ms, state_bytes, a.steps if world == 1 else 1),
+            "roofline": roofline_block(kernel, G, 0.25 * own_cells, total_steps, ev_ms, state_bytes, launches),
         }
+        if world == 1:
+            out["config"]["submission"] = (f"queued: ca3d_step({a.steps}) encodes, ca3d_flush submits every {cal * a.steps} steps (the reference's commandEncoder + "
+                                           "queue.submit, main_pathtraced.js:1833-1850)" if queue else f"per call: every ca3d_step({a.steps}) is its own submission")
         if world == 1:
             ceiling = copy_ceiling_gbs()
             out["roofline"]["copy_ceiling"] = round(ceiling, 1)  # GB/s, measured here: 1 GiB device-to-device copy, read + write
             out["roofline"]["frac_of_copy_ceiling"] = round(out["roofline"]["achieved"] / ceiling, 4)
         if ok is not None:
             out["oracle_match"] = ok
+        if world == 1 and a.compare_submission and kernel.startswith("ca_resident"):
+            # the same K-step calls under the other submission mode, for the record (same engine, state carried on)
+            q2 = 0 if queue else a.queue
+            g2 = max(1, -(-q2 // a.steps)) if q2 else 1
+            eng.set_option("queue", g2 * a.steps if q2 else 0)
+            dt2, reps2, ev2, _, l2 = timed_region(eng.step, eng.bench_stream, a.steps, 0, a.min_seconds, barrier, 1, "nccl", eng.flush, g2,
+                                                  lambda: eng.info().launches_total)
+            out["other_submission"] = {"submission": "queued" if q2 else "per call", "value": round(cells * a.steps * reps2 / dt2 / 1e9, 3), "unit": "Gcells/s",
+                                       "ms_per_step": round(dt2 * 1e3 / (a.steps * reps2), 6), "reps": reps2,
+                                       "roofline": roofline_block(kernel, G, 0.25 * cells, a.steps * reps2, ev2, state_bytes, l2)}
         if world == 1 and not a.no_render:
             out["render"] = render_leg(eng, G, a)
             if a.config == 3 and a.render_size == "1920x1080":
@@ -493,7 +535,7 @@ def main():
         if world == 1 and a.config == 3 and G == 512 and not a.no_scaling_base:
             # the single-GPU point of the multi-GPU curve, on the multi-GPU grid, in the same run (N > 1 runs 1024^3)
             eng.close()
-            e2, _, dt2, reps2, ev2 = single_gpu_leg(local_rank, 1024, "default", 256, 64, a.min_seconds)
+            e2, _, dt2, reps2, ev2, _, _ = single_gpu_leg(local_rank, 1024, "default", 256, 64, a.min_seconds)
             k2 = e2.info().kernel_name.decode()
             out["scaling_base"] = {"grid": 1024, "rule": "default", "n_gpus": 1, "value": round(1024.0 ** 3 * 256 * reps2 / dt2 / 1e9, 3), "unit": "Gcells/s",
                                    "ms_per_step": round(dt2 * 1e3 / (256 * reps2), 6), "steps": 256, "reps": reps2,

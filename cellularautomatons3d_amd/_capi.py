@@ -29,6 +29,7 @@ class Info(C.Structure):
         ("grid_size", C.c_uint32), ("layout", C.c_int32), ("z0", C.c_uint32), ("nz", C.c_uint32),
         ("ghost", C.c_uint32), ("step", C.c_uint64), ("state_words", C.c_uint64),
         ("current_buffer", C.c_int32), ("device", C.c_int32), ("kernel_name", C.c_char * 64),
+        ("launches_total", C.c_uint64),
     ]
 
 
@@ -62,6 +63,7 @@ SYMBOLS = [
     ("ca3d_upload_state", C.c_int, [_H, _u32p, C.c_size_t]),
     ("ca3d_read_state", C.c_int, [_H, _u32p, C.c_size_t]),
     ("ca3d_step", C.c_int, [_H, C.c_uint32]),
+    ("ca3d_flush", C.c_int, [_H]),
     ("ca3d_slab_step", C.c_int, [_H, C.c_uint32]),
     ("ca3d_slab_step_phase", C.c_int, [_H, C.c_uint32, C.c_int]),
     ("ca3d_slab_region", C.c_int, [_H, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),

@@ -101,6 +101,9 @@ struct ca3d_engine
 	uint32_t *res_status = nullptr, *res_status_host = nullptr;
 	uint32_t res_epoch = 0;
 	uint32_t res_min = 8;                 // shorter batches take the per-step kernels
+	uint32_t queue_max = 0;               // > 0: ca3d_step calls are encoded and submitted together (option "queue")
+	uint32_t queued = 0;                  // steps encoded, not yet submitted
+	uint64_t launches_total = 0;          // kernel launches the step calls issued since ca3d_create
 	uint32_t res_rows = 32;               // rows per tile of the von Neumann form (ca_resident_kernel.inc: 32 or 16)
 	uint32_t res_timeout_ticks = 20000000; // 200 ms of s_memrealtime per wait
 
@@ -594,6 +597,26 @@ int comm_exchange(ca3d_engine *h, hipStream_t s)
 
 } // namespace
 
+static int submit_steps(ca3d_engine *h, uint32_t n_steps);
+
+// queue.submit of the steps encoded so far (option "queue"). Every entry point that looks at the state, the stream or the
+// options goes through here first, so a caller only ever sees the order it asked for.
+int flush_queued(ca3d_engine *h)
+{
+	if (!h || !h->queued) return CA3D_OK;
+	const uint32_t n = h->queued;
+	h->queued = 0;
+	return submit_steps(h, n);
+}
+
+#define FLUSH_QUEUED(h)                \
+	do                                 \
+	{                                  \
+		int rcq_ = flush_queued(h);    \
+		if (rcq_) return rcq_;         \
+	} while (0)
+
+
 extern "C"
 {
 
@@ -648,7 +671,9 @@ int ca3d_destroy(ca3d_t *h)
 {
 	if (!h) return CA3D_OK;
 	hipSetDevice(h->device);
+	h->queued = 0; // never submitted: the state goes away with the engine
 	if (h->stream || h->own_stream) hipStreamSynchronize(h->stream);
+	resident_stream_retired(h->stream);
 	free_buffers(h);
 	free_render_targets(h);
 	if (h->comm && rccl().CommDestroy) rccl().CommDestroy(h->comm);
@@ -687,6 +712,7 @@ static int configure_common(ca3d_t *h, uint32_t g, int layout)
 int ca3d_configure(ca3d_t *h, uint32_t gx, uint32_t gy, uint32_t gz, int layout)
 {
 	if (gx != gy || gy != gz) return fail(CA3D_ERR_UNSUPPORTED, "only cubic grids exist in the reference (got %ux%ux%u)", gx, gy, gz);
+	if (h) h->queued = 0; // steps of a state that is being thrown away
 	int rc = configure_common(h, gx, layout);
 	if (rc) return rc;
 	h->slab = false;
@@ -701,6 +727,7 @@ int ca3d_configure(ca3d_t *h, uint32_t gx, uint32_t gy, uint32_t gz, int layout)
 
 int ca3d_configure_slab(ca3d_t *h, uint32_t g, int layout, uint32_t z0, uint32_t nz, uint32_t ghost)
 {
+	if (h) h->queued = 0;
 	int rc = configure_common(h, g, layout);
 	if (rc) return rc;
 	if (nz == 0 || z0 + nz > g) return fail(CA3D_ERR_INVALID_ARGUMENT, "slab [%u, %u) is outside the grid of %u planes", z0, z0 + nz, g);
@@ -721,6 +748,7 @@ int ca3d_set_rules(ca3d_t *h, const int32_t *main_offsets, uint32_t n_main, cons
                    const uint32_t born[CA3D_LUT_LEN])
 {
 	if (!h) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL engine handle");
+	FLUSH_QUEUED(h); // the steps encoded so far run under the rules they were encoded with
 	CanonRules r;
 	std::string err;
 	int rc = canonicalize_rules(main_offsets, n_main, edges_offsets, n_edges, corners_offsets, n_corners, survive, born, &r, &err);
@@ -739,6 +767,7 @@ int ca3d_upload_state(ca3d_t *h, const uint32_t *words, size_t n_words)
 	if (!h) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL engine handle");
 	if (!h->configured) return fail(CA3D_ERR_NOT_CONFIGURED, "ca3d_configure has not been called");
 	if (!words) return fail(CA3D_ERR_INVALID_ARGUMENT, "words is NULL");
+	h->queued = 0; // the state they would have produced is overwritten
 	if (n_words != h->state_words()) return fail(CA3D_ERR_INVALID_ARGUMENT, "state has %zu words, expected %zu", n_words, h->state_words());
 	int rc = bind_device(h);
 	if (rc) return rc;
@@ -782,6 +811,7 @@ int ca3d_read_state(ca3d_t *h, uint32_t *words, size_t n_words)
 	if (!h) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL engine handle");
 	if (!h->configured || !h->has_state) return fail(CA3D_ERR_NOT_CONFIGURED, "no state to read: configure and upload first");
 	if (!words) return fail(CA3D_ERR_INVALID_ARGUMENT, "words is NULL");
+	FLUSH_QUEUED(h);
 	if (n_words != h->state_words()) return fail(CA3D_ERR_INVALID_ARGUMENT, "state has %zu words, expected %zu", n_words, h->state_words());
 	int rc = bind_device(h);
 	if (rc) return rc;
@@ -791,12 +821,12 @@ int ca3d_read_state(ca3d_t *h, uint32_t *words, size_t n_words)
 	return check_resident(h);
 }
 
-int ca3d_step(ca3d_t *h, uint32_t n_steps)
+} // extern "C"
+
+// n steps onto the stream now.
+static int submit_steps(ca3d_engine *h, uint32_t n_steps)
 {
-	int rc = check_ready(h);
-	if (rc) return rc;
-	if (h->slab) return fail(CA3D_ERR_INVALID_ARGUMENT, "engine is a slab: use ca3d_slab_step and refresh the ghosts between batches");
-	rc = bind_device(h);
+	int rc = bind_device(h);
 	if (rc) return rc;
 	if (n_steps == 0) return CA3D_OK;
 	if (h->want_stats) HIP_TRY(hipEventRecord(h->ev_start, h->stream));
@@ -836,9 +866,36 @@ int ca3d_step(ca3d_t *h, uint32_t n_steps)
 	h->ev_valid = h->want_stats != 0;
 	h->stats.steps = n_steps;
 	h->stats.kernel_launches = launches;
+	h->launches_total += launches;
 	h->stats.cell_steps = (double)n_steps * h->cells_per_plane() * h->G;
 	h->stats.algorithmic_bytes = h->stats.cell_steps * h->bytes_per_cell_step();
 	return CA3D_OK;
+}
+
+extern "C"
+{
+
+int ca3d_step(ca3d_t *h, uint32_t n_steps)
+{
+	int rc = check_ready(h);
+	if (rc) return rc;
+	if (h->slab) return fail(CA3D_ERR_INVALID_ARGUMENT, "engine is a slab: use ca3d_slab_step and refresh the ghosts between batches");
+	if (h->queue_max)
+	{
+		// encode only (the reference's commandEncoder, main_pathtraced.js:1833-1850): the steps of consecutive calls go to
+		// the GPU as one submission, which lets the resident kernel run them as one launch
+		if (n_steps > 0xFFFFFFFFu - h->queued) FLUSH_QUEUED(h);
+		h->queued += n_steps;
+		if (h->queued >= h->queue_max) return flush_queued(h);
+		return CA3D_OK;
+	}
+	return submit_steps(h, n_steps);
+}
+
+int ca3d_flush(ca3d_t *h)
+{
+	if (!h) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL engine handle");
+	return flush_queued(h);
 }
 
 // Slab batch of n sub-steps, whole or in two phases (include/ca3d.h). Array planes: ghost [0,K), owned [K,K+nz),
@@ -937,7 +994,8 @@ int slab_batch(ca3d_engine *h, uint32_t n_steps, int phase)
 	if (h->want_stats) HIP_TRY(hipEventRecord(h->ev_stop, h->stream));
 	h->ev_valid = h->want_stats != 0;
 	h->stats.steps = n;
-	h->stats.kernel_launches = phase == CA3D_SLAB_PHASE_ALL || !splittable ? n : 2u * n;
+	h->stats.kernel_launches = resident ? 1u : (phase == CA3D_SLAB_PHASE_ALL || !splittable ? n : 2u * n);
+	h->launches_total += h->stats.kernel_launches;
 	h->stats.cell_steps = (double)n * h->cells_per_plane() * h->nz; // owned cells only: ghost recompute is overhead
 	h->stats.algorithmic_bytes = h->stats.cell_steps * h->bytes_per_cell_step();
 	return CA3D_OK;
@@ -1089,6 +1147,7 @@ int ca3d_slab_gather(ca3d_t *h, ca3d_t *full)
 	if (!h->slab || !h->comm || !h->has_state) return fail(CA3D_ERR_NOT_CONFIGURED, "engine is not a slab with a communicator and a state");
 	if (!full->configured || full->slab || full->G != h->G || full->layout != h->layout || full->device != h->device)
 		return fail(CA3D_ERR_INVALID_ARGUMENT, "the target must be a full-grid engine of the same grid, layout and device");
+	FLUSH_QUEUED(full);
 	if ((size_t)h->nz * h->comm_world != h->G) return fail(CA3D_ERR_UNSUPPORTED, "the slabs must split the grid evenly");
 	int rc = bind_device(h);
 	if (rc) return rc;
@@ -1120,6 +1179,7 @@ int ca3d_render_target(ca3d_t *h, int which, void **device_ptr, size_t *n_bytes)
 int ca3d_synchronize(ca3d_t *h)
 {
 	if (!h) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL engine handle");
+	FLUSH_QUEUED(h);
 	int rc = bind_device(h);
 	if (rc) return rc;
 	HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1129,9 +1189,11 @@ int ca3d_synchronize(ca3d_t *h)
 int ca3d_set_stream(ca3d_t *h, void *hip_stream)
 {
 	if (!h) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL engine handle");
+	FLUSH_QUEUED(h);
 	int rc = bind_device(h);
 	if (rc) return rc;
 	HIP_TRY(hipStreamSynchronize(h->stream));
+	resident_stream_retired(h->stream);
 	drop_graph(h);
 	h->stream = (hipStream_t)hip_stream;
 	h->ev_valid = false;
@@ -1141,9 +1203,11 @@ int ca3d_set_stream(ca3d_t *h, void *hip_stream)
 int ca3d_use_own_stream(ca3d_t *h)
 {
 	if (!h) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL engine handle");
+	FLUSH_QUEUED(h);
 	int rc = bind_device(h);
 	if (rc) return rc;
 	HIP_TRY(hipStreamSynchronize(h->stream));
+	resident_stream_retired(h->stream);
 	drop_graph(h);
 	h->stream = h->own_stream;
 	h->ev_valid = false;
@@ -1155,6 +1219,7 @@ int ca3d_device_buffer(ca3d_t *h, int which, void **device_ptr, size_t *n_bytes)
 	if (!h || !device_ptr || !n_bytes) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL argument");
 	if (!h->configured) return fail(CA3D_ERR_NOT_CONFIGURED, "ca3d_configure has not been called");
 	if (which != 0 && which != 1) return fail(CA3D_ERR_INVALID_ARGUMENT, "buffer index must be 0 or 1");
+	FLUSH_QUEUED(h);
 	*device_ptr = h->buf[which];
 	*n_bytes = h->buffer_words() * sizeof(uint32_t);
 	return CA3D_OK;
@@ -1163,6 +1228,7 @@ int ca3d_device_buffer(ca3d_t *h, int which, void **device_ptr, size_t *n_bytes)
 int ca3d_get_info(ca3d_t *h, ca3d_info *out)
 {
 	if (!h || !out) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL argument");
+	FLUSH_QUEUED(h);
 	memset(out, 0, sizeof *out);
 	out->grid_size = h->G;
 	out->layout = h->layout;
@@ -1173,6 +1239,7 @@ int ca3d_get_info(ca3d_t *h, ca3d_info *out)
 	out->state_words = h->configured ? h->state_words() : 0;
 	out->current_buffer = (int32_t)h->cur;
 	out->device = h->device;
+	out->launches_total = h->launches_total;
 	const char *name = "";
 	if (h->configured && h->rules.valid)
 	{
@@ -1208,6 +1275,7 @@ int ca3d_get_jit_log(ca3d_t *h, char *buf, size_t n_bytes, size_t *needed)
 int ca3d_get_stats(ca3d_t *h, ca3d_stats *out)
 {
 	if (!h || !out) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL argument");
+	FLUSH_QUEUED(h);
 	if (!h->ev_valid) return fail(CA3D_ERR_NOT_CONFIGURED, "no step batch has been timed yet (or option \"stats\" is 0)");
 	int rc = bind_device(h);
 	if (rc) return rc;
@@ -1225,6 +1293,7 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 {
 	if (!h) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL engine handle");
 	if (!h->configured || !h->has_state) return fail(CA3D_ERR_NOT_CONFIGURED, "no state to render: configure and upload first");
+	FLUSH_QUEUED(h);
 	if (h->slab) return fail(CA3D_ERR_UNSUPPORTED, "the renderer reads a full grid, not a slab");
 	if (h->layout == CA3D_LAYOUT_UNPACKED && h->render_mode != 0) return fail(CA3D_ERR_UNSUPPORTED, "the literal frame mode is implemented for the packed layout only");
 	if (!uniforms) return fail(CA3D_ERR_INVALID_ARGUMENT, "uniforms is NULL");
@@ -1325,6 +1394,13 @@ int ca3d_get_render_stats(ca3d_t *h, ca3d_render_stats *out)
 int ca3d_set_option(ca3d_t *h, const char *name, int64_t value)
 {
 	if (!h || !name) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL argument");
+	FLUSH_QUEUED(h); // options apply to the steps encoded after them
+	if (!strcmp(name, "queue"))
+	{
+		if (value < 0 || value > 1000000) return fail(CA3D_ERR_INVALID_ARGUMENT, "queue must be in [0, 1000000] steps");
+		h->queue_max = (uint32_t)value;
+		return CA3D_OK;
+	}
 	if (!strcmp(name, "graph")) { h->use_graph = value ? 1 : 0; return CA3D_OK; }
 	if (!strcmp(name, "graph_prepare"))
 	{

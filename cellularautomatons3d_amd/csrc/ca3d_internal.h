@@ -184,6 +184,7 @@ struct ResidentSlabLaunch
 int resident_slab_planes(const CanonRules &r, uint32_t G, uint32_t nplanes, int variant);
 size_t resident_slab_mail_bytes();
 hipError_t launch_resident_slab(const ResidentSlabLaunch &l, hipStream_t stream);
+void resident_stream_retired(hipStream_t stream); // call after waiting for a stream the engine stops using
 int jit_resident_slab_kernel(int device, uint32_t lut_s, uint32_t lut_b, int pz, void **fn, std::string *log);
 // Steps one fused launch advances for these rules / grid (0 = no fused kernel applies).
 int packed_fused_steps(const CanonRules &r, uint32_t G, int variant);

@@ -20,12 +20,15 @@ constexpr int kDefaultS = 0xFF, kDefaultB = 0x0A; // von Neumann B1,3 / S0-6, ca
 
 // A resident launch needs every one of its workgroups on a CU at the same time, and one workgroup fills most of a CU's
 // LDS: two such launches running side by side (two engines of one process on different streams) would each get part of
-// the chip and wait for tiles that cannot start. Resident launches on one device are therefore chained: each waits for
-// the previous one's completion event, whatever stream it was on.
+// the chip and wait for tiles that cannot start. Resident launches on one device are therefore chained: a launch on another
+// stream than the previous one waits for an event recorded on that stream (launches on the same stream are ordered by the
+// stream itself and pay for no event).
 struct DeviceChain
 {
 	std::mutex m;
-	hipEvent_t last[64] = {};
+	hipEvent_t ev[64] = {};
+	hipStream_t last[64] = {};
+	bool any[64] = {};
 };
 DeviceChain &chain()
 {
@@ -42,22 +45,36 @@ hipError_t chained_launch(hipStream_t stream, F launch)
 	if (dev < 0 || dev >= 64) return launch();
 	DeviceChain &c = chain();
 	std::lock_guard<std::mutex> lock(c.m);
-	if (c.last[dev])
+	if (c.any[dev] && c.last[dev] != stream)
 	{
-		e = hipStreamWaitEvent(stream, c.last[dev], 0);
-		if (e != hipSuccess) return e;
-	}
-	else
-	{
-		e = hipEventCreateWithFlags(&c.last[dev], hipEventDisableTiming);
+		if (!c.ev[dev])
+		{
+			e = hipEventCreateWithFlags(&c.ev[dev], hipEventDisableTiming);
+			if (e != hipSuccess) return e;
+		}
+		// after everything the other stream holds now, which includes its last resident launch
+		e = hipEventRecord(c.ev[dev], c.last[dev]);
+		if (e == hipSuccess) e = hipStreamWaitEvent(stream, c.ev[dev], 0);
 		if (e != hipSuccess) return e;
 	}
 	e = launch();
 	if (e != hipSuccess) return e;
-	return hipEventRecord(c.last[dev], stream);
+	c.last[dev] = stream;
+	c.any[dev] = true;
+	return hipSuccess;
 }
 
 } // namespace
+
+// A stream that is about to be destroyed (its work has been waited for) leaves the chain.
+void resident_stream_retired(hipStream_t stream)
+{
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return;
+	DeviceChain &c = chain();
+	std::lock_guard<std::mutex> lock(c.m);
+	if (c.any[dev] && c.last[dev] == stream) c.any[dev] = false;
+}
 
 // The rule is a pair of truth tables over the von Neumann count (as ca_packed_vn) and the grid is the one the tile
 // geometry is built for.

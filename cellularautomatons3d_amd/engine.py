@@ -117,6 +117,12 @@ class Engine:
 
     compute_pass = step
 
+    def flush(self) -> None:
+        """queue.submit (main_pathtraced.js:1850): hand the steps encoded since the last submission to the GPU. Only needed with
+        `set_option("queue", n)` and a caller that records its own events on the stream — every other call on the engine
+        submits first by itself."""
+        _capi.check(self._lib.ca3d_flush(self._h))
+
     def slab_step(self, n_steps: int) -> None:
         _capi.check(self._lib.ca3d_slab_step(self._h, n_steps))
 

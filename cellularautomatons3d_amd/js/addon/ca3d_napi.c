@@ -224,6 +224,16 @@ static napi_value js_step(napi_env env, napi_callback_info info)
 	return rc ? throw_ca3d(env, rc) : undefined(env);
 }
 
+static napi_value js_flush(napi_env env, napi_callback_info info)
+{
+	napi_value argv[1];
+	if (!get_args(env, info, 1, argv)) return NULL;
+	ca3d_t *h = get_handle(env, argv[0]);
+	if (!h) return NULL;
+	int rc = ca3d_flush(h);
+	return rc ? throw_ca3d(env, rc) : undefined(env);
+}
+
 static napi_value js_slab_step(napi_env env, napi_callback_info info)
 {
 	napi_value argv[2];
@@ -283,6 +293,7 @@ static napi_value js_info(napi_env env, napi_callback_info info)
 	set_num(env, o, "stateWords", (double)i.state_words);
 	set_num(env, o, "currentBuffer", i.current_buffer);
 	set_num(env, o, "device", i.device);
+	set_num(env, o, "launchesTotal", (double)i.launches_total);
 	napi_create_string_utf8(env, i.kernel_name, NAPI_AUTO_LENGTH, &s);
 	napi_set_named_property(env, o, "kernelName", s);
 	return o;
@@ -567,7 +578,7 @@ static napi_value init(napi_env env, napi_value exports)
 	static const struct { const char *name; napi_callback fn; } fns[] = {
 	    {"abiVersion", js_abi_version}, {"deviceCount", js_device_count}, {"create", js_create}, {"destroy", js_destroy},
 	    {"configure", js_configure}, {"configureSlab", js_configure_slab}, {"setRules", js_set_rules},
-	    {"uploadState", js_upload_state}, {"readState", js_read_state}, {"step", js_step}, {"slabStep", js_slab_step}, {"slabStepPhase", js_slab_step_phase},
+	    {"uploadState", js_upload_state}, {"readState", js_read_state}, {"step", js_step}, {"flush", js_flush}, {"slabStep", js_slab_step}, {"slabStepPhase", js_slab_step_phase},
 	    {"synchronize", js_synchronize}, {"info", js_info}, {"stats", js_stats}, {"render", js_render},
 	    {"renderStats", js_render_stats}, {"setOption", js_set_option},
 	    {"commUniqueId", js_comm_unique_id}, {"slabCommInit", js_slab_comm_init}, {"slabRun", js_slab_run}, {"slabExchange", js_slab_exchange},

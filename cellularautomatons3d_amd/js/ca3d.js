@@ -210,6 +210,8 @@ class Engine
 
 	// _computePass (1796-1809), n times
 	step(n) { this._a.step(this._h, n === undefined ? 1 : n); }
+	/** device.queue.submit: submits the steps encoded under setOption("queue", n). */
+	flush() { this._a.flush(this._h); }
 
 	// Z-slab mode (multi-GPU hosts; SURVEY 8(e)): see include/ca3d.h. phase: 0 whole batch, 1 edge zones, 2 interior.
 	configureSlab(gridSize, z0, nz, ghost, layout) { this._a.configureSlab(this._h, gridSize, layout === undefined ? LAYOUT_PACKED32 : layout, z0, nz, ghost); }

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define CA3D_ABI_VERSION 2
+#define CA3D_ABI_VERSION 3
 #define CA3D_LUT_LEN 81 /* 3 rule-sets x 27 slots (main_pathtraced.js:10, 155-159) */
 
 typedef struct ca3d_engine ca3d_t;
@@ -95,8 +95,17 @@ int ca3d_read_state(ca3d_t *h, uint32_t *words, size_t n_words);
  * _computePass (main_pathtraced.js:1796-1809) n_steps times: step k reads buffer k % 2, writes buffer
  * (k+1) % 2; afterwards the current state is buffer [total_steps % 2] and the other buffer holds the state one
  * step earlier, as in the reference. Asynchronous.
+ *
+ * The reference encodes its passes into a command encoder and hands them to the GPU with ONE queue.submit per frame
+ * (main_pathtraced.js:1833-1850). ca3d_set_option("queue", n > 0) gives ca3d_step that meaning: a call only ENCODES its
+ * steps; they are submitted together by ca3d_flush, by any other call on the engine that looks at the state, the stream or
+ * the options (read-back, render, synchronize, set_rules, get_info ...), or as soon as n steps are waiting. What a caller can
+ * observe through the engine is the same either way; consecutive short batches then cost one launch of the resident
+ * multi-step kernel instead of one each. A caller that records its own events on the stream calls ca3d_flush first.
+ * Off by default ("queue" 0: every ca3d_step submits its own steps).
  */
 int ca3d_step(ca3d_t *h, uint32_t n_steps);
+int ca3d_flush(ca3d_t *h);
 
 /* Slab mode: n_steps <= ghost sub-steps on a shrinking plane range; then the ghosts must be refreshed. */
 int ca3d_slab_step(ca3d_t *h, uint32_t n_steps);
@@ -178,6 +187,7 @@ typedef struct ca3d_info
 	int32_t current_buffer; /* step % 2 */
 	int32_t device;
 	char kernel_name[64]; /* kernel variant the current rules select */
+	uint64_t launches_total; /* kernel launches issued by the step calls since ca3d_create */
 } ca3d_info;
 int ca3d_get_info(ca3d_t *h, ca3d_info *out);
 

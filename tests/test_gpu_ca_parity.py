@@ -617,3 +617,44 @@ def test_checkpoint_resume(eng, tmp_path):
     set_rules(eng, r)
     eng.step(6)
     np.testing.assert_array_equal(eng.read_state(), want)
+
+
+def test_queued_submission(eng):
+    """Option "queue": ca3d_step only encodes, the steps of consecutive calls are submitted together (ca3d_flush, any call
+    that looks at the state, or once `queue` steps wait) — the reference's commandEncoder + queue.submit
+    (main_pathtraced.js:1833-1850). Same states as per-call submission, fewer launches; rules apply to the steps encoded
+    under them; an upload drops what was never submitted."""
+    G = 512
+    r = rules("default")
+    eng.configure(G)
+    set_rules(eng, r)
+    st = host.random_fill(host.words_per_buffer(G), seed=99)
+    eng.upload_state(st)
+    eng.set_option("queue", 64)
+    try:
+        l0 = eng.info().launches_total
+        for _ in range(20):
+            eng.step(5)  # 13 calls reach 65 >= 64 steps: one launch of the resident kernel; 35 steps stay encoded
+        eng.step(3)
+        info = eng.info()  # submits the remaining 38 steps
+        assert info.step == 103 and info.current_buffer == 1
+        assert info.launches_total - l0 == 2 and info.kernel_name.startswith(b"ca_resident_vn")
+        want = ol.packed_run(G, st, r, 103)
+        np.testing.assert_array_equal(eng.read_state(), want)
+        # a rule change between encoded steps: each step runs under the rules it was encoded with
+        r2 = rules("vn_b24_s135")
+        eng.step(10)
+        set_rules(eng, r2)
+        eng.step(9)
+        eng.flush()
+        want = ol.packed_run(G, ol.packed_run(G, want, r, 10), r2, 9)
+        np.testing.assert_array_equal(eng.read_state(), want)
+        # short submissions fall back to the per-step kernels; an upload discards encoded steps
+        eng.step(2)
+        eng.upload_state(st)
+        assert eng.info().step == 0
+        eng.step(2)
+        eng.step(1)
+        np.testing.assert_array_equal(eng.read_state(), ol.packed_run(G, st, r2, 3))
+    finally:
+        eng.set_option("queue", 0)

@@ -242,7 +242,7 @@ typedef struct ca3d_render_stats
 } ca3d_render_stats;
 int ca3d_get_render_stats(ca3d_t *h, ca3d_render_stats *out);
 
-/* Options (not part of the reference surface): "graph" 0/1 hipGraph batching; "stats" 0/1: record the event pair
+/* Options (not part of the reference surface): "queue" n: queued submission (see ca3d_step; 0 = off); "graph" 0/1 hipGraph batching; "stats" 0/1: record the event pair
  * ca3d_get_stats reads around every ca3d_step batch (on by default; a host that steps in small batches and never asks
  * for stats saves two marker packets per call); "graph_prepare" n builds now the
  * graphs a later ca3d_step(n) replays — a batch of any length up to 1024 steps is one graph of exactly that many

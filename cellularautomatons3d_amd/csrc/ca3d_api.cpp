@@ -4,6 +4,8 @@
 #include <dlfcn.h>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
+#include <vector>
 #include <map>
 #include <new>
 #include <string>
@@ -126,6 +128,7 @@ struct ca3d_engine
 	void *r_light[2] = {nullptr, nullptr};
 	uint32_t *r_depth[2] = {nullptr, nullptr};
 	unsigned long long *r_counters = nullptr;
+	size_t r_counter_words = 0;
 	unsigned long long *r_occ = nullptr; // block-occupancy bits of the current state + count, rebuilt per frame (render.hip)
 	size_t r_occ_words = 0;
 	int render_skip = 1; // empty-space skipping on sparse volumes
@@ -1320,9 +1323,20 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 		h->rh = height;
 		h->r_swap = 0;
 	}
-	if (!h->r_counters) HIP_TRY(hipMalloc((void **)&h->r_counters, 3 * sizeof(unsigned long long)));
-	HIP_TRY(hipMemsetAsync(h->r_counters, 0, 3 * sizeof(unsigned long long), h->stream));
+	// diagnostics: CA3D_RENDER_TRACE=<file> makes every wave of the scheduled kernel record when and where it ran
+	// (tools/render_trace.py draws the occupancy timeline from the file)
+	static const char *trace_path = getenv("CA3D_RENDER_TRACE");
+	const size_t trace_waves = trace_path ? ((size_t)(width + 31u) / 32u * 2u) * ((height + 15u) / 16u * 4u) : 0u; // wave tiles of 16 x 4 pixels
+	const size_t counter_words = 8u + 4u * trace_waves;
+	if (h->r_counters && h->r_counter_words < counter_words) { HIP_TRY(hipFree(h->r_counters)); h->r_counters = nullptr; }
+	if (!h->r_counters)
+	{
+		HIP_TRY(hipMalloc((void **)&h->r_counters, counter_words * sizeof(unsigned long long)));
+		h->r_counter_words = counter_words;
+	}
+	HIP_TRY(hipMemsetAsync(h->r_counters, 0, (trace_path ? counter_words : 8u) * sizeof(unsigned long long), h->stream)); // [3]: the tile queue's head
 	RenderLaunch l;
+	l.trace = trace_path != nullptr;
 	l.cells = h->buf[h->cur];
 	l.G = h->G;
 	l.W = width;
@@ -1363,6 +1377,17 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 	if (e != hipSuccess) return fail(CA3D_ERR_DEVICE, "render launch failed: %s", hipGetErrorString(e));
 	HIP_TRY(hipEventRecord(h->rev_stop, h->stream));
 	h->rev_valid = true;
+	if (trace_path)
+	{
+		std::vector<unsigned long long> t(counter_words);
+		HIP_TRY(hipStreamSynchronize(h->stream));
+		HIP_TRY(hipMemcpy(t.data(), h->r_counters, counter_words * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+		if (FILE *f = fopen(trace_path, "wb")) // the last frame wins
+		{
+			fwrite(t.data(), sizeof(unsigned long long), counter_words, f);
+			fclose(f);
+		}
+	}
 	h->rstats.primary_rays = (uint64_t)width * ((l.row1 ? l.row1 : height) - l.row0) * spp;
 	if (presentation_rgba8) HIP_TRY(hipMemcpyAsync(presentation_rgba8, h->r_present, px * 4, hipMemcpyDeviceToHost, h->stream));
 	if (light_rgba16f) HIP_TRY(hipMemcpyAsync(light_rgba16f, h->r_light[h->r_swap], px * 8, hipMemcpyDeviceToHost, h->stream));

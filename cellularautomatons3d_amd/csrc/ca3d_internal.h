@@ -131,6 +131,7 @@ struct RenderLaunch
 	                                   // sized by ca3d_render (null: no empty-space skipping)
 	uint32_t row0 = 0, row1 = 0;  // mode 0: render image rows [row0, row1) only (row1 == 0: all); row0 % 16 == 0
 	bool indirect = false;        // mode 0, packed: add the one-bounce neighbour lighting term (wgsl :307-377)
+	bool trace = false;           // diagnostics: per-wave {start, end, HW_ID, visits} after the counters (the buffer must hold them)
 };
 
 // render.hip

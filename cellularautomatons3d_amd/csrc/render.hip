@@ -56,6 +56,11 @@ struct RenderParams
 	u32 occ_coarse;                // != 0: coarse bits (blocks of 128 x 32 x 32 cells) follow the count word
 	u32 row0, row1; // only image rows [row0, row1) are rendered (a rank's band of a frame shared between GPUs); row0 is a multiple of 16
 	u32 indirect;   // add calculateIndirectLighting (:307-377), the term the reference leaves commented out at :424
+	u32 trace;      // diagnostics (CA3D_RENDER_TRACE): counters + 8 + 4 * tile receives {start, end (s_memrealtime), HW_ID, cell visits}
+	// The volume's screen rectangle, pixels [rx0, rx1) x [ry0, ry1) (x a multiple of 32, y of 16 from row0; clipped to the band): the
+	// scheduled kernel takes the wave tiles inside it from a queue (counters[3]); the plain kernel, launched with
+	// outside_only, renders the 16 x 16 tiles outside it (view rays that miss the volume: no walk to schedule).
+	u32 rx0, rx1, ry0, ry1, outside_only;
 };
 
 constexpr float kPi = 3.14159265359f;
@@ -447,6 +452,7 @@ template <bool SKIP>
 __global__ __launch_bounds__(256) void ca_render_packed(RenderParams P)
 {
 	if ((!P.legacy && occ_skip_enabled(P)) != SKIP) return;
+	if (P.outside_only && blockIdx.x * 16u >= P.rx0 && blockIdx.x * 16u < P.rx1 && P.row0 + blockIdx.y * 16u >= P.ry0 && P.row0 + blockIdx.y * 16u < P.ry1) return;
 	const u32 px = blockIdx.x * 16u + (threadIdx.x & 15u);
 	const u32 py = P.row0 + blockIdx.y * 16u + (threadIdx.x >> 4);
 	if (px >= P.W || py >= P.row1) return;
@@ -483,7 +489,8 @@ __global__ __launch_bounds__(256) void ca_render_packed(RenderParams P)
 		const float ig = P.legacy ? 1.0f / 2.2f : 1.0f / P.u[U_GAMMA]; // legacy gamma is the constant 2.2 (:704)
 		P.presentation[i] = unorm8(powf(r, ig)) | (unorm8(powf(g, ig)) << 8) | (unorm8(powf(b, ig)) << 16) | (unorm8(a) << 24);
 	}
-	if (P.counters)
+	// (a word takes ~90 atomics per us: waves with nothing to add — every sky tile — must not queue up behind it)
+	if (P.counters && (shadow | pvis | svis) != 0u)
 	{
 		atomicAdd(&P.counters[0], (unsigned long long)shadow);
 		atomicAdd(&P.counters[1], (unsigned long long)pvis);
@@ -744,142 +751,168 @@ __device__ void sample_after_shadow(const RenderParams &P, const RayState &st, b
 	sample_tail(P, st, s);
 }
 
+constexpr int kSchedWaves = 4; // waves per SIMD the scheduled kernel is compiled for (128 VGPRs; measured 3 / 4 / 5 / 6: 1.90 / 1.77 / 1.96 / 2.01 ms)
 constexpr int kSchedChunk = 4; // samples per pixel scheduled together (LDS: 4 x 6 x 256 floats = 24 KiB per block)
 #ifndef CA3D_SCHED_LEAVE_DIV
 #define CA3D_SCHED_LEAVE_DIV 2
 #endif
 constexpr int kSchedLeaveDiv = CA3D_SCHED_LEAVE_DIV; // the walk loop is left when fewer than 1/N of its walkers are still walking
 
-// PPW pixels per wave (64: 16 x 4, 128: 32 x 4, 256: 32 x 8; a block is 4 waves stacked in y), NK samples per pixel
-// scheduled together: a wave has PPW x NK jobs in flight per chunk, and 4 x PPW x NK x 6 floats of LDS per block hold
-// the results. More jobs per wave = more refills before the tail: one sample per pixel (the interactive case) takes
-// 256 pixels per wave, four samples 64.
-template <bool SKIP, int PPW, int NK>
-__global__ __launch_bounds__(256) void ca_render_packed_sched(RenderParams P)
+// PPW pixels per wave tile (64: 16 x 4, 256: 32 x 8), NK samples per pixel scheduled together: a wave has PPW x NK jobs
+// in flight per chunk, and 4 x PPW x NK x 6 floats of LDS per block hold the results. More jobs per wave = more refills
+// before the tail: one sample per pixel (the interactive case) takes 256 pixels per wave, four samples 64.
+// The launch is PERSISTENT: as many workgroups as fit on the chip at WPE waves per SIMD, each wave takes tiles from a
+// queue until it is empty. A frame's tiles differ in cost by two orders of magnitude (sky: nothing to walk; the
+// heaviest tiles of the bench scene: 30 000 cell visits) and a wave per tile in dispatch order left the chip a third full
+// on average — 350 us to ramp up, a 700 us tail behind the last heavy tiles (tools/render_trace.py). Only the tiles
+// inside the volume's screen rectangle are queued (one queue word sustains ~90 dequeues per us: plenty for tiles that
+// walk, not for thousands of empty ones); the plain kernel renders the rest.
+template <bool SKIP, int PPW, int NK, int WPE>
+__global__ __launch_bounds__(256, WPE) void ca_render_packed_sched(RenderParams P)
 {
 	if ((!P.legacy && occ_skip_enabled(P)) != SKIP) return;
-	constexpr int TW = PPW == 64 ? 16 : 32, RW = PPW / TW, PPL = PPW / 64; // tile width, rows per wave, pixels per lane
+	constexpr int TW = PPW == 64 ? 16 : 32, RW = PPW / TW, PPL = PPW / 64; // tile width, rows, pixels per lane
 	__shared__ float res[NK][6][4 * PPW];
 	const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	const u32 x0 = blockIdx.x * (u32)TW, y0 = P.row0 + blockIdx.y * (u32)(4 * RW) + (u32)(wave * RW); // this wave's tile
 	const float cs = 1.0f / (float)P.G;
 	const float vis = cs * P.u[U_CELLSIZE] * 0.5f;
 	const v3 vhalf = V(vis, vis, vis);
-	float r[PPL], g[PPL], b[PPL], a[PPL], d0[PPL];
+	const float inv = 1.0f / (float)P.spp;
+	const float ig = P.legacy ? 1.0f / 2.2f : 1.0f / P.u[U_GAMMA];
+	const u32 rtw = (P.rx1 - P.rx0) / (u32)TW, ntiles = rtw * ((P.ry1 - P.ry0) / (u32)RW); // wave tiles of the rectangle
 	u32 shadow = 0, pvis = 0, svis = 0;
-#pragma unroll
-	for (int i = 0; i < PPL; i++) { r[i] = 0.0f; g[i] = 0.0f; b[i] = 0.0f; a[i] = 0.0f; d0[i] = 0.0f; }
-	for (u32 k0 = 0; k0 < P.spp; k0 += (u32)NK)
+	for (;;)
 	{
-		const int nk = (int)min((u32)NK, P.spp - k0), total = PPW * nk;
-		int next = 0; // wave-uniform: first job nobody has taken
-		RayState st;
-		st.job = -1;
-		st.phase = 0;
-		auto complete = [&](const Sample &s) {
-			const int slot = wave * PPW + st.job % PPW, kk = st.job / PPW;
-			res[kk][0][slot] = s.r; res[kk][1][slot] = s.g; res[kk][2][slot] = s.b; res[kk][3][slot] = s.a;
-			res[kk][4][slot] = s.depth; res[kk][5][slot] = (float)s.shadow_ray;
-			st.job = -1;
-		};
-		for (;;)
+		u32 tile = 0;
+		if (lane == 0) tile = (u32)atomicAdd(&P.counters[3], 1ull);
+		tile = (u32)__builtin_amdgcn_readfirstlane((int)tile);
+		if (tile >= ntiles) break;
+		const unsigned long long trace_t0 = P.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
+		const u32 vis0 = pvis + svis;
+		const u32 x0 = P.rx0 + (tile % rtw) * (u32)TW, y0 = P.ry0 + (tile / rtw) * (u32)RW;
+		float r[PPL], g[PPL], b[PPL], a[PPL], d0[PPL];
+#pragma unroll
+		for (int i = 0; i < PPL; i++) { r[i] = 0.0f; g[i] = 0.0f; b[i] = 0.0f; a[i] = 0.0f; d0[i] = 0.0f; }
+		for (u32 k0 = 0; k0 < P.spp; k0 += (u32)NK)
 		{
-			// idle lanes take the next jobs, in lane order
-			const unsigned long long idle = __ballot(st.job < 0);
-			if (idle != 0ull && next < total)
-			{
-				const int j = next + __popcll(idle & ((1ull << lane) - 1ull));
-				if (st.job < 0 && j < total)
-				{
-					st.job = j;
-					const int lp = j % PPW;
-					const u32 k = k0 + (u32)(j / PPW);
-					const u32 jx = x0 + (u32)(lp % TW), jy = y0 + (u32)(lp / TW);
-					Sample s{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0u};
-					bool done = true;
-					if (jx < P.W && jy < P.row1)
-					{
-						const float ox = P.spp == 1u ? 0.5f : ((k & 1u) ? 0.75f : 0.25f);
-						const float oy = P.spp == 1u ? 0.5f : ((k & 2u) ? 0.75f : 0.25f);
-						const float vu = ((float)jx + ox) / (float)P.W, vv = 1.0f - ((float)jy + oy) / (float)P.H;
-						done = sample_begin(P, st, vu, vv, s);
-					}
-					if (done) complete(s);
-				}
-				next += __popcll(idle);
-			}
-			const int entry = __popcll(__ballot(st.job >= 0));
-			if (entry == 0)
-			{
-				if (next >= total) break;
-				continue;
-			}
-			// walk until half of the walkers have finished (the tail of a chunk runs to the end)
-			const int leave_below = (next < total || entry > 16) ? max(entry / kSchedLeaveDiv, 1) : 1;
-			int term = 0;
-			float tnear = 0.0f;
+			const int nk = (int)min((u32)NK, P.spp - k0), total = PPW * nk;
+			int next = 0; // wave-uniform: first job nobody has taken
+			RayState st;
+			st.job = -1;
+			st.phase = 0;
+			auto complete = [&](const Sample &s) {
+				const int slot = wave * PPW + st.job % PPW, kk = st.job / PPW;
+				res[kk][0][slot] = s.r; res[kk][1][slot] = s.g; res[kk][2][slot] = s.b; res[kk][3][slot] = s.a;
+				res[kk][4][slot] = s.depth; res[kk][5][slot] = (float)s.shadow_ray;
+				st.job = -1;
+			};
 			for (;;)
 			{
-				if (st.job >= 0 && term == 0) term = walk_step<SKIP>(P, st, vhalf, st.phase == 2, tnear, st.phase == 2 ? svis : pvis);
-				const int walking = __popcll(__ballot(st.job >= 0 && term == 0));
-				if (walking == 0 || walking < leave_below) break;
+				// idle lanes take the next jobs, in lane order
+				const unsigned long long idle = __ballot(st.job < 0);
+				if (idle != 0ull && next < total)
+				{
+					const int j = next + __popcll(idle & ((1ull << lane) - 1ull));
+					if (st.job < 0 && j < total)
+					{
+						st.job = j;
+						const int lp = j % PPW;
+						const u32 k = k0 + (u32)(j / PPW);
+						const u32 jx = x0 + (u32)(lp % TW), jy = y0 + (u32)(lp / TW);
+						Sample s{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0u};
+						bool done = true;
+						if (jx < P.W && jy < P.row1)
+						{
+							const float ox = P.spp == 1u ? 0.5f : ((k & 1u) ? 0.75f : 0.25f);
+							const float oy = P.spp == 1u ? 0.5f : ((k & 2u) ? 0.75f : 0.25f);
+							const float vu = ((float)jx + ox) / (float)P.W, vv = 1.0f - ((float)jy + oy) / (float)P.H;
+							done = sample_begin(P, st, vu, vv, s);
+						}
+						if (done) complete(s);
+					}
+					next += __popcll(idle);
+				}
+				const int entry = __popcll(__ballot(st.job >= 0));
+				if (entry == 0)
+				{
+					if (next >= total) break;
+					continue;
+				}
+				// walk until half of the walkers have finished (the tail of a chunk runs to the end)
+				const int leave_below = (next < total || entry > 16) ? max(entry / kSchedLeaveDiv, 1) : 1;
+				int term = 0;
+				float tnear = 0.0f;
+				for (;;)
+				{
+					if (st.job >= 0 && term == 0) term = walk_step<SKIP>(P, st, vhalf, st.phase == 2, tnear, st.phase == 2 ? svis : pvis);
+					const int walking = __popcll(__ballot(st.job >= 0 && term == 0));
+					if (walking == 0 || walking < leave_below) break;
+				}
+				if (st.job >= 0 && term != 0)
+				{
+					Sample s;
+					bool done = true;
+					if (st.phase == 1) done = sample_after_primary(P, st, term == 1, tnear, s);
+					else sample_after_shadow(P, st, term == 1, s);
+					if (done) complete(s);
+				}
 			}
-			if (st.job >= 0 && term != 0)
+			// this lane's own pixels, samples in order: the same float sums as the plain kernel
+			__builtin_amdgcn_wave_barrier();
+#pragma unroll
+			for (int i = 0; i < PPL; i++)
 			{
-				Sample s;
-				bool done = true;
-				if (st.phase == 1) done = sample_after_primary(P, st, term == 1, tnear, s);
-				else sample_after_shadow(P, st, term == 1, s);
-				if (done) complete(s);
+				const int slot = wave * PPW + i * 64 + lane;
+				for (int kk = 0; kk < nk; kk++)
+				{
+					r[i] += res[kk][0][slot]; g[i] += res[kk][1][slot]; b[i] += res[kk][2][slot]; a[i] += res[kk][3][slot];
+					if (k0 == 0 && kk == 0) d0[i] = res[kk][4][slot];
+					shadow += (u32)res[kk][5][slot];
+				}
 			}
+			__builtin_amdgcn_wave_barrier();
 		}
-		// this lane's own pixels, samples in order: the same float sums as the plain kernel
-		__builtin_amdgcn_wave_barrier();
 #pragma unroll
 		for (int i = 0; i < PPL; i++)
 		{
-			const int slot = wave * PPW + i * 64 + lane;
-			for (int kk = 0; kk < nk; kk++)
+			const int lp = i * 64 + lane;
+			const u32 px = x0 + (u32)(lp % TW), py = y0 + (u32)(lp / TW);
+			if (px >= P.W || py >= P.row1) continue;
+			const float rr = r[i] * inv, gg = g[i] * inv, bb = b[i] * inv, aa = a[i] * inv;
+			const size_t idx = (size_t)py * P.W + px;
+			if (P.light)
 			{
-				r[i] += res[kk][0][slot]; g[i] += res[kk][1][slot]; b[i] += res[kk][2][slot]; a[i] += res[kk][3][slot];
-				if (k0 == 0 && kk == 0) d0[i] = res[kk][4][slot];
-				shadow += (u32)res[kk][5][slot];
+				const __half2 rg = __floats2half2_rn(rr, gg), ba = __floats2half2_rn(bb, 1.0f);
+				uint2 v;
+				v.x = *reinterpret_cast<const u32 *>(&rg);
+				v.y = *reinterpret_cast<const u32 *>(&ba);
+				P.light[idx] = v;
+			}
+			if (P.depth)
+			{
+				const __half2 d = __floats2half2_rn(d0[i], 1.0f);
+				P.depth[idx] = *reinterpret_cast<const u32 *>(&d);
+			}
+			if (P.presentation)
+				P.presentation[idx] = unorm8(powf(rr, ig)) | (unorm8(powf(gg, ig)) << 8) | (unorm8(powf(bb, ig)) << 16) | (unorm8(aa) << 24);
+		}
+		if (P.trace)
+		{
+			u32 tv = pvis + svis - vis0;
+			for (int o = 32; o > 0; o >>= 1) tv += __shfl_xor(tv, o);
+			if (lane == 0)
+			{
+				unsigned long long *t = P.counters + 8 + 4 * (size_t)tile;
+				t[0] = trace_t0;
+				t[1] = __builtin_amdgcn_s_memrealtime();
+				t[2] = (unsigned long long)__builtin_amdgcn_s_getreg((15 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32); // HW_ID (wave slot, SIMD, CU, SH, SE), XCC_ID
+				t[3] = tv;
 			}
 		}
-		__builtin_amdgcn_wave_barrier();
 	}
-	const float inv = 1.0f / (float)P.spp;
-	const float ig = P.legacy ? 1.0f / 2.2f : 1.0f / P.u[U_GAMMA];
-#pragma unroll
-	for (int i = 0; i < PPL; i++)
-	{
-		const int lp = i * 64 + lane;
-		const u32 px = x0 + (u32)(lp % TW), py = y0 + (u32)(lp / TW);
-		if (px >= P.W || py >= P.row1) continue;
-		const float rr = r[i] * inv, gg = g[i] * inv, bb = b[i] * inv, aa = a[i] * inv;
-		const size_t idx = (size_t)py * P.W + px;
-		if (P.light)
-		{
-			const __half2 rg = __floats2half2_rn(rr, gg), ba = __floats2half2_rn(bb, 1.0f);
-			uint2 v;
-			v.x = *reinterpret_cast<const u32 *>(&rg);
-			v.y = *reinterpret_cast<const u32 *>(&ba);
-			P.light[idx] = v;
-		}
-		if (P.depth)
-		{
-			const __half2 d = __floats2half2_rn(d0[i], 1.0f);
-			P.depth[idx] = *reinterpret_cast<const u32 *>(&d);
-		}
-		if (P.presentation)
-			P.presentation[idx] = unorm8(powf(rr, ig)) | (unorm8(powf(gg, ig)) << 8) | (unorm8(powf(bb, ig)) << 16) | (unorm8(aa) << 24);
-	}
-	if (P.counters)
-	{
-		atomicAdd(&P.counters[0], (unsigned long long)shadow);
-		atomicAdd(&P.counters[1], (unsigned long long)pvis);
-		atomicAdd(&P.counters[2], (unsigned long long)svis);
-	}
+	atomicAdd(&P.counters[0], (unsigned long long)shadow);
+	atomicAdd(&P.counters[1], (unsigned long long)pvis);
+	atomicAdd(&P.counters[2], (unsigned long long)svis);
 }
 
 // ================================================================================================ occupancy
@@ -1189,6 +1222,46 @@ __global__ __launch_bounds__(256) void ca_render_frame_packed(FrameParams F)
 
 } // namespace
 
+// Screen rectangle of the volume (the cube [-0.5, 0.5]^3) in pixels, from the same camera model as sample_begin: the 8
+// corners projected, two pixels of margin, x aligned to 32 and y to 16, clipped to the band. A corner beside or behind
+// the camera: the whole band. Only a hint for WHERE the scheduled kernel runs — the plain kernel renders the rest and both
+// produce the same pixels, so a rectangle that is too small costs time, never correctness.
+static void volume_rect(RenderParams &P)
+{
+	const float *v = P.u + U_VIEW;
+	const double m[3][3] = {{v[0], v[4], v[8]}, {v[1], v[5], v[9]}, {v[2], v[6], v[10]}}; // world dir = m * camera dir
+	const double det = m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) +
+	                   m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
+	const double aspect = (double)P.u[U_WINDOW] / (double)P.u[U_WINDOW + 1];
+	double lo_x = 1e30, hi_x = -1e30, lo_y = 1e30, hi_y = -1e30;
+	bool whole = !(fabs(det) > 1e-12) || !(aspect > 0.0);
+	for (int c = 0; c < 8 && !whole; c++)
+	{
+		const double d[3] = {(c & 1 ? 0.5 : -0.5) - v[12], (c & 2 ? 0.5 : -0.5) - v[13], (c & 4 ? 0.5 : -0.5) - v[14]};
+		double q[3]; // camera-space position: m^-1 * d (Cramer)
+		for (int k = 0; k < 3; k++)
+		{
+			double t[3][3];
+			for (int i = 0; i < 3; i++)
+				for (int j = 0; j < 3; j++) t[i][j] = j == k ? d[i] : m[i][j];
+			q[k] = (t[0][0] * (t[1][1] * t[2][2] - t[1][2] * t[2][1]) - t[0][1] * (t[1][0] * t[2][2] - t[1][2] * t[2][0]) +
+			        t[0][2] * (t[1][0] * t[2][1] - t[1][1] * t[2][0])) / det;
+		}
+		if (!(q[2] < -1e-3)) { whole = true; break; } // the view ray looks down -z
+		const double vu = 0.5 - 0.5 * P.cot_half_fov * (q[0] / q[2]) / aspect, vv = 0.5 - 0.5 * P.cot_half_fov * (q[1] / q[2]);
+		const double x = vu * P.W, y = (1.0 - vv) * P.H;
+		lo_x = fmin(lo_x, x); hi_x = fmax(hi_x, x); lo_y = fmin(lo_y, y); hi_y = fmax(hi_y, y);
+	}
+	if (whole) { lo_x = 0; hi_x = P.W; lo_y = 0; hi_y = P.H; }
+	const double x0 = fmax(0.0, floor(lo_x) - 2.0), x1 = fmin((double)P.W, ceil(hi_x) + 2.0);
+	const double y0 = fmax((double)P.row0, floor(lo_y) - 2.0), y1 = fmin((double)P.row1, ceil(hi_y) + 2.0);
+	if (!(x1 > x0) || !(y1 > y0)) return; // the volume is off screen (or outside the band): nothing to schedule
+	P.rx0 = ((u32)x0 / 32u) * 32u;
+	P.rx1 = (((u32)x1 + 31u) / 32u) * 32u;
+	P.ry0 = P.row0 + (((u32)y0 - P.row0) / 16u) * 16u;
+	P.ry1 = P.row0 + (((u32)y1 - P.row0 + 15u) / 16u) * 16u;
+}
+
 hipError_t launch_render(const RenderLaunch &l, hipStream_t stream)
 {
 	RenderParams P;
@@ -1206,6 +1279,7 @@ hipError_t launch_render(const RenderLaunch &l, hipStream_t stream)
 	P.counters = l.counters;
 	P.legacy = l.legacy ? 1u : 0u;
 	P.indirect = l.indirect && !l.legacy ? 1u : 0u;
+	P.trace = l.trace ? 1u : 0u;
 	P.occ = nullptr;
 	P.occ_words = 0;
 	P.occ_coarse = 0;
@@ -1223,6 +1297,7 @@ hipError_t launch_render(const RenderLaunch &l, hipStream_t stream)
 	}
 	P.row0 = l.row0;
 	P.row1 = l.row1 ? l.row1 : l.H;
+	P.rx0 = P.rx1 = P.ry0 = P.ry1 = P.outside_only = 0;
 	const dim3 grid((l.W + 15u) / 16u, (l.mode == 1 ? l.H + 15u : P.row1 - P.row0 + 15u) / 16u);
 	if (l.mode == 1)
 	{
@@ -1232,17 +1307,35 @@ hipError_t launch_render(const RenderLaunch &l, hipStream_t stream)
 		F.prev_depth = l.prev_depth;
 		hipLaunchKernelGGL(ca_render_frame_packed, grid, dim3(256), 0, stream, F);
 	}
-	else if (l.sched && !P.indirect && l.spp == 1)
+	else if (l.sched && !P.indirect && l.counters)
 	{
-		// one sample per pixel: 256 pixels per wave (a block covers 32 x 32 pixels)
-		const dim3 g1((l.W + 31u) / 32u, (P.row1 - P.row0 + 31u) / 32u);
-		hipLaunchKernelGGL((ca_render_packed_sched<false, 256, 1>), g1, dim3(256), 0, stream, P);
-		if (P.occ) hipLaunchKernelGGL((ca_render_packed_sched<true, 256, 1>), g1, dim3(256), 0, stream, P);
-	}
-	else if (l.sched && !P.indirect) // the indirect-lighting mode runs in the plain kernel (one pixel per lane)
-	{
-		hipLaunchKernelGGL((ca_render_packed_sched<false, 64, kSchedChunk>), grid, dim3(256), 0, stream, P);
-		if (P.occ) hipLaunchKernelGGL((ca_render_packed_sched<true, 64, kSchedChunk>), grid, dim3(256), 0, stream, P);
+		// the scheduled kernel on the volume's screen rectangle (persistent: as many workgroups as the chip holds at 4 waves
+		// per SIMD, fewer when the rectangle has fewer wave tiles), the plain kernel on the tiles around it
+		volume_rect(P);
+		const bool one = l.spp == 1; // one sample per pixel: 256 pixels per wave tile (32 x 8), else 64 (16 x 4)
+		const u32 tiles = ((P.rx1 - P.rx0) / (one ? 32u : 16u)) * ((P.ry1 - P.ry0) / (one ? 8u : 4u));
+		if (tiles)
+		{
+			int dev = 0, cus = 256;
+			if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+			const u32 wgs = min((tiles + 3u) / 4u, (u32)cus * (u32)kSchedWaves);
+			if (one)
+			{
+				hipLaunchKernelGGL((ca_render_packed_sched<false, 256, 1, kSchedWaves>), dim3(wgs), dim3(256), 0, stream, P);
+				if (P.occ) hipLaunchKernelGGL((ca_render_packed_sched<true, 256, 1, kSchedWaves>), dim3(wgs), dim3(256), 0, stream, P);
+			}
+			else
+			{
+				hipLaunchKernelGGL((ca_render_packed_sched<false, 64, kSchedChunk, kSchedWaves>), dim3(wgs), dim3(256), 0, stream, P);
+				if (P.occ) hipLaunchKernelGGL((ca_render_packed_sched<true, 64, kSchedChunk, kSchedWaves>), dim3(wgs), dim3(256), 0, stream, P);
+			}
+		}
+		if (tiles == 0 || P.rx0 > 0 || P.rx1 < l.W || P.ry0 > P.row0 || P.ry1 < P.row1)
+		{
+			P.outside_only = tiles ? 1u : 0u;
+			hipLaunchKernelGGL(ca_render_packed<false>, grid, dim3(256), 0, stream, P);
+			if (P.occ) hipLaunchKernelGGL(ca_render_packed<true>, grid, dim3(256), 0, stream, P);
+		}
 	}
 	else
 	{

@@ -3,7 +3,7 @@
 // calling hand-written HIP kernels through a thin C-ABI shared library via N-API"): N CA steps of the 512^3 packed
 // grid, default rule, and 1080p / 4 spp frames, driven through ca3d.js -> ca3d_napi.node -> libca3d.so. Prints one
 // JSON line; bench.py (the driver's contract) measures the same kernels from Python.
-//   node cellularautomatons3d_amd/js/bench.js [--grid 512] [--steps 2048] [--warmup 256] [--frames 10 --uniforms u.f32]
+//   node cellularautomatons3d_amd/js/bench.js [--grid 512] [--steps 2048] [--reps 10] [--warmup 256] [--frames 10 --uniforms u.f32]
 // The renderer leg needs the 128-float uniform block the UI's MemoryManager would supply (camera maths stays in
 // front of the engine): python -c "from cellularautomatons3d_amd import host; host.uniform_block(1920, 1080,
 // host.orbit_camera()).tofile('u.f32')"
@@ -21,20 +21,28 @@ const eng = new c.Engine(0);
 eng.configure(G);
 eng.setRuleStrings({});
 eng.uploadState(c.randomFill((G / 32) * G * G, 0xCA3D0001, 0));
+const reps = arg("reps", 10);
 eng.setOption("graph_prepare", Math.max(steps, warmup));
+// the calls of a frame are encoded and submitted together, as the reference does with its command encoder and one
+// queue.submit (main_pathtraced.js:1833-1850): `reps` calls of `steps` steps, submissions of `steps` steps
+eng.setOption("queue", steps);
 eng.step(warmup);
-eng.synchronize();
-const t0 = process.hrtime.bigint();
 eng.step(steps);
 eng.synchronize();
+const l0 = eng.info().launchesTotal;
+const t0 = process.hrtime.bigint();
+for (let i = 0; i < reps; i++) eng.step(steps);
+eng.flush();
+eng.synchronize();
 const dt = Number(process.hrtime.bigint() - t0) / 1e9;
-const st = eng.stats();
-const launchUs = st.gpuMs * 1e3 / st.kernelLaunches; // the resident kernel runs the whole batch in one launch
-const stepUs = st.gpuMs * 1e3 / steps;
+const launches = eng.info().launchesTotal - l0, total = steps * reps;
+const st = eng.stats(); // the last submission
+const launchUs = st.gpuMs * 1e3 / st.kernelLaunches; // the resident kernel runs a whole submission in one launch
+const stepUs = dt * 1e6 / total;
 const out = {
-	metric: `Gcells/s CA step at ${G}^3 (Node.js host)`, value: +(G ** 3 * steps / dt / 1e9).toFixed(3), unit: "Gcells/s", steps, warmup,
-	ms_per_step: +(dt * 1e3 / steps).toFixed(6), kernel: eng.info().kernelName, launch_us: +launchUs.toFixed(3),
-	steps_per_launch: Math.round(steps / st.kernelLaunches), roofline_frac: +((0.25 * G ** 3) / (stepUs * 1e-6) / 8e12).toFixed(4), node: process.version
+	metric: `Gcells/s CA step at ${G}^3 (Node.js host)`, value: +(G ** 3 * total / dt / 1e9).toFixed(3), unit: "Gcells/s", steps, reps, warmup,
+	ms_per_step: +(dt * 1e3 / total).toFixed(6), kernel: eng.info().kernelName, launch_us: +launchUs.toFixed(3),
+	steps_per_launch: Math.round(total / launches), roofline_frac: +((0.25 * G ** 3) / (stepUs * 1e-6) / 8e12).toFixed(4), node: process.version
 };
 if (frames > 0 && uniformsPath)
 {

@@ -32,6 +32,25 @@ assert.deepStrictEqual(Buffer.from(eng.readState().buffer), Buffer.from(a.buffer
 assert.ok(/class/.test(eng.info().kernelName));
 assert.ok(eng.stats().gpuMs > 0);
 
+// queued submission: step() encodes, flush() / any state-reading call submits; the same states as call-by-call
+{
+	const before = eng.readState();
+	eng.setOption("queue", 16);
+	const l0 = eng.info().launchesTotal;
+	for (let i = 0; i < 5; i++) eng.step(2);
+	eng.flush();
+	assert.strictEqual(eng.info().step, 13);
+	const queued = eng.readState();
+	eng.setOption("queue", 0);
+	eng.uploadState(before);
+	for (let i = 0; i < 5; i++) eng.step(2);
+	assert.deepStrictEqual(Buffer.from(eng.readState().buffer), Buffer.from(queued.buffer));
+	assert.ok(eng.info().launchesTotal > l0);
+	// back to the state the render check below expects (3 steps from `st`)
+	eng.uploadState(st);
+	eng.step(3);
+}
+
 // render the current state with a uniform block supplied by the caller (written by the Python test)
 const ub = fs.readFileSync(path.join(outDir, "uniforms.f32")); // small reads come from a pooled ArrayBuffer: honour byteOffset
 const u = new Float32Array(ub.buffer.slice(ub.byteOffset, ub.byteOffset + 512));

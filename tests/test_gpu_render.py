@@ -102,6 +102,36 @@ def test_camera_inside_volume(eng):
     _compare(eng, cells, G, host.uniform_block(W, H, host.camera_matrix((0.1, -0.05, 0.2), (0.0, 1.0, 0.0), 0.4)), W, H, 1, min_ok=0.995)
 
 
+@pytest.mark.parametrize("position,axis,angle", [((0.9, 0.0, 0.9), (0.0, 1.0, 0.0), 0.35),   # the volume crosses the left edge of the frame
+                                                 ((0.0, 0.0, 0.75), (0.0, 1.0, 0.0), 3.0),    # looking away: the volume is off screen
+                                                 ((0.0, 0.3, 4.0), (1.0, 0.0, 0.0), -0.05),   # far away: a rectangle of a few tiles
+                                                 ((0.2, 0.6, 0.4), (1.0, 0.0, 0.0), -0.9)])   # close above a face: corners beside the camera
+def test_volume_rectangle_cases(eng, position, axis, angle):
+    """The scheduled kernel runs on the volume's screen rectangle and the plain kernel on the tiles around it
+    (render.hip: volume_rect): partly or wholly off screen, tiny, and with corners that do not project, the frame
+    stays the plain kernel's bit for bit (checked inside _compare) and the oracle's within the tolerance."""
+    G, W, H = 64, 320, 180
+    cells = host.random_fill(host.words_per_buffer(G), seed=21, and_rounds=3)
+    u = host.uniform_block(W, H, host.camera_matrix(position, axis, angle))
+    eng.configure(G)
+    set_rules(eng, rules("default"))
+    eng.upload_state(cells)
+    for spp in (1, 4):
+        eng.set_option("render_sched", 0)
+        pres0, light0, depth0 = eng.render(u, W, H, spp)
+        st0 = eng.render_stats()
+        eng.set_option("render_sched", 1)
+        pres, light, depth = eng.render(u, W, H, spp)
+        st1 = eng.render_stats()
+        np.testing.assert_array_equal(pres, pres0)
+        np.testing.assert_array_equal(light.view(np.uint16), light0.view(np.uint16))
+        np.testing.assert_array_equal(depth.view(np.uint16), depth0.view(np.uint16))
+        assert (st0.shadow_rays, st0.primary_cell_visits, st0.shadow_cell_visits) == (st1.shadow_rays, st1.primary_cell_visits, st1.shadow_cell_visits)
+    olight, odepth, opres, _ = ol.render(cells, G, u, W, H, 4)
+    ok = np.abs(light.astype(np.float32)[..., :3] - olight[..., :3]).max(-1) <= 2e-3
+    assert ok.mean() >= 0.995, ok.mean()
+
+
 def test_material_colour_depth_overlay_and_gamma(eng):
     G, W, H = 64, 160, 90
     cells = host.random_fill(host.words_per_buffer(G), seed=6, and_rounds=4)

@@ -328,7 +328,7 @@ void refresh_kernels(ca3d_engine *h)
 		h->vn_jit = j;
 		h->kernel_name = "ca_packed_vn(jit)";
 	}
-	if (resident && jit_resident_kernel(h->device, ls, lb, h->res_rows, &h->res_jit_fn, &h->jit_log) == CA3D_OK) h->res_ready = true;
+	if (resident && jit_resident_kernel(h->device, ls, lb, h->G == 256u ? 256u : h->res_rows, &h->res_jit_fn, &h->jit_log) == CA3D_OK) h->res_ready = true;
 }
 
 // A failed specialisation is not an error of the call that triggered it (the ahead-of-time kernels take over), but it

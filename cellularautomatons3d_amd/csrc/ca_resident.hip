@@ -78,7 +78,7 @@ void resident_stream_retired(hipStream_t stream)
 
 // The rule is a pair of truth tables over the von Neumann count (as ca_packed_vn) and the grid is the one the tile
 // geometry is built for.
-bool resident_kernel_applies(const CanonRules &r, uint32_t G, int variant) { return G == 512u && vn_kernel_applies(r, G, variant); }
+bool resident_kernel_applies(const CanonRules &r, uint32_t G, int variant) { return (G == 512u || G == 256u) && vn_kernel_applies(r, G, variant); }
 
 bool resident_class_applies(const CanonRules &r, uint32_t G, int variant)
 {
@@ -87,6 +87,7 @@ bool resident_class_applies(const CanonRules &r, uint32_t G, int variant)
 
 size_t resident_mail_bytes(uint32_t G, uint32_t rows)
 {
+	if (G == 256u) return 2u * (size_t)256u * 4u * 256u * sizeof(unsigned long long); // 256 tiles, faces of up to 256 words
 	const size_t tiles = (size_t)(G / rows) * (G / kResTileRows);
 	return 2u * tiles * 4u * kResFaceWords * sizeof(unsigned long long);
 }
@@ -130,7 +131,21 @@ hipError_t launch_resident(const ResidentLaunch &l, hipStream_t stream)
 	a.steps = l.steps;
 	a.epoch0 = l.epoch0;
 	a.timeout_ticks = l.timeout_ticks;
-	if (l.rows != 16u && l.rows != 32u) return hipErrorInvalidValue;
+	if (l.G == 256u)
+	{
+		// 8 x 32 tiles of 32 rows x 8 planes, 256 threads each (ca_resident_kernel.inc: CW = 8, PZ = 8)
+		if (l.jit_fn)
+		{
+			void *args[] = {(void *)&a};
+			return chained_launch(stream, [&]() { return hipModuleLaunchKernel((hipFunction_t)l.jit_fn, 256, 1, 1, 256, 1, 1, 0, stream, args, nullptr); });
+		}
+		if (l.lut_s != (u32)kDefaultS || l.lut_b != (u32)kDefaultB) return hipErrorInvalidValue;
+		return chained_launch(stream, [&]() {
+			hipLaunchKernelGGL((ca_resident_vn256<kDefaultS, kDefaultB>), dim3(256), dim3(256), 0, stream, a);
+			return hipGetLastError();
+		});
+	}
+	if (l.G != 512u || (l.rows != 16u && l.rows != 32u)) return hipErrorInvalidValue;
 	const u32 tiles = (l.G / l.rows) * (l.G / kResTileRows), threads = 16u * l.rows;
 	if (l.jit_fn)
 	{

@@ -619,6 +619,49 @@ def test_checkpoint_resume(eng, tmp_path):
     np.testing.assert_array_equal(eng.read_state(), want)
 
 
+@pytest.mark.parametrize("tables", ["default", "vn_b24_s135"])
+def test_resident_kernel_at_256(eng, tables):
+    """BASELINE configs[1] (256^3, 1000 steps) through the resident kernel's 256^3 form: 256 tiles of 8 words x 32 rows x 8
+    planes (rows of 8 words: two grid rows per DPP row), y faces smaller than a tile's thread count. Batches of several
+    lengths, a sparse state, the other ping-pong buffer, and 1000 steps in one launch against the oracle."""
+    G = 256
+    r = rules(tables)
+    eng.configure(G)
+    set_rules(eng, r)
+    assert eng.info().kernel_name.startswith(b"ca_resident_vn")
+    st = host.random_fill(host.words_per_buffer(G), seed=256)
+    eng.upload_state(st)
+    want = st
+    total = 0
+    from cellularautomatons3d_amd import slab
+    for n in (8, 9, 21):
+        eng.step(n)
+        prev = ol.packed_run(G, want, r, n - 1)
+        want = ol.packed_step(G, prev, r)
+        total += n
+        np.testing.assert_array_equal(eng.read_state(), want, err_msg=f"after a batch of {n}")
+        assert eng.info().current_buffer == total % 2 and eng.info().step == total
+        other = slab.device_tensor(*eng.device_buffer(1 - total % 2), 0).cpu().numpy().view(np.uint32)
+        np.testing.assert_array_equal(other, prev, err_msg="the other buffer holds the state one step earlier")
+    st2 = host.initial_state(G)
+    eng.upload_state(st2)
+    eng.step(100)
+    np.testing.assert_array_equal(eng.read_state(), ol.packed_run(G, st2, r, 100))
+    eng.upload_state(st)
+    eng.step(1000)
+    assert eng.info().kernel_name.startswith(b"ca_resident_vn")
+    got = eng.read_state()
+    np.testing.assert_array_equal(got, ol.packed_run(G, st, r, 1000))
+    eng.set_option("resident", 0)
+    try:
+        assert eng.info().kernel_name.startswith(b"ca_packed_vn")
+        eng.upload_state(st)
+        eng.step(1000)
+        np.testing.assert_array_equal(eng.read_state(), got)
+    finally:
+        eng.set_option("resident", 1)
+
+
 def test_queued_submission(eng):
     """Option "queue": ca3d_step only encodes, the steps of consecutive calls are submitted together (ca3d_flush, any call
     that looks at the state, or once `queue` steps wait) — the reference's commandEncoder + queue.submit

@@ -9,7 +9,8 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 int main(int argc, char **argv)
 {
-	const u32 steps = argc > 1 ? atoi(argv[1]) : 4, G = 512;
+	const int rows = argc > 3 ? atoi(argv[3]) : 32; // 32 / 16: rows per tile at 512^3; 256: the 256^3 form
+	const u32 steps = argc > 1 ? atoi(argv[1]) : 4, G = rows == 256 ? 256 : 512;
 	const size_t words = (size_t)G / 32 * G * G;
 	std::vector<u32> h(words);
 	u32 x = 12345;
@@ -24,7 +25,6 @@ int main(int argc, char **argv)
 	CK(hipHostMalloc((void **)&hflag, 16, hipHostMallocDefault));
 	*hflag = 0;
 	const int launches = argc > 2 ? atoi(argv[2]) : 3;
-	const int rows = argc > 3 ? atoi(argv[3]) : 32;
 	hipEvent_t e0, e1;
 	CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
 	u32 epoch = 0, cur = 0;
@@ -33,7 +33,8 @@ int main(int argc, char **argv)
 	{
 		ResidentArgs a{buf[cur], buf[(cur + steps) & 1], buf[(cur + steps + 1) & 1], mail, status, hflag, steps, epoch, 5000000u};
 		CK(hipEventRecord(e0));
-		if (rows == 16) hipLaunchKernelGGL((ca_resident_vn<0xFF, 0x0A, 16>), dim3(512), dim3(256), 0, 0, a);
+		if (rows == 256) hipLaunchKernelGGL((ca_resident_vn256<0xFF, 0x0A>), dim3(256), dim3(256), 0, 0, a);
+		else if (rows == 16) hipLaunchKernelGGL((ca_resident_vn<0xFF, 0x0A, 16>), dim3(512), dim3(256), 0, 0, a);
 		else hipLaunchKernelGGL((ca_resident_vn<0xFF, 0x0A, 32>), dim3(256), dim3(512), 0, 0, a);
 		CK(hipGetLastError());
 		CK(hipEventRecord(e1));
@@ -50,7 +51,7 @@ int main(int argc, char **argv)
 			std::vector<u32> tt(700);
 			CK(hipMemcpy(tt.data(), status, 616 * 4, hipMemcpyDeviceToHost));
 			static const char *nm[7] = {"poll", "halo+barrier", "face pass", "ym/yp reads", "z faces+prefetch", "main pass", "to_image"};
-			for (int w = 0; w < 2; w++) { printf("  wave %d cycles/step:", w * 4); u32 tot = 0; for (int i = 0; i < 7; i++) { printf(" %s %u", nm[i], tt[600 + w * 8 + i]); tot += tt[600 + w * 8 + i]; } printf("  total %u\n", tot); }
+			for (int w = 0; w < 2; w++) { printf("  wave %d cycles/step:", w * (rows == 32 ? 4 : 2)); u32 tot = 0; for (int i = 0; i < 7; i++) { printf(" %s %u", nm[i], tt[600 + w * 8 + i]); tot += tt[600 + w * 8 + i]; } printf("  total %u\n", tot); }
 		}
 #endif
 		if (st[0])

@@ -272,7 +272,7 @@ def copy_ceiling_gbs():
     return 2.0 * n * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
-def pmc_traffic(kernel, G):
+def pmc_traffic(kernel, G, steps_per_launch=1):
     """Fabric bytes per launch (FETCH_SIZE + WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes) from the committed
     rocprofv3 PMC passes of this command (profiles/pmc_traffic.json; tools/profile_round.sh collects them), or None:
     counters cannot be read from inside an un-profiled run."""
@@ -283,7 +283,10 @@ def pmc_traffic(kernel, G):
         d = json.load(open(p))
         for key in (f"{kernel}@{G}", f"{kernel.split('(')[0].split('<')[0]}@{G}"):
             if key in d:
-                return d[key].get("hbm_bytes_per_launch")
+                e = d[key]
+                if "steps_per_launch" in e:  # a resident kernel: the pass was taken at that many steps per launch
+                    return round(e["hbm_bytes_per_launch"] / e["steps_per_launch"] * steps_per_launch)
+                return e.get("hbm_bytes_per_launch")
     except Exception:
         pass
     return None
@@ -386,7 +389,7 @@ def roofline_block(kernel, G, bytes_per_step, total_steps, ev_ms, state_bytes, l
         steps_per_launch = int(steps_per_launch)
     launch_ms = ev_ms / max(1, launches)
     achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
-    traffic = pmc_traffic(kernel, G)
+    traffic = pmc_traffic(kernel, G, steps_per_launch)
     fits = 2 * state_bytes < INFINITY_CACHE_BYTES
     return {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

@@ -11,10 +11,13 @@ DRV="bench.py --steps 20 --warmup 5"          # the driver's own command
 python $DRV > "$out/${tag}_bench512_driver_cmd.json"
 python bench.py > "$out/${tag}_bench512_default.json"
 python bench.py $Q --resident 0 --steps 512 --warmup 64 > "$out/${tag}_bench512_perstep.json"
+python $DRV $Q --compare-submission > "$out/${tag}_bench512_driver_cmd_both_submissions.json"
 python tools/run_resident.py > "$out/${tag}_resident_batches.txt" 2>/dev/null
 python tools/run_resident_class.py > "$out/${tag}_resident_class_batches.txt" 2>/dev/null
 tools/ubench/resident_probe_stamps 10000 2 32 > "$out/${tag}_resident_phases.txt" 2>/dev/null || true
 tools/ubench/resident_probe_nowait 10000 2 32 >> "$out/${tag}_resident_phases.txt" 2>/dev/null || true
+tools/ubench/resident_probe_stamps 10000 2 256 > "$out/${tag}_resident256_phases.txt" 2>/dev/null || true
+tools/ubench/resident_probe_nowait 10000 2 256 >> "$out/${tag}_resident256_phases.txt" 2>/dev/null || true
 stats() { rocprofv3 --output-format csv --kernel-trace --stats -d "$out/${tag}_stats_$1" -o s -- python ${@:2} > "$out/${tag}_bench_$1_under_rocprof.json"; }
 stats 512_driver_cmd $DRV $Q
 stats 512_perstep bench.py $Q --resident 0 --steps 512 --warmup 64
@@ -50,4 +53,7 @@ for n in 0 1; do python tools/run_slab_rccl.py --ghost 32 --batches 40 --native 
 for k in 16 32; do python tools/run_slab_rccl.py --ghost $k --batches 40 --native 1 --resident 1 2>/dev/null | grep "^slab"; done >> "$out/${tag}_slab_rccl_loopback.txt"
 python tools/run_slab_rccl.py --grid 2048 --planes 256 --ghost 16 --batches 15 --native 1 --rule clustered 2>/dev/null | grep "^slab" >> "$out/${tag}_slab_rccl_loopback.txt"
 find "$out" -name "*kernel_trace.csv" -delete; find "$out" -name "*counter_collection.csv" -delete; find "$out" -name "*agent_info.csv" -delete
+bash tools/pmc_render.sh ${tag}_render > "$out/${tag}_pmc_render.json" 2>/dev/null
+CA3D_RENDER_TRACE=/tmp/rt.bin python tools/run_render.py --frames 3 > /dev/null 2>&1 && python tools/render_trace.py /tmp/rt.bin > "$out/${tag}_render_trace.txt"
+rm -rf "$out"/${tag}_render_pmc_*
 echo done

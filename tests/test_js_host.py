@@ -84,4 +84,4 @@ def test_node_bench_reports_the_headline_metric(tmp_path):
               "--uniforms", str(tmp_path / "u.f32"))
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     d = json.loads(r.stdout.strip().splitlines()[-1])
-    assert d["kernel"].startswith("ca_packed_vn") and d["value"] > 100 and d["render"]["value"] > 10
+    assert d["kernel"].startswith("ca_resident_vn") and d["steps_per_launch"] == 256 and d["value"] > 100 and d["render"]["value"] > 10

@@ -701,3 +701,30 @@ def test_queued_submission(eng):
         np.testing.assert_array_equal(eng.read_state(), ol.packed_run(G, st, r2, 3))
     finally:
         eng.set_option("queue", 0)
+
+
+@pytest.mark.gpu
+def test_bench_line_single_gpu_queued_and_per_call():
+    """bench.py at N = 1 as the driver runs it (a small grid): one JSON line and nothing else on stdout, the state checked
+    against the oracle after warm-up + calibration + timed steps, the K-step calls submitted together (`ca3d_flush`) with the
+    per-call figure beside it, `roofline` per launch of the resident kernel."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--grid", "256", "--steps", "20", "--warmup", "5", "--queue", "256",
+           "--min-seconds", "0.0001", "--no-cpu-baseline", "--no-render", "--no-scaling-base", "--check", "--compare-submission"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["oracle_match"] is True and d["n_gpus"] == 1 and d["steps"] == 20 and d["unit"] == "Gcells/s"
+    rf = d["roofline"]
+    assert rf["kernel"].startswith("ca_resident_vn") and rf["steps_per_launch"] == 260 and rf["bound"] == "hbm"
+    assert abs(rf["achieved"] / rf["peak"] - rf["frac"]) < 1e-3
+    assert d["config"]["submission"].startswith("queued") and d["reps"] % 13 == 0
+    other = d["other_submission"]
+    assert other["submission"] == "per call" and other["roofline"]["steps_per_launch"] == 20 and other["value"] > 0

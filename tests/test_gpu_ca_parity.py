@@ -703,7 +703,6 @@ def test_queued_submission(eng):
         eng.set_option("queue", 0)
 
 
-@pytest.mark.gpu
 def test_bench_line_single_gpu_queued_and_per_call():
     """bench.py at N = 1 as the driver runs it (a small grid): one JSON line and nothing else on stdout, the state checked
     against the oracle after warm-up + calibration + timed steps, the K-step calls submitted together (`ca3d_flush`) with the

@@ -68,6 +68,7 @@ def parse(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-render", action="store_true", help="skip the renderer legs (N=1)")
     ap.add_argument("--no-scaling-base", action="store_true", help="N=1, config 3: skip the 1024^3 single-GPU leg")
+    ap.add_argument("--no-per-step-leg", action="store_true", help="N=1: skip the per-step-kernel leg printed beside a resident-kernel headline")
     ap.add_argument("--multi-render", action="store_true",
                     help="N>1: also time the frame shared between the ranks (volume all-gather + bands of image rows); "
                          "off by default (on for --config 5) so that the scaling run times the CA step alone")
@@ -531,6 +532,17 @@ def main():
             out["other_submission"] = {"submission": "queued" if q2 else "per call", "value": round(cells * a.steps * reps2 / dt2 / 1e9, 3), "unit": "Gcells/s",
                                        "ms_per_step": round(dt2 * 1e3 / (a.steps * reps2), 6), "reps": reps2,
                                        "roofline": roofline_block(kernel, G, 0.25 * cells, a.steps * reps2, ev2, state_bytes, l2)}
+        if world == 1 and kernel.startswith("ca_resident") and not a.no_per_step_leg:
+            # the same grid through the per-step kernels (every step reads and writes the state): the fraction of the HBM roofline
+            # in the usual sense, next to the resident kernel's on-chip rate
+            eng.set_option("queue", 0)
+            eng.set_option("resident", 0)
+            eng.set_option("graph_prepare", 256)
+            dt3, reps3, ev3, _, _ = timed_region(eng.step, eng.bench_stream, 256, 64, a.min_seconds, barrier, 1, "nccl")
+            k3 = eng.info().kernel_name.decode()
+            out["per_step_kernels"] = {"value": round(cells * 256 * reps3 / dt3 / 1e9, 3), "unit": "Gcells/s", "ms_per_step": round(dt3 * 1e3 / (256 * reps3), 6),
+                                       "steps": 256, "reps": reps3, "roofline": roofline_block(k3, G, 0.25 * cells, 256 * reps3, ev3, state_bytes)}
+            eng.set_option("resident", a.resident)
         if world == 1 and not a.no_render:
             out["render"] = render_leg(eng, G, a)
             if a.config == 3 and a.render_size == "1920x1080":

@@ -6,7 +6,7 @@ tag=${1:-r2_x}
 out=$PWD/gpurun_out
 mkdir -p "$out"
 export TMPDIR=/tmp
-Q="--no-cpu-baseline --no-render --no-scaling-base"
+Q="--no-cpu-baseline --no-render --no-scaling-base --no-per-step-leg"
 DRV="bench.py --steps 20 --warmup 5"          # the driver's own command
 python $DRV > "$out/${tag}_bench512_driver_cmd.json"
 python bench.py > "$out/${tag}_bench512_default.json"

@@ -61,7 +61,7 @@ struct RenderParams
 	// scheduled kernel takes the wave tiles inside it from a queue (counters[3]); the plain kernel, launched with
 	// outside_only, renders the 16 x 16 tiles outside it (view rays that miss the volume: no walk to schedule).
 	u32 rx0, rx1, ry0, ry1, outside_only;
-	// Box around the occupied coarse blocks, in cells (ca_occupancy_coarse): [0] x1, [1] ~x0, [2] y1, [3] ~y0, [4] z1, [5] ~z0, each the
+	// Box around the occupied blocks (32 x 8 x 8 cells each), in cells (ca_occupancy): [0] x1, [1] ~x0, [2] y1, [3] ~y0, [4] z1, [5] ~z0, each the
 	// maximum over the occupied blocks (zero-initialised: an empty volume gives x0 > x1), or null. A view ray that misses it cannot
 	// meet a live cell: the sparse-volume kernels answer "no hit" without walking.
 	const u32 *live_box;
@@ -481,7 +481,7 @@ __device__ __forceinline__ u32 unorm8(float x) { return (u32)__float2int_rn(fmin
 // match the frame's occupancy (occ_skip_enabled) returns at once: the choice is made on the device, without a host
 // round trip, and the variant that runs carries none of the other's code in its loops.
 template <bool SKIP>
-__global__ __launch_bounds__(256) void ca_render_packed(RenderParams P)
+__global__ __launch_bounds__(256, 4) void ca_render_packed(RenderParams P)
 {
 	if ((!P.legacy && occ_skip_enabled(P)) != SKIP) return;
 	const bool whole_frame = SKIP && live_box_small(P); // the scheduled kernel has left the frame to this one
@@ -955,17 +955,25 @@ __global__ __launch_bounds__(256, WPE) void ca_render_packed_sched(RenderParams 
 // occ: one bit per block of 32 x 8 x 8 cells (index wx + cols * (by + G/8 * bz)), set when any cell of the block is
 // alive; the 64-bit word after the bits accumulates their count. Rebuilt from the current state before every frame
 // (one read of the volume: ~5 us at 512^3).
+// live_box (nullable): the corner cells of the occupied blocks, reduced to six maxima (RenderParams::live_box) — per wave by
+// shuffles, per workgroup in LDS, then at most six atomics per workgroup.
 __global__ __launch_bounds__(256) void ca_occupancy(const u32 *__restrict__ cells, unsigned long long *__restrict__ occ, u32 G, u32 cols,
-                                                     u32 nblocks, u32 occ_words)
+                                                     u32 nblocks, u32 occ_words, u32 *__restrict__ live_box)
 {
+	__shared__ u32 wg_box[6];
+	if (threadIdx.x < 6u) wg_box[threadIdx.x] = 0u;
 	const u32 bk = blockIdx.x * 256u + threadIdx.x; // consecutive lanes = consecutive wx
 	u32 any = 0;
+	u32 box[6] = {0, 0, 0, 0, 0, 0};
 	if (bk < nblocks)
 	{
 		const u32 nb = G >> 3;
 		const u32 wx = bk % cols, byz = bk / cols, by = byz % nb, bz = byz / nb;
 		for (u32 dz = 0; dz < 8; dz++)
 			for (u32 dy = 0; dy < 8; dy++) any |= cells[wx + ((size_t)(by * 8 + dy) + (size_t)(bz * 8 + dz) * G) * cols];
+		box[0] = (wx + 1u) * 32u; box[1] = ~(wx * 32u);
+		box[2] = (by + 1u) * 8u; box[3] = ~(by * 8u);
+		box[4] = (bz + 1u) * 8u; box[5] = ~(bz * 8u);
 	}
 	const unsigned long long m = __ballot(any != 0);
 	if ((threadIdx.x & 63u) == 0 && (bk >> 6) < occ_words)
@@ -973,21 +981,31 @@ __global__ __launch_bounds__(256) void ca_occupancy(const u32 *__restrict__ cell
 		occ[bk >> 6] = m;
 		if (m) atomicAdd(&occ[occ_words], (unsigned long long)__popcll(m));
 	}
+	if (!live_box) return;
+	__syncthreads();
+	if (m)
+	{
+#pragma unroll
+		for (int i = 0; i < 6; i++)
+		{
+			u32 v = any ? box[i] : 0u;
+			for (int o = 32; o > 0; o >>= 1) v = max(v, (u32)__shfl_xor((int)v, o));
+			if ((threadIdx.x & 63u) == 0) atomicMax(&wg_box[i], v);
+		}
+	}
+	__syncthreads();
+	if (threadIdx.x < 6u && wg_box[threadIdx.x]) atomicMax(&live_box[threadIdx.x], wg_box[threadIdx.x]);
 }
 
 // Second level from the first: one bit per 4 x 4 x 4 fine blocks (128 x 32 x 32 cells), stored after the count word.
-__global__ __launch_bounds__(256) void ca_occupancy_coarse(unsigned long long *__restrict__ occ, u32 G, u32 cols, u32 ncoarse, u32 occ_words, u32 *__restrict__ live_box)
+__global__ __launch_bounds__(256) void ca_occupancy_coarse(unsigned long long *__restrict__ occ, u32 G, u32 cols, u32 ncoarse, u32 occ_words)
 {
 	const u32 ck = blockIdx.x * 256u + threadIdx.x; // cwx + (cols / 4) * (cby + (G / 32) * cbz)
 	u32 any = 0;
-	u32 box[6] = {0, 0, 0, 0, 0, 0}; // this block's corner cells in the live_box encoding (RenderParams), if it is occupied
 	if (ck < ncoarse)
 	{
 		const u32 ccols = cols >> 2, nb = G >> 3, cnb = G >> 5;
 		const u32 cwx = ck % ccols, cbyz = ck / ccols, cby = cbyz % cnb, cbz = cbyz / cnb;
-		box[0] = (cwx + 1u) * 128u; box[1] = ~(cwx * 128u);
-		box[2] = (cby + 1u) * 32u; box[3] = ~(cby * 32u);
-		box[4] = (cbz + 1u) * 32u; box[5] = ~(cbz * 32u);
 		for (u32 dz = 0; dz < 4; dz++)
 			for (u32 dy = 0; dy < 4; dy++)
 			{
@@ -997,16 +1015,6 @@ __global__ __launch_bounds__(256) void ca_occupancy_coarse(unsigned long long *_
 	}
 	const unsigned long long m = __ballot(any != 0);
 	if ((threadIdx.x & 63u) == 0 && ck < ((ncoarse + 63u) & ~63u)) occ[occ_words + 1u + (ck >> 6)] = m;
-	if (live_box && m)
-	{
-#pragma unroll
-		for (int i = 0; i < 6; i++)
-		{
-			u32 v = any ? box[i] : 0u;
-			for (int o = 32; o > 0; o >>= 1) v = max(v, (u32)__shfl_xor((int)v, o));
-			if ((threadIdx.x & 63u) == 0) atomicMax(&live_box[i], v);
-		}
-	}
 }
 
 // ================================================================================================ literal frame
@@ -1341,13 +1349,11 @@ hipError_t launch_render(const RenderLaunch &l, hipStream_t stream)
 		P.occ_coarse = l.G % 128u == 0 ? 1u : 0u;
 		hipError_t e = hipMemsetAsync(l.occ + P.occ_words, 0, sizeof(unsigned long long), stream);
 		if (e != hipSuccess) return e;
-		hipLaunchKernelGGL(ca_occupancy, dim3((nblocks + 255u) / 256u), dim3(256), 0, stream, l.cells, l.occ, l.G, P.cols, nblocks, P.occ_words);
+		u32 *box = l.counters ? reinterpret_cast<u32 *>(l.counters + 4) : nullptr; // three of the counter words the per-frame memset clears
+		hipLaunchKernelGGL(ca_occupancy, dim3((nblocks + 255u) / 256u), dim3(256), 0, stream, l.cells, l.occ, l.G, P.cols, nblocks, P.occ_words, box);
+		P.live_box = box;
 		if (P.occ_coarse)
-		{
-			u32 *box = l.counters ? reinterpret_cast<u32 *>(l.counters + 4) : nullptr; // three of the counter words the per-frame memset clears
-			hipLaunchKernelGGL(ca_occupancy_coarse, dim3((nblocks / 64u + 255u) / 256u), dim3(256), 0, stream, l.occ, l.G, P.cols, nblocks / 64u, P.occ_words, box);
-			P.live_box = box;
-		}
+			hipLaunchKernelGGL(ca_occupancy_coarse, dim3((nblocks / 64u + 255u) / 256u), dim3(256), 0, stream, l.occ, l.G, P.cols, nblocks / 64u, P.occ_words);
 		P.occ = l.occ;
 	}
 	P.row0 = l.row0;

@@ -65,6 +65,7 @@ struct RenderParams
 	// maximum over the occupied blocks (zero-initialised: an empty volume gives x0 > x1), or null. A view ray that misses it cannot
 	// meet a live cell: the sparse-volume kernels answer "no hit" without walking.
 	const u32 *live_box;
+	u32 spread; // the launch includes ca_render_packed_spread: a small live box is its frame, not the plain kernel's
 };
 
 constexpr float kPi = 3.14159265359f;
@@ -484,7 +485,8 @@ template <bool SKIP>
 __global__ __launch_bounds__(256, 4) void ca_render_packed(RenderParams P)
 {
 	if ((!P.legacy && occ_skip_enabled(P)) != SKIP) return;
-	const bool whole_frame = SKIP && live_box_small(P); // the scheduled kernel has left the frame to this one
+	const bool whole_frame = SKIP && live_box_small(P); // the scheduled kernel has left the frame to the plain ones
+	if (whole_frame && P.spread) return;               // ... to ca_render_packed_spread
 	if (P.outside_only && !whole_frame && blockIdx.x * 16u >= P.rx0 && blockIdx.x * 16u < P.rx1 && P.row0 + blockIdx.y * 16u >= P.ry0 && P.row0 + blockIdx.y * 16u < P.ry1) return;
 	const u32 px = blockIdx.x * 16u + (threadIdx.x & 15u);
 	const u32 py = P.row0 + blockIdx.y * 16u + (threadIdx.x >> 4);
@@ -523,6 +525,70 @@ __global__ __launch_bounds__(256, 4) void ca_render_packed(RenderParams P)
 		P.presentation[i] = unorm8(powf(r, ig)) | (unorm8(powf(g, ig)) << 8) | (unorm8(powf(b, ig)) << 16) | (unorm8(a) << 24);
 	}
 	// (a word takes ~90 atomics per us: waves with nothing to add — every sky tile — must not queue up behind it)
+	if (P.counters && (shadow | pvis | svis) != 0u)
+	{
+		atomicAdd(&P.counters[0], (unsigned long long)shadow);
+		atomicAdd(&P.counters[1], (unsigned long long)pvis);
+		atomicAdd(&P.counters[2], (unsigned long long)svis);
+	}
+}
+
+// The frame of a sparse volume with a SMALL live box (live_box_small): every ray outside the box's silhouette is answered at once,
+// the rays inside it — a few thousand pixels next to each other — are all the walking there is. One lane per SAMPLE instead of
+// per pixel (8 x 8-pixel tiles at 4 samples, the samples of a pixel summed in order through LDS) and the tiles dealt round-robin
+// to a persistent launch: the same walks land on four times as many lanes spread over every CU, instead of some forty workgroups
+// of the plain kernel walking four samples one after the other.
+template <bool SKIP>
+__global__ __launch_bounds__(256, 4) void ca_render_packed_spread(RenderParams P)
+{
+	if ((!P.legacy && occ_skip_enabled(P)) != SKIP) return;
+	if (!live_box_small(P)) return;
+	__shared__ float res[6][256];
+	const u32 tid = threadIdx.x, spp = P.spp; // 1 or 4 (ca3d_render)
+	const u32 tw = spp == 1u ? 16u : 8u, th = tw; // pixels of a tile: 256 / spp
+	const u32 ntx = (P.W + tw - 1u) / tw, nty = (P.row1 - P.row0 + th - 1u) / th;
+	const u32 p = tid / spp, k = tid % spp;
+	u32 shadow = 0, pvis = 0, svis = 0;
+	const float inv = 1.0f / (float)spp;
+	const float ig = P.legacy ? 1.0f / 2.2f : 1.0f / P.u[U_GAMMA];
+	for (u32 t = blockIdx.x; t < ntx * nty; t += gridDim.x)
+	{
+		const u32 px = (t % ntx) * tw + p % tw, py = P.row0 + (t / ntx) * th + p / tw;
+		const bool live = px < P.W && py < P.row1;
+		Sample s{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0u};
+		if (live)
+		{
+			const float ox = spp == 1u ? 0.5f : ((k & 1u) ? 0.75f : 0.25f);
+			const float oy = spp == 1u ? 0.5f : ((k & 2u) ? 0.75f : 0.25f);
+			const float vu = ((float)px + ox) / (float)P.W, vv = 1.0f - ((float)py + oy) / (float)P.H;
+			s = shade_sample<SKIP>(P, vu, vv, pvis, svis);
+			shadow += s.shadow_ray;
+		}
+		res[0][tid] = s.r; res[1][tid] = s.g; res[2][tid] = s.b; res[3][tid] = s.a; res[4][tid] = s.depth;
+		__syncthreads();
+		if (live && k == 0u)
+		{
+			float r = 0.0f, g = 0.0f, b = 0.0f, a = 0.0f; // samples in order: the plain kernel's sums
+			for (u32 kk = 0; kk < spp; kk++) { r += res[0][tid + kk]; g += res[1][tid + kk]; b += res[2][tid + kk]; a += res[3][tid + kk]; }
+			r *= inv; g *= inv; b *= inv; a *= inv;
+			const size_t i = (size_t)py * P.W + px;
+			if (P.light)
+			{
+				const __half2 rg = __floats2half2_rn(r, g), ba = __floats2half2_rn(b, 1.0f);
+				uint2 v;
+				v.x = *reinterpret_cast<const u32 *>(&rg);
+				v.y = *reinterpret_cast<const u32 *>(&ba);
+				P.light[i] = v;
+			}
+			if (P.depth)
+			{
+				const __half2 d = __floats2half2_rn(res[4][tid], 1.0f);
+				P.depth[i] = *reinterpret_cast<const u32 *>(&d);
+			}
+			if (P.presentation) P.presentation[i] = unorm8(powf(r, ig)) | (unorm8(powf(g, ig)) << 8) | (unorm8(powf(b, ig)) << 16) | (unorm8(a) << 24);
+		}
+		__syncthreads();
+	}
 	if (P.counters && (shadow | pvis | svis) != 0u)
 	{
 		atomicAdd(&P.counters[0], (unsigned long long)shadow);
@@ -1340,6 +1406,7 @@ hipError_t launch_render(const RenderLaunch &l, hipStream_t stream)
 	P.trace = l.trace ? 1u : 0u;
 	P.occ = nullptr;
 	P.live_box = nullptr;
+	P.spread = 0;
 	P.occ_words = 0;
 	P.occ_coarse = 0;
 	if (!l.legacy && l.mode != 1 && l.occ)
@@ -1394,7 +1461,16 @@ hipError_t launch_render(const RenderLaunch &l, hipStream_t stream)
 		P.outside_only = tiles ? 1u : 0u;
 		const bool around = tiles == 0 || P.rx0 > 0 || P.rx1 < l.W || P.ry0 > P.row0 || P.ry1 < P.row1; // tiles outside the rectangle exist
 		if (around) hipLaunchKernelGGL(ca_render_packed<false>, grid, dim3(256), 0, stream, P);
-		if (P.occ && (around || P.live_box)) hipLaunchKernelGGL(ca_render_packed<true>, grid, dim3(256), 0, stream, P); // also the whole frame of a small live box
+		if (P.occ && P.live_box)
+		{
+			// a sparse volume with a small live box: its frame belongs to the spread kernel (a persistent launch: it costs a dense frame
+			// a thousand workgroups that return at once)
+			int dev = 0, cus = 256;
+			if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+			P.spread = 1u;
+			hipLaunchKernelGGL(ca_render_packed_spread<true>, dim3((u32)cus * 4u), dim3(256), 0, stream, P);
+		}
+		if (P.occ && around) hipLaunchKernelGGL(ca_render_packed<true>, grid, dim3(256), 0, stream, P);
 	}
 	else
 	{

@@ -96,6 +96,27 @@ def test_empty_space_skipping_on_a_sparse_volume(eng, G, W, H, spp):
         assert v_skip * 3 < v_plain, (v_skip, v_plain)
 
 
+@pytest.mark.parametrize("spp", [1, 4])
+def test_small_live_box_frame(eng, spp):
+    """A sparse volume whose live cells sit in a small box (the reference's start-up seed a few steps on): view rays that miss
+    the box of the occupied blocks are answered without a walk and the frame is rendered one lane per sample by
+    ca_render_packed_spread — bit for bit the plain kernel's frame (inside _compare), the oracle's within the tolerance, and
+    almost no cell visits."""
+    G, W, H = 256, 320, 180
+    cells = ol.packed_run(G, host.initial_state(G), rules("default"), 12)
+    for pose in (host.camera_matrix(), host.orbit_camera(1.2, (1.0, 0.3, 0.0), 0.8)):
+        _compare(eng, cells, G, host.uniform_block(W, H, pose), W, H, spp)
+        st = eng.render_stats()
+        assert st.primary_cell_visits < 2 * st.primary_rays, (st.primary_cell_visits, st.primary_rays)
+    # nothing alive at all: every ray is answered at once, only the light gizmo can show
+    eng.upload_state(np.zeros(host.words_per_buffer(G), dtype=np.uint32))
+    u = host.uniform_block(W, H, host.camera_matrix())
+    pres, light, depth = eng.render(u, W, H, spp)
+    olight, odepth, opres, _ = ol.render(np.zeros(host.words_per_buffer(G), dtype=np.uint32), G, u, W, H, spp)
+    np.testing.assert_array_equal(light.astype(np.float32), olight)
+    assert eng.render_stats().primary_cell_visits == 0
+
+
 def test_camera_inside_volume(eng):
     G, W, H = 64, 160, 90
     cells = host.random_fill(host.words_per_buffer(G), seed=5, and_rounds=5)

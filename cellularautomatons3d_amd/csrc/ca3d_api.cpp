@@ -108,13 +108,25 @@ struct ca3d_engine
 	uint64_t launches_total = 0;          // kernel launches the step calls issued since ca3d_create
 	uint32_t res_rows = 32;               // rows per tile of the von Neumann form (ca_resident_kernel.inc: 32 or 16)
 	uint32_t res_timeout_ticks = 20000000; // 200 ms of s_memrealtime per wait
+	// Recovery of a resident launch that gave up (full-grid engines). A launch of n >= 2 steps never writes the buffer it reads:
+	// the final state goes to a third buffer (`spare`), the state one step earlier to the other ping-pong buffer, and the three
+	// pointers rotate, so that buf[step % 2] / buf[(step + 1) % 2] keep the reference's meaning. Launches whose completion the
+	// host has not looked at yet are remembered; when one of them timed out (it, and every launch queued behind it, wrote
+	// nothing: ca_resident_kernel.inc res_must_skip) the engine goes back to that launch's input and runs all their steps
+	// through the per-step kernels.
+	uint32_t *spare = nullptr;
+	struct ResPending { uint32_t epoch0, n, cur_before; uint64_t step_before; uint32_t *in, *other, *spare; };
+	std::vector<ResPending> res_pending;
+	uint32_t res_fault_tile = 0;          // option "resident_fault_tile": applies to the next resident launch only
+	uint32_t res_recovered = 0;           // launches recovered from since ca3d_create
+	std::string res_note;                 // why the resident path is off although the rules / grid have a resident kernel
 
 	// halo transport inside the engine (RCCL, loaded on first use): communicator over the ranks of the slab chain, a second
 	// stream so that an exchange can run under the interior phase, the events that order the two
 	void *comm = nullptr; // ncclComm_t
 	int comm_rank = 0, comm_world = 0;
 	hipStream_t comm_stream = nullptr;
-	hipEvent_t ev_edges = nullptr, ev_comm = nullptr;
+	hipEvent_t ev_edges = nullptr, ev_comm = nullptr, ev_gather = nullptr;
 	bool ghosts_valid = false; // the ghost planes hold the neighbours' planes of the current step
 	int comm_graph = 0;        // capture batch + exchange into one graph (unsplit batches)
 	std::map<uint64_t, hipGraphExec_t> comm_graphs;
@@ -180,12 +192,16 @@ void free_resident(ca3d_engine *h)
 	h->res_epoch = 0;
 	h->res_check = false;
 	h->res_failed = false;
+	h->res_pending.clear();
+	h->res_note.clear();
 }
 
 void free_buffers(ca3d_engine *h)
 {
 	drop_graph(h);
 	free_resident(h);
+	if (h->spare) hipFree(h->spare);
+	h->spare = nullptr;
 	for (int i = 0; i < 2; i++)
 	{
 		if (h->buf[i]) hipFree(h->buf[i]);
@@ -261,7 +277,7 @@ int enqueue_step(ca3d_engine *h, int src, uint32_t lo, uint32_t hi, hipStream_t 
 // (Re)select the kernels for the current rules and grid; compiles the rule's specialisation when one applies. Called
 // whenever rules, grid or the relevant options change — never from the step path (the WebGPU analogue is pipeline
 // creation). A failed compile leaves the ahead-of-time kernels in charge.
-void refresh_kernels(ca3d_engine *h)
+void select_kernels(ca3d_engine *h)
 {
 	h->vn_jit = VnJit{};
 	h->class_jit = ClassJit{};
@@ -331,11 +347,49 @@ void refresh_kernels(ca3d_engine *h)
 	if (resident && jit_resident_kernel(h->device, ls, lb, h->G == 256u ? 256u : h->res_rows, &h->res_jit_fn, &h->jit_log) == CA3D_OK) h->res_ready = true;
 }
 
+// A resident launch only completes when ALL its workgroups are on the chip at once (they wait for each other's faces). Ask the
+// runtime before selecting one: occupancy of the chosen kernel per CU x the CUs the engine's stream may use (a CU mask, a
+// partitioned device) against the tile count. Too few: the per-step kernels run, and ca3d_last_error says why. What the
+// query cannot see (another process or stream holding CUs) is left to the kernels' bounded waits and the recovery below.
+void check_residency(ca3d_engine *h)
+{
+	h->res_note.clear();
+	if (!h->res_ready && !h->res_slab_fn) return;
+	if (hipSetDevice(h->device) != hipSuccess) return;
+	uint32_t tiles = 0, cap = 0;
+	char buf[256];
+	if (h->res_ready)
+	{
+		const uint32_t rows = (h->res_class || h->G == 256u) ? 32u : h->res_rows;
+		if (resident_capacity(h->G, rows, h->res_jit_fn, h->stream, &tiles, &cap) && cap < tiles)
+		{
+			h->res_ready = false;
+			h->res_class = false;
+			snprintf(buf, sizeof buf, "resident multi-step kernel not selected: it needs %u co-resident workgroups, this device / stream holds %u; per-step kernels in use", tiles, cap);
+			h->res_note = buf;
+		}
+	}
+	if (h->res_slab_fn && resident_slab_capacity(h->res_slab_fn, h->stream, &tiles, &cap) && cap < tiles)
+	{
+		h->res_slab_fn = nullptr;
+		snprintf(buf, sizeof buf, "resident slab kernel not selected: it needs %u co-resident workgroups, this device / stream holds %u; per-step kernels in use", tiles, cap);
+		h->res_note = buf;
+	}
+}
+
+void refresh_kernels(ca3d_engine *h)
+{
+	select_kernels(h);
+	check_residency(h);
+}
+
 // A failed specialisation is not an error of the call that triggered it (the ahead-of-time kernels take over), but it
-// must not be silent: the message goes where the caller looks (ca3d_last_error, ca3d_get_jit_log).
+// must not be silent: the message goes where the caller looks (ca3d_last_error, ca3d_get_jit_log). Likewise a resident
+// kernel that exists for the rules but cannot be co-resident on this device / stream.
 void note_jit_failure(const ca3d_engine *h)
 {
 	if (!h->jit_log.empty()) g_last_error = "run-time kernel specialisation failed, pre-built kernels in use: " + h->jit_log;
+	else if (!h->res_note.empty()) g_last_error = h->res_note;
 }
 
 int check_ready(ca3d_engine *h)
@@ -418,18 +472,74 @@ int step_graph(ca3d_engine *h, uint32_t n, uint32_t start, ca3d_engine::StepGrap
 }
 
 constexpr size_t kResStatusBytes = (4 + 1024) * sizeof(uint32_t); // abort word + per-tile progress words
+} // namespace
+static int submit_steps(ca3d_engine *h, uint32_t n_steps);
+namespace
+{
 
-// A resident launch that timed out leaves an invalid state behind: say so at the first call that waits for the GPU.
+// Looks at the resident launches issued since the last look; the stream must have been waited for. Slab engines: a launch
+// that timed out leaves an invalid state behind (the neighbours' ghosts were refreshed from it) — an error, the path goes
+// off. Full-grid engines recover (see ca3d_engine::res_pending): the failed launch and the ones behind it wrote nothing, so
+// the engine returns to the failed launch's input and runs all their steps through the per-step kernels, then waits for
+// them. Success with the resident path switched off; ca3d_last_error carries the note.
 int check_resident(ca3d_engine *h)
 {
-	if (!h->res_check || !h->res_status_host) return CA3D_OK;
+	if (!h->res_status_host) return CA3D_OK;
+	if (!h->res_check && h->res_pending.empty()) return CA3D_OK;
 	h->res_check = false;
-	if (*h->res_status_host == 0) return CA3D_OK;
-	const uint32_t who = *h->res_status_host;
+	if (*h->res_status_host == 0) { h->res_pending.clear(); return CA3D_OK; }
+	const uint32_t who = h->res_status_host[0], ep = h->res_status_host[1];
 	h->res_failed = true; // per-step kernels from here on
-	h->has_state = false;
-	return fail(CA3D_ERR_DEVICE, "resident multi-step kernel: a wait for neighbour tile faces timed out (tile %u gave up first) — were all 256 "
-	            "workgroups resident? The state is invalid: upload it again; the engine now uses the per-step kernels", who - 1u);
+	size_t idx = h->res_pending.size();
+	for (size_t i = 0; i < h->res_pending.size(); i++)
+		if (h->res_pending[i].epoch0 == ep) { idx = i; break; }
+	if (h->slab || idx == h->res_pending.size())
+	{
+		h->res_pending.clear();
+		h->has_state = false;
+		return fail(CA3D_ERR_DEVICE, "resident multi-step kernel: a wait for neighbour tile faces timed out (tile %u gave up first) — were all its "
+		            "workgroups resident? The state is invalid: upload it again; the engine now uses the per-step kernels", who - 1u);
+	}
+	const ca3d_engine::ResPending p = h->res_pending[idx];
+	uint64_t total = 0;
+	for (size_t i = idx; i < h->res_pending.size(); i++) total += h->res_pending[i].n;
+	h->res_pending.clear();
+	drop_graph(h);
+	h->buf[p.cur_before] = p.in;
+	h->buf[p.cur_before ^ 1u] = p.other;
+	h->spare = p.spare;
+	h->cur = p.cur_before;
+	h->step = p.step_before;
+	HIP_TRY(hipMemsetAsync(h->res_mail, 0, h->res_mail_bytes, h->stream));
+	HIP_TRY(hipMemsetAsync(h->res_status, 0, kResStatusBytes, h->stream));
+	h->res_status_host[0] = h->res_status_host[1] = 0;
+	h->res_epoch = 0;
+	h->res_recovered++;
+	char note[256];
+	snprintf(note, sizeof note, "resident multi-step kernel: a wait for neighbour tile faces timed out (tile %u gave up first); the %llu steps "
+	         "it and the launches behind it covered were re-run through the per-step kernels, which stay in use", who - 1u, (unsigned long long)total);
+	h->res_note = note;
+	while (total)
+	{
+		const uint32_t n = total > 0x40000000ull ? 0x40000000u : (uint32_t)total;
+		int rc = submit_steps(h, n);
+		if (rc) return rc;
+		total -= n;
+	}
+	HIP_TRY(hipStreamSynchronize(h->stream));
+	g_last_error = h->res_note;
+	return CA3D_OK;
+}
+
+// Before anything that reads the state, hands out its buffers or changes how steps run: make sure no unverified resident
+// launch is outstanding (wait for the stream, recover if one gave up). Costs nothing when none is.
+int settle_resident(ca3d_engine *h)
+{
+	if (h->res_pending.empty() && !h->res_check) return CA3D_OK;
+	int rc = bind_device(h);
+	if (rc) return rc;
+	HIP_TRY(hipStreamSynchronize(h->stream));
+	return check_resident(h);
 }
 
 // n steps as ONE launch of the resident kernel (state in registers between steps).
@@ -487,10 +597,17 @@ int resident_steps(ca3d_engine *h, uint32_t n)
 {
 	int rc0 = resident_buffers(h, n);
 	if (rc0) return rc0;
+	if (n >= 2u && !h->spare)
+	{
+		HIP_TRY(hipMalloc((void **)&h->spare, h->buffer_words() * sizeof(uint32_t)));
+	}
+	uint32_t *in = h->buf[h->cur], *other = h->buf[h->cur ^ 1u];
 	ResidentLaunch l;
-	l.in = h->buf[h->cur];
-	l.out_last = h->buf[(h->cur + n) & 1u];
-	l.out_prev = h->buf[(h->cur + n + 1u) & 1u];
+	l.in = in;
+	// n >= 2: nothing is written to the input (see ca3d_engine::spare); n == 1: the other buffer receives the new state and
+	// the input IS the state one step earlier
+	l.out_last = n >= 2u ? h->spare : other;
+	l.out_prev = n >= 2u ? other : in;
 	l.G = h->G;
 	l.mail = h->res_mail;
 	l.status = h->res_status;
@@ -498,14 +615,25 @@ int resident_steps(ca3d_engine *h, uint32_t n)
 	l.steps = n;
 	l.epoch0 = h->res_epoch;
 	l.timeout_ticks = h->res_timeout_ticks;
+	l.fault_tile = h->res_fault_tile;
+	h->res_fault_tile = 0;
 	l.lut_s = l.lut_b = 0;
 	if (!h->res_class) vn_tables(h->rules, &l.lut_s, &l.lut_b);
 	l.jit_fn = h->res_jit_fn;
 	l.rows = h->res_class ? 32u : h->res_rows;
 	hipError_t e = launch_resident(l, h->stream);
 	if (e != hipSuccess) return fail(CA3D_ERR_DEVICE, "resident kernel launch failed: %s", hipGetErrorString(e));
+	h->res_pending.push_back({h->res_epoch, n, h->cur, h->step, in, other, h->spare});
+	if (n >= 2u)
+	{
+		// rotate: buf[(cur + n) % 2] = the final state, the other one = the state one step earlier, the input becomes the spare
+		if (!h->step_graphs.empty() || !h->slab_graphs.empty() || !h->comm_graphs.empty()) drop_graph(h); // they hold the old pointers
+		const uint32_t f = (h->cur + n) & 1u;
+		h->buf[f] = h->spare;
+		h->buf[f ^ 1u] = other;
+		h->spare = in;
+	}
 	h->res_epoch += n;
-	h->res_check = true;
 	h->kernel_name = h->res_class ? "ca_resident_class(jit)" : (h->res_jit_fn ? "ca_resident_vn(jit)" : "ca_resident_vn");
 	return CA3D_OK;
 }
@@ -600,8 +728,6 @@ int comm_exchange(ca3d_engine *h, hipStream_t s)
 
 } // namespace
 
-static int submit_steps(ca3d_engine *h, uint32_t n_steps);
-
 // queue.submit of the steps encoded so far (option "queue"). Every entry point that looks at the state, the stream or the
 // options goes through here first, so a caller only ever sees the order it asked for.
 int flush_queued(ca3d_engine *h)
@@ -682,6 +808,7 @@ int ca3d_destroy(ca3d_t *h)
 	if (h->comm && rccl().CommDestroy) rccl().CommDestroy(h->comm);
 	if (h->ev_edges) hipEventDestroy(h->ev_edges);
 	if (h->ev_comm) hipEventDestroy(h->ev_comm);
+	if (h->ev_gather) hipEventDestroy(h->ev_gather);
 	if (h->comm_stream) hipStreamDestroy(h->comm_stream);
 	if (h->r_counters) hipFree(h->r_counters);
 	if (h->r_occ) hipFree(h->r_occ);
@@ -752,6 +879,7 @@ int ca3d_set_rules(ca3d_t *h, const int32_t *main_offsets, uint32_t n_main, cons
 {
 	if (!h) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL engine handle");
 	FLUSH_QUEUED(h); // the steps encoded so far run under the rules they were encoded with
+	if (int rcs = settle_resident(h)) return rcs; // ... and a recovery re-runs them under those rules too
 	CanonRules r;
 	std::string err;
 	int rc = canonicalize_rules(main_offsets, n_main, edges_offsets, n_edges, corners_offsets, n_corners, survive, born, &r, &err);
@@ -789,14 +917,16 @@ int ca3d_upload_state(ca3d_t *h, const uint32_t *words, size_t n_words)
 	h->cur = 0;
 	h->pending_edges = 0; // a restart between the two phases of a batch abandons the batch
 	h->ghosts_valid = false;
+	h->res_pending.clear(); // their results have just been overwritten
 	if (h->res_status_host && *h->res_status_host)
 	{
 		// a resident launch gave up earlier: clean mailboxes and status for whoever turns the path on again
 		HIP_TRY(hipMemsetAsync(h->res_mail, 0, h->res_mail_bytes, h->stream));
 		HIP_TRY(hipMemsetAsync(h->res_status, 0, kResStatusBytes, h->stream));
-		*h->res_status_host = 0;
+		h->res_status_host[0] = h->res_status_host[1] = 0;
 		h->res_epoch = 0;
 		h->res_check = false;
+		h->res_failed = true;
 	}
 	h->has_state = true;
 	h->binary_state = false;
@@ -818,10 +948,12 @@ int ca3d_read_state(ca3d_t *h, uint32_t *words, size_t n_words)
 	if (n_words != h->state_words()) return fail(CA3D_ERR_INVALID_ARGUMENT, "state has %zu words, expected %zu", n_words, h->state_words());
 	int rc = bind_device(h);
 	if (rc) return rc;
+	rc = settle_resident(h); // a resident launch that gave up is recovered from before the state is looked at
+	if (rc) return rc;
 	const size_t off = h->slab ? (size_t)h->ghost * h->plane_words : 0;
 	HIP_TRY(hipMemcpyAsync(words, h->buf[h->cur] + off, n_words * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
 	HIP_TRY(hipStreamSynchronize(h->stream));
-	return check_resident(h);
+	return CA3D_OK;
 }
 
 } // extern "C"
@@ -835,6 +967,15 @@ static int submit_steps(ca3d_engine *h, uint32_t n_steps)
 	if (h->want_stats) HIP_TRY(hipEventRecord(h->ev_start, h->stream));
 	uint32_t left = n_steps;
 	uint64_t launches = 0;
+	const bool want_resident = h->res_ready && h->use_resident && !h->res_failed && n_steps >= h->res_min && h->stream != nullptr;
+	if (!h->res_pending.empty() && (!want_resident || h->res_pending.size() >= 64u))
+	{
+		// Per-step kernels write the ping-pong buffers whatever happened before them — one of which is the input a recovery
+		// would start from (a launch queued behind a failed one does nothing, a per-step kernel cannot know): verify the
+		// resident launches still outstanding first. Also for a host that never looks at the state, so that the list stays short.
+		rc = settle_resident(h);
+		if (rc) return rc;
+	}
 	if (h->res_ready && h->use_resident && !h->res_failed && n_steps >= h->res_min && h->stream != nullptr)
 	{
 		rc = resident_steps(h, n_steps);
@@ -1151,6 +1292,7 @@ int ca3d_slab_gather(ca3d_t *h, ca3d_t *full)
 	if (!full->configured || full->slab || full->G != h->G || full->layout != h->layout || full->device != h->device)
 		return fail(CA3D_ERR_INVALID_ARGUMENT, "the target must be a full-grid engine of the same grid, layout and device");
 	FLUSH_QUEUED(full);
+	if (int rcs = settle_resident(full)) return rcs;
 	if ((size_t)h->nz * h->comm_world != h->G) return fail(CA3D_ERR_UNSUPPORTED, "the slabs must split the grid evenly");
 	int rc = bind_device(h);
 	if (rc) return rc;
@@ -1158,8 +1300,22 @@ int ca3d_slab_gather(ca3d_t *h, ca3d_t *full)
 	size_t bytes;
 	rc = ca3d_slab_region(h, CA3D_SLAB_OWNED, &owned, &bytes);
 	if (rc) return rc;
-	// ncclAllGather straight between the engines' device buffers, in rank (= z) order, on the slab engine's stream
+	// ncclAllGather straight between the engines' device buffers, in rank (= z) order, on the slab engine's stream. When the
+	// target engine runs on another stream the gather waits for what that stream still does with the buffer (a frame being
+	// rendered from it) and that stream waits for the gather before it touches the buffer again.
+	const bool cross = full->stream != h->stream;
+	if (cross)
+	{
+		if (!h->ev_gather) HIP_TRY(hipEventCreateWithFlags(&h->ev_gather, hipEventDisableTiming));
+		HIP_TRY(hipEventRecord(h->ev_gather, full->stream));
+		HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_gather, 0));
+	}
 	NCCL_TRY(rccl().AllGather(owned, full->buf[full->cur], bytes / sizeof(uint32_t), kNcclUint32, h->comm, h->stream));
+	if (cross)
+	{
+		HIP_TRY(hipEventRecord(h->ev_gather, h->stream));
+		HIP_TRY(hipStreamWaitEvent(full->stream, h->ev_gather, 0));
+	}
 	full->has_state = true;
 	return CA3D_OK;
 }
@@ -1189,6 +1345,13 @@ int ca3d_synchronize(ca3d_t *h)
 	return check_resident(h);
 }
 
+int ca3d_recovered_launches(ca3d_t *h, uint32_t *out_count)
+{
+	if (!h || !out_count) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL argument");
+	*out_count = h->res_recovered;
+	return CA3D_OK;
+}
+
 int ca3d_set_stream(ca3d_t *h, void *hip_stream)
 {
 	if (!h) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL engine handle");
@@ -1196,10 +1359,14 @@ int ca3d_set_stream(ca3d_t *h, void *hip_stream)
 	int rc = bind_device(h);
 	if (rc) return rc;
 	HIP_TRY(hipStreamSynchronize(h->stream));
+	rc = check_resident(h);
+	if (rc) return rc;
 	resident_stream_retired(h->stream);
 	drop_graph(h);
 	h->stream = (hipStream_t)hip_stream;
 	h->ev_valid = false;
+	refresh_kernels(h); // the new stream may be confined to fewer CUs (CU mask): residency is checked per stream
+	note_jit_failure(h);
 	return CA3D_OK;
 }
 
@@ -1210,10 +1377,14 @@ int ca3d_use_own_stream(ca3d_t *h)
 	int rc = bind_device(h);
 	if (rc) return rc;
 	HIP_TRY(hipStreamSynchronize(h->stream));
+	rc = check_resident(h);
+	if (rc) return rc;
 	resident_stream_retired(h->stream);
 	drop_graph(h);
 	h->stream = h->own_stream;
 	h->ev_valid = false;
+	refresh_kernels(h);
+	note_jit_failure(h);
 	return CA3D_OK;
 }
 
@@ -1223,6 +1394,7 @@ int ca3d_device_buffer(ca3d_t *h, int which, void **device_ptr, size_t *n_bytes)
 	if (!h->configured) return fail(CA3D_ERR_NOT_CONFIGURED, "ca3d_configure has not been called");
 	if (which != 0 && which != 1) return fail(CA3D_ERR_INVALID_ARGUMENT, "buffer index must be 0 or 1");
 	FLUSH_QUEUED(h);
+	if (int rcs = settle_resident(h)) return rcs;
 	*device_ptr = h->buf[which];
 	*n_bytes = h->buffer_words() * sizeof(uint32_t);
 	return CA3D_OK;
@@ -1304,6 +1476,8 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 	if (spp != 1 && spp != 4) return fail(CA3D_ERR_INVALID_ARGUMENT, "spp must be 1 or 4");
 	if (h->render_mode == 1 && spp != 1) return fail(CA3D_ERR_INVALID_ARGUMENT, "the literal frame mode takes one jittered sample per pixel (spp = 1)");
 	int rc = bind_device(h);
+	if (rc) return rc;
+	rc = settle_resident(h); // the frame shows a state the engine has verified
 	if (rc) return rc;
 	const size_t px = (size_t)width * height;
 	if (width != h->rw || height != h->rh)
@@ -1420,6 +1594,16 @@ int ca3d_set_option(ca3d_t *h, const char *name, int64_t value)
 {
 	if (!h || !name) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL argument");
 	FLUSH_QUEUED(h); // options apply to the steps encoded after them
+	if (strcmp(name, "queue") && strcmp(name, "stats"))
+		if (int rcs = settle_resident(h)) return rcs; // ... and a recovery re-runs steps under the options they were issued with
+	if (!strcmp(name, "resident_fault_tile"))
+	{
+		// diagnostics: tile `value - 1` of the NEXT resident launch leaves at once, as a workgroup that never became resident
+		// would; its neighbours time out and the engine recovers (tests/test_gpu_ca_parity.py)
+		if (value < 0 || value > 1024) return fail(CA3D_ERR_INVALID_ARGUMENT, "resident_fault_tile must be in [0, 1024]");
+		h->res_fault_tile = (uint32_t)value;
+		return CA3D_OK;
+	}
 	if (!strcmp(name, "queue"))
 	{
 		if (value < 0 || value > 1000000) return fail(CA3D_ERR_INVALID_ARGUMENT, "queue must be in [0, 1000000] steps");

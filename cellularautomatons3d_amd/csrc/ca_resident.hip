@@ -101,6 +101,57 @@ int resident_slab_planes(const CanonRules &r, uint32_t G, uint32_t nplanes, int 
 	return pz >= 4u && pz <= 24u && pz % 2u == 0 ? (int)pz : 0;
 }
 
+namespace
+{
+// CUs a kernel on `stream` may be placed on: the device's, or fewer under a CU mask (hipExtStreamCreateWithCUMask)
+uint32_t usable_cus(hipStream_t stream)
+{
+	int dev = 0, cus = 0;
+	if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 0;
+	if (stream)
+	{
+		uint32_t mask[16] = {};
+		if (hipExtStreamGetCUMask(stream, 16, mask) == hipSuccess)
+		{
+			uint32_t n = 0;
+			for (uint32_t w : mask) n += (uint32_t)__builtin_popcount(w);
+			if (n && n < (uint32_t)cus) cus = (int)n;
+		}
+		else (void)hipGetLastError();
+	}
+	return (uint32_t)cus;
+}
+} // namespace
+
+bool resident_capacity(uint32_t G, uint32_t rows, void *jit_fn, hipStream_t stream, uint32_t *tiles, uint32_t *capacity)
+{
+	const uint32_t threads = G == 256u ? 256u : 16u * rows;
+	*tiles = G == 256u ? 256u : (G / rows) * (G / kResTileRows);
+	*capacity = 0;
+	int per_cu = 0;
+	hipError_t e;
+	if (jit_fn) e = hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (hipFunction_t)jit_fn, (int)threads, 0);
+	else if (G == 256u) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)ca_resident_vn256<kDefaultS, kDefaultB>, (int)threads, 0);
+	else if (rows == 16u) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)ca_resident_vn<kDefaultS, kDefaultB, 16>, (int)threads, 0);
+	else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)ca_resident_vn<kDefaultS, kDefaultB, 32>, (int)threads, 0);
+	const uint32_t cus = usable_cus(stream);
+	if (e != hipSuccess || per_cu <= 0 || cus == 0) { (void)hipGetLastError(); return false; }
+	*capacity = (uint32_t)per_cu * cus;
+	return true;
+}
+
+bool resident_slab_capacity(void *fn, hipStream_t stream, uint32_t *tiles, uint32_t *capacity)
+{
+	*tiles = (uint32_t)(kSlabTY * kSlabTZ);
+	*capacity = 0;
+	int per_cu = 0;
+	const hipError_t e = hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (hipFunction_t)fn, kSlabThreads, 0);
+	const uint32_t cus = usable_cus(stream);
+	if (e != hipSuccess || per_cu <= 0 || cus == 0) { (void)hipGetLastError(); return false; }
+	*capacity = (uint32_t)per_cu * cus;
+	return true;
+}
+
 size_t resident_slab_mail_bytes() { return 2u * (size_t)(kSlabTY * kSlabTZ) * 4u * kSlabFace * sizeof(unsigned long long); }
 
 hipError_t launch_resident_slab(const ResidentSlabLaunch &l, hipStream_t stream)
@@ -131,6 +182,7 @@ hipError_t launch_resident(const ResidentLaunch &l, hipStream_t stream)
 	a.steps = l.steps;
 	a.epoch0 = l.epoch0;
 	a.timeout_ticks = l.timeout_ticks;
+	a.fault_tile = l.fault_tile;
 	if (l.G == 256u)
 	{
 		// 8 x 32 tiles of 32 rows x 8 planes, 256 threads each (ca_resident_kernel.inc: CW = 8, PZ = 8)

@@ -174,6 +174,12 @@ class Engine:
     def synchronize(self) -> None:
         _capi.check(self._lib.ca3d_synchronize(self._h))
 
+    def recovered_launches(self) -> int:
+        """Resident launches that timed out and whose steps were re-run through the per-step kernels (the state stayed valid)."""
+        n = C.c_uint32()
+        _capi.check(self._lib.ca3d_recovered_launches(self._h, C.byref(n)))
+        return int(n.value)
+
     def set_stream(self, hip_stream: int) -> None:
         """Run on a caller-owned hipStream_t; 0 is HIP's legacy default stream."""
         _capi.check(self._lib.ca3d_set_stream(self._h, C.c_void_p(int(hip_stream))))

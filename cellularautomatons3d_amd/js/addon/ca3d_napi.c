@@ -47,6 +47,13 @@ static int get_args(napi_env env, napi_callback_info info, size_t want, napi_val
 	return 1;
 }
 
+/* What a handle external points at: the engine and the number of asynchronous jobs that still use it (main thread only). */
+typedef struct
+{
+	ca3d_t *h; /* first member: a Slot * reads as a ca3d_t ** */
+	int pending;
+} Slot;
+
 static ca3d_t *get_handle(napi_env env, napi_value v)
 {
 	void *p = NULL;
@@ -96,9 +103,9 @@ static void finalize_handle(napi_env env, void *data, void *hint)
 {
 	(void)env;
 	(void)hint;
-	ca3d_t **slot = (ca3d_t **)data;
-	if (*slot) ca3d_destroy(*slot);
-	*slot = NULL;
+	Slot *slot = (Slot *)data; /* no job is pending: every job holds a reference to the external */
+	if (slot->h) ca3d_destroy(slot->h);
+	slot->h = NULL;
 	free(slot);
 }
 
@@ -111,8 +118,9 @@ static napi_value js_create(napi_env env, napi_callback_info info)
 	ca3d_t *h = NULL;
 	int rc = ca3d_create(device, &h);
 	if (rc) return throw_ca3d(env, rc);
-	ca3d_t **slot = (ca3d_t **)malloc(sizeof *slot);
-	*slot = h;
+	Slot *slot = (Slot *)calloc(1, sizeof *slot);
+	if (!slot) { ca3d_destroy(h); napi_throw_error(env, NULL, "out of memory"); return NULL; }
+	slot->h = h;
 	napi_value ext;
 	NAPI_OK_OR_NULL(napi_create_external(env, slot, finalize_handle, NULL, &ext));
 	return ext;
@@ -125,9 +133,15 @@ static napi_value js_destroy(napi_env env, napi_callback_info info)
 	void *p = NULL;
 	if (napi_get_value_external(env, argv[0], &p) == napi_ok && p)
 	{
-		ca3d_t **slot = (ca3d_t **)p;
-		if (*slot) ca3d_destroy(*slot);
-		*slot = NULL;
+		Slot *slot = (Slot *)p;
+		if (slot->pending)
+		{
+			/* a libuv worker is inside ca3d_read_state / ca3d_render / ca3d_synchronize on this engine */
+			napi_throw_error(env, NULL, "the engine has asynchronous work pending: await it before close()");
+			return NULL;
+		}
+		if (slot->h) ca3d_destroy(slot->h);
+		slot->h = NULL;
 	}
 	return undefined(env);
 }
@@ -453,8 +467,9 @@ typedef struct
 	uint32_t w, hh, spp;
 	uint8_t *pres;
 	uint16_t *light, *depth;
-	napi_ref refs[3]; /* the typed arrays stay alive (and in place) until the job completes */
+	napi_ref refs[4]; /* the handle external and the typed arrays stay alive (and in place) until the job completes */
 	int nrefs;
+	Slot *slot;       /* its `pending` count keeps destroy() away while the worker runs */
 } AsyncJob;
 
 static void job_execute(napi_env env, void *data)
@@ -483,6 +498,7 @@ static void job_complete(napi_env env, napi_status status, void *data)
 		napi_create_error(env, NULL, msg, &v);
 		napi_reject_deferred(env, j->deferred, v);
 	}
+	if (j->slot) j->slot->pending--;
 	for (int i = 0; i < j->nrefs; i++) napi_delete_reference(env, j->refs[i]);
 	napi_delete_async_work(env, j->work);
 	free(j);
@@ -499,6 +515,7 @@ static napi_value job_start(napi_env env, AsyncJob *j, const char *name)
 		napi_throw_error(env, NULL, "could not queue the asynchronous job");
 		return NULL;
 	}
+	if (j->slot) j->slot->pending++;
 	return promise;
 }
 
@@ -507,7 +524,15 @@ static void job_keep(napi_env env, AsyncJob *j, napi_value v)
 	napi_valuetype t;
 	napi_typeof(env, v, &t);
 	if (t == napi_null || t == napi_undefined) return;
-	if (napi_create_reference(env, v, 1, &j->refs[j->nrefs]) == napi_ok) j->nrefs++;
+	if (j->nrefs < (int)(sizeof j->refs / sizeof j->refs[0]) && napi_create_reference(env, v, 1, &j->refs[j->nrefs]) == napi_ok) j->nrefs++;
+}
+
+/* The job keeps the handle external alive (its finalizer destroys the engine) and counts itself on the slot. */
+static void job_hold_engine(napi_env env, AsyncJob *j, napi_value handle)
+{
+	void *p = NULL;
+	if (napi_get_value_external(env, handle, &p) == napi_ok) j->slot = (Slot *)p;
+	job_keep(env, j, handle);
 }
 
 static napi_value js_read_state_async(napi_env env, napi_callback_info info)
@@ -521,6 +546,7 @@ static napi_value js_read_state_async(napi_env env, napi_callback_info info)
 	AsyncJob *j = (AsyncJob *)calloc(1, sizeof *j);
 	if (!j) { napi_throw_error(env, NULL, "out of memory"); return NULL; }
 	j->h = h; j->kind = 0; j->words = (uint32_t *)w; j->n_words = n;
+	job_hold_engine(env, j, argv[0]);
 	job_keep(env, j, argv[1]);
 	return job_start(env, j, "ca3d.readState");
 }
@@ -549,6 +575,7 @@ static napi_value js_render_async(napi_env env, napi_callback_info info)
 	j->h = h; j->kind = 1; j->w = w; j->hh = hh; j->spp = spp;
 	memcpy(j->uniforms, u, sizeof j->uniforms); /* the block is consumed now, like the reference's writeBuffer */
 	j->pres = (uint8_t *)pres; j->light = (uint16_t *)light; j->depth = (uint16_t *)depth;
+	job_hold_engine(env, j, argv[0]);
 	job_keep(env, j, argv[5]); job_keep(env, j, argv[6]); job_keep(env, j, argv[7]);
 	return job_start(env, j, "ca3d.render");
 }
@@ -562,6 +589,7 @@ static napi_value js_synchronize_async(napi_env env, napi_callback_info info)
 	AsyncJob *j = (AsyncJob *)calloc(1, sizeof *j);
 	if (!j) { napi_throw_error(env, NULL, "out of memory"); return NULL; }
 	j->h = h; j->kind = 2;
+	job_hold_engine(env, j, argv[0]);
 	return job_start(env, j, "ca3d.synchronize");
 }
 

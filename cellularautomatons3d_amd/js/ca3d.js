@@ -178,11 +178,19 @@ class Engine
 		this.gridSize = 0;
 	}
 
-	close() { if (this._h) { this._a.destroy(this._h); this._h = null; } }
+	// An asynchronous job holds the engine on a worker thread until its promise settles: nothing else may enter the engine
+	// meanwhile (it is not thread-safe), and it must not be destroyed under the worker.
+	_idle(what)
+	{
+		if (this._inflight) { throw new Error("ca3d: " + what + "() while an asynchronous call is pending on this engine — await it first"); }
+	}
+	close() { this._idle("close"); if (this._h) { this._a.destroy(this._h); this._h = null; } }
+	/** close() once every asynchronous call issued so far has settled. */
+	closeAsync() { return (this._pending || Promise.resolve()).then(() => this.close()); }
 
-	configure(gridSize, layout) { this._a.configure(this._h, gridSize, layout || LAYOUT_PACKED32); this.gridSize = gridSize; }
+	configure(gridSize, layout) { this._idle("configure"); this._a.configure(this._h, gridSize, layout || LAYOUT_PACKED32); this.gridSize = gridSize; }
 
-	setRules(mainOffsets, edgesOffsets, cornersOffsets, survive, born) { this._a.setRules(this._h, mainOffsets, edgesOffsets, cornersOffsets, survive, born); }
+	setRules(mainOffsets, edgesOffsets, cornersOffsets, survive, born) { this._idle("setRules"); this._a.setRules(this._h, mainOffsets, edgesOffsets, cornersOffsets, survive, born); }
 
 	setRuleStrings(rules)
 	{
@@ -199,19 +207,20 @@ class Engine
 		this.uploadState(initialState(gridSize, randomInitialState, random));
 	}
 
-	uploadState(words) { this._a.uploadState(this._h, words); }
+	uploadState(words) { this._idle("uploadState"); this._a.uploadState(this._h, words); }
 
 	readState()
 	{
+		this._idle("readState");
 		const out = new Uint32Array(this.info().stateWords);
 		this._a.readState(this._h, out);
 		return out;
 	}
 
 	// _computePass (1796-1809), n times
-	step(n) { this._a.step(this._h, n === undefined ? 1 : n); }
+	step(n) { this._idle("step"); this._a.step(this._h, n === undefined ? 1 : n); }
 	/** device.queue.submit: submits the steps encoded under setOption("queue", n). */
-	flush() { this._a.flush(this._h); }
+	flush() { this._idle("flush"); this._a.flush(this._h); }
 
 	// Z-slab mode (multi-GPU hosts; SURVEY 8(e)): see include/ca3d.h. phase: 0 whole batch, 1 edge zones, 2 interior.
 	configureSlab(gridSize, z0, nz, ghost, layout) { this._a.configureSlab(this._h, gridSize, layout === undefined ? LAYOUT_PACKED32 : layout, z0, nz, ghost); }
@@ -225,12 +234,13 @@ class Engine
 	slabExchange() { this._a.slabExchange(this._h); }
 	slabGather(full) { this._a.slabGather(this._h, full._h); }
 
-	synchronize() { this._a.synchronize(this._h); }
+	synchronize() { this._idle("synchronize"); this._a.synchronize(this._h); }
 
 	// _renderPass (1775-1794) with the reference's 128-float block (MemoryManager.bufferf32)
 	render(uniforms, width, height, spp, targets)
 	{
 		const t = targets || {};
+		this._idle("render");
 		this._a.render(this._h, uniforms, width, height, spp || 1, t.presentation || null, t.light || null, t.depth || null);
 	}
 
@@ -239,8 +249,11 @@ class Engine
 	// the promise has settled (asynchronous calls issued meanwhile queue up behind it by themselves).
 	_queue(start)
 	{
-		const p = (this._pending || Promise.resolve()).then(start, start);
-		this._pending = p.catch(() => undefined);
+		this._inflight = (this._inflight || 0) + 1;
+		const done = () => { this._inflight--; };
+		const run = () => { const inflight = this._inflight; this._inflight = 0; try { return start(); } finally { this._inflight = inflight; } };
+		const p = (this._pending || Promise.resolve()).then(run, run);
+		this._pending = p.then(done, done);
 		return p;
 	}
 	readStateAsync()
@@ -257,10 +270,10 @@ class Engine
 	}
 	synchronizeAsync() { return this._queue(() => this._a.synchronizeAsync(this._h)); }
 
-	info() { return this._a.info(this._h); }
-	stats() { return this._a.stats(this._h); }
-	renderStats() { return this._a.renderStats(this._h); }
-	setOption(name, value) { this._a.setOption(this._h, name, value); }
+	info() { this._idle("info"); return this._a.info(this._h); }
+	stats() { this._idle("stats"); return this._a.stats(this._h); }
+	renderStats() { this._idle("renderStats"); return this._a.renderStats(this._h); }
+	setOption(name, value) { this._idle("setOption"); this._a.setOption(this._h, name, value); }
 }
 
 module.exports = {

@@ -350,24 +350,29 @@ class SlabRenderer:
         # number of rows, starting at its band, clamped so that the window stays inside the target), no pickled host objects
         rows = max(band_rows(height, world, k)[1] - band_rows(height, world, k)[0] for k in range(world))
         start = min(y0, height - rows)
-        if y1 > y0:
-            self.full.render(uniforms, width, height, spp, readback=False, rows=(y0, y1))
-            ptr, nbytes = self.full.render_target(0)
-            target = device_tensor(ptr, nbytes, self.device).view(torch.uint8).view(height, width * 4)
-            mine = target[start:start + rows].contiguous()
-        else:
-            mine = torch.zeros((rows, width * 4), dtype=torch.uint8, device=f"cuda:{self.device}")
-        parts = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
+        # Everything below runs on the engines' stream: the render was enqueued there, so the window copy, the tensors the
+        # gather fills and the read-back must be ordered behind it (on torch's default stream they would race the kernel and
+        # the collective); the collective's own stream is ordered against this one by torch.distributed.
         with torch.cuda.stream(self.se.stream):
+            if y1 > y0:
+                self.full.render(uniforms, width, height, spp, readback=False, rows=(y0, y1))
+                ptr, nbytes = self.full.render_target(0)
+                target = device_tensor(ptr, nbytes, self.device).view(torch.uint8).view(height, width * 4)
+                mine = target[start:start + rows].contiguous()
+            else:
+                mine = torch.zeros((rows, width * 4), dtype=torch.uint8, device=f"cuda:{self.device}")
+            parts = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
             dist.gather(mine, parts, dst=0, group=self.group)
-        if rank != 0:
-            return None
+            if rank != 0:
+                return None
+            host_parts = [p.to("cpu", non_blocking=False) for p in parts]  # a blocking copy on this stream: behind the gather
+        self.se.stream.synchronize()
         frame = np.empty((height, width, 4), dtype=np.uint8)
         for k in range(world):
             b0, b1 = band_rows(height, world, k)
             s0 = min(b0, height - rows)
             if b1 > b0:
-                frame[b0:b1] = parts[k].cpu().numpy().reshape(rows, width, 4)[b0 - s0:b1 - s0]
+                frame[b0:b1] = host_parts[k].numpy().reshape(rows, width, 4)[b0 - s0:b1 - s0]
         return frame
 
     def close(self) -> None:

@@ -170,11 +170,20 @@ int ca3d_render_target(ca3d_t *h, int which, void **device_ptr, size_t *n_bytes)
 
 int ca3d_synchronize(ca3d_t *h);
 
+/* Resident launches that gave up (a wait for neighbour tile faces timed out: not all workgroups were on the chip) and
+ * whose steps the engine re-ran through the per-step kernels, since ca3d_create. The calls that noticed returned CA3D_OK
+ * with the final state intact; ca3d_last_error() carried a note and the resident path stays off until
+ * ca3d_set_option("resident", 1). Slab engines do not recover (the neighbours' ghosts came from the failed launch):
+ * they return CA3D_ERR_DEVICE and want a new upload. */
+int ca3d_recovered_launches(ca3d_t *h, uint32_t *out_count);
+
 /* Interop: run on a caller-owned hipStream_t (e.g. torch's current stream). NULL is HIP's legacy default stream
  * (what torch uses unless told otherwise), not "none". ca3d_use_own_stream goes back to the engine's stream. */
 int ca3d_set_stream(ca3d_t *h, void *hip_stream);
 int ca3d_use_own_stream(ca3d_t *h);
-/* Device pointer of ping-pong buffer `which` (0/1) — whole allocation including ghosts. */
+/* Device pointer of ping-pong buffer `which` (0/1) — whole allocation including ghosts. Valid until the next ca3d_step /
+ * ca3d_upload_state / ca3d_configure on the engine: a resident multi-step launch writes its result to a third buffer and
+ * rotates the three (buffer [step % 2] is always the current state, the other one the state one step earlier). */
 int ca3d_device_buffer(ca3d_t *h, int which, void **device_ptr, size_t *n_bytes);
 
 typedef struct ca3d_info
@@ -251,8 +260,11 @@ int ca3d_get_render_stats(ca3d_t *h, ca3d_render_stats *out);
  * kernel for the current rule, compiled inside ca3d_set_rules / ca3d_configure (on by default; a failed compile
  * keeps the pre-built kernels and is reported through ca3d_get_jit_log); "resident" 0/1: batches of "resident_min" (default 8) steps and more run as ONE launch of
  * the resident multi-step kernel where one exists (512^3, von Neumann rule tables: the state stays in registers and only
- * tile faces cross the chip; every in-kernel wait is bounded by "resident_timeout_us", default 200 000 — a timeout makes
- * the next ca3d_synchronize / ca3d_read_state / ca3d_get_stats fail with CA3D_ERR_DEVICE and turns the path off);
+ * tile faces cross the chip; a resident kernel is only selected when the runtime says all its workgroups fit on the CUs the
+ * engine's stream may use; every in-kernel wait is bounded by "resident_timeout_us", default 200 000 — after a timeout the
+ * engine re-runs the affected steps through the per-step kernels at the next call that looks at the state and turns the
+ * path off: ca3d_recovered_launches; "resident_fault_tile" t: diagnostics, tile t - 1 of the next resident launch leaves at
+ * once, which makes that launch time out);
  * "roll" 0/1 the rolling-window form of the run-time compiled class kernels (on by
  * default where it applies), "roll_z" 0/2/4/8 its planes per thread (0: chosen per launch); "graph_min" n: batches shorter than n
  * steps are launched kernel by kernel instead of as a captured graph; "render_mode" 0/1; "render_row_begin" / "render_row_end":

@@ -92,6 +92,9 @@ assert.throws(() => eng.uploadState(new Uint32Array(3)), /expected/);
 	const timer = setInterval(() => { ticks++; }, 0);
 	const pres2 = new Uint8Array(W * H * 4), light2 = new Uint16Array(W * H * 4);
 	const jobs = [eng.readStateAsync(), eng.renderAsync(u, W, H, 1, { presentation: pres2, light: light2 }), eng.synchronizeAsync(), eng.readStateAsync()];
+	// while a worker thread is inside the engine nothing else may enter it, and it cannot be destroyed under the worker
+	assert.throws(() => eng.step(1), /asynchronous call is pending/);
+	assert.throws(() => eng.close(), /asynchronous call is pending/);
 	const done = await Promise.all(jobs);
 	clearInterval(timer);
 	assert.deepStrictEqual(Buffer.from(done[0].buffer), Buffer.from(stateSync.buffer));
@@ -99,6 +102,8 @@ assert.throws(() => eng.uploadState(new Uint32Array(3)), /expected/);
 	assert.deepStrictEqual(Buffer.from(pres2.buffer), Buffer.from(pres.buffer));
 	assert.deepStrictEqual(Buffer.from(light2.buffer), Buffer.from(light.buffer));
 	await assert.rejects(eng.renderAsync(u, W, H, 3, {}), /spp must be 1 or 4/);
-	eng.close();
+	const last = eng.readStateAsync();
+	await eng.closeAsync(); // waits for what is pending, then destroys
+	assert.deepStrictEqual(Buffer.from((await last).buffer), Buffer.from(stateSync.buffer));
 	console.log("ok");
 })().catch((e) => { console.error(e); process.exit(1); });

@@ -376,7 +376,7 @@ def test_resident_multi_step_kernel(eng, tables, rows):
     eng.step(60)
     np.testing.assert_array_equal(got, eng.read_state())
     np.testing.assert_array_equal(got, ol.packed_run(G, st2, r, 60))
-    # 1000 steps on a dense state in one launch against 1000 launches of the per-step kernel
+    # 1000 steps on a dense state in one launch against 1000 launches of the per-step kernel AND against the oracle
     eng.upload_state(st)
     eng.step(1000)
     per_step = eng.read_state()
@@ -384,7 +384,55 @@ def test_resident_multi_step_kernel(eng, tables, rows):
     eng.upload_state(st)
     eng.step(1000)
     assert eng.info().kernel_name.startswith(b"ca_resident_vn")
-    np.testing.assert_array_equal(eng.read_state(), per_step)
+    got = eng.read_state()
+    np.testing.assert_array_equal(got, per_step)
+    if rows == 32:
+        np.testing.assert_array_equal(got, ol.packed_run(G, st, r, 1000), err_msg="1000 resident steps vs the oracle")
+    assert eng.recovered_launches() == 0
+
+
+@pytest.mark.parametrize("name,G,n", [("default", 512, 40), ("default", 256, 33), ("clustered", 512, 16)])
+def test_resident_launch_that_gives_up_is_recovered(name, G, n):
+    """A resident launch only completes when all its workgroups are on the chip. Simulate one that is not (option
+    "resident_fault_tile": that tile leaves at once, exactly what a workgroup stuck in the dispatcher's queue looks like to
+    its neighbours) with a short timeout: the neighbours' waits expire, the launch and the resident launches queued behind
+    it write nothing, and the engine re-runs their steps from the intact input through the per-step kernels — the call
+    sequence ends bit-exact with the oracle, the resident path is off afterwards and can be turned on again."""
+    from cellularautomatons3d_amd import Engine
+
+    r = rules(name)
+    with Engine(0) as e:
+        e.configure(G)
+        set_rules(e, r)
+        assert e.info().kernel_name.startswith(b"ca_resident")
+        st = host.random_fill(host.words_per_buffer(G), seed=404, and_rounds=1)
+        e.upload_state(st)
+        e.set_option("resident_timeout_us", 3000)
+        e.step(9)                                 # a good launch first: the failing one starts from a rotated buffer set
+        e.set_option("resident_fault_tile", 38)   # tile 37 of the next launch never shows up
+        e.step(n)
+        e.step(n + 1)                             # queued behind the failing one: must not touch anything
+        e.step(3)                                 # a short batch (per-step kernels) behind both
+        got = e.read_state()
+        assert e.recovered_launches() == 1
+        assert not e.info().kernel_name.startswith(b"ca_resident"), e.info().kernel_name
+        total = 9 + n + n + 1 + 3
+        assert e.info().step == total and e.info().current_buffer == total % 2
+        want_prev = ol.packed_run(G, st, r, total - 1)
+        want = ol.packed_step(G, want_prev, r)
+        np.testing.assert_array_equal(got, want)
+        from cellularautomatons3d_amd import slab
+        other = slab.device_tensor(*e.device_buffer(1 - total % 2), 0).cpu().numpy().view(np.uint32)
+        np.testing.assert_array_equal(other, want_prev, err_msg="the other buffer holds the state one step earlier")
+        # the per-step kernels carry on; the path can be switched on again and works
+        e.step(5)
+        want = ol.packed_run(G, want, r, 5)
+        np.testing.assert_array_equal(e.read_state(), want)
+        e.set_option("resident", 1)
+        assert e.info().kernel_name.startswith(b"ca_resident")
+        e.step(12)
+        np.testing.assert_array_equal(e.read_state(), ol.packed_run(G, want, r, 12))
+        assert e.recovered_launches() == 1
 
 
 @pytest.mark.parametrize("name", ["clustered", "moore_b4s4", "edges_main", "corners_main", "vn_edges_only", "moore_wide"])
@@ -419,6 +467,12 @@ def test_resident_class_kernel(eng, name):
     assert np.array_equal(got, eng.read_state())
     assert np.array_equal(got, ol.packed_run(G, edge, r, 12))
     eng.set_option("resident", 1)
+    if name == "clustered":
+        # a long batch in one launch against the oracle (256 steps of the live kernel's full semantics)
+        eng.upload_state(st)
+        eng.step(256)
+        assert eng.info().kernel_name == b"ca_resident_class(jit)"
+        assert np.array_equal(eng.read_state(), ol.packed_run(G, st, r, 256)), "256 resident class steps vs the oracle"
 
 
 def test_batches_of_any_length_replay_as_graphs(eng):

@@ -6,7 +6,7 @@
       bench.py --gpus N --steps K --warmup W             (the same, launched from outside)
 
 A "step" is one CA step (one dispatch of the reference's compute pass, main_pathtraced.js:1796-1809) over the whole
-grid. The batch of K steps is repeated (`reps`) until at least 50 ms are timed. At N = 1 the K-step calls are ENCODED
+grid. The batch of K steps is repeated (`reps`) until at least 1 s is timed (every CA leg). At N = 1 the K-step calls are ENCODED
 (`ca3d_set_option("queue")`) and handed to the GPU 2048 steps at a time (`ca3d_flush`) — what the reference does with its
 command encoder and one queue.submit (main_pathtraced.js:1833-1850) — so the value does not depend on K: the resident
 multi-step kernel runs a submission as one launch. `--submit call` makes every K-step call its own submission.
@@ -18,9 +18,15 @@ Configs 4 and 5 at N = 1 run the same grid on one GPU: the base of the scaling c
 carries it as `scaling_base`, measured in the same run). The state is resident in HBM before the timed region; the
 timed region is bracketed by barrier + synchronize and the max over ranks is taken.
 
-Prints ONE JSON line on rank 0 with `roofline` (algorithmic bytes per launch / launch duration from HIP events recorded
-on the engine's stream around the timed region, against the 8 TB/s HBM peak) and, at N = 1, `cpu_baseline` (the CPU
-oracle timed on this host's cores on a bounded sample).
+Prints ONE JSON line on rank 0 with `roofline` and, at N = 1, `cpu_baseline` (the CPU oracle timed on this host's cores on a
+bounded sample). `roofline` names the limiter of the kernel that ran: per-step kernels read and write the state every step —
+algorithmic bytes per launch / launch duration (HIP events on the engine's stream around the timed region) against the
+8 TB/s HBM peak; the resident multi-step kernels keep the state on chip, what bounds them is vector-instruction issue —
+wave-instructions per second (count per wave and step from the committed rocprofv3 SQ pass of this command, profiles/) against
+1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction — with the algorithmic-byte rate beside it as `hbm_equivalent`.
+The N = 1 line also carries: `per_step_kernels` (the same grid with every step through memory: the HBM-path fraction),
+`per_call` (every K-step call its own submission), `grid_256` (BASELINE configs[1]'s grid), `render` / `render_4k`,
+`scaling_base` (1024^3 on one GPU).
 """
 import argparse
 import json
@@ -36,7 +42,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 INFINITY_CACHE_BYTES = 256 << 20
-MIN_TIMED_SECONDS = 0.05
+MIN_TIMED_SECONDS = 1.0
+VALU_PEAK_GWIPS = 1024 * 2.4 / 2.0  # G wave-instructions/s: 256 CUs x 4 SIMD-32, a wave64 VALU instruction issues over 2 cycles (MI355X_MICROARCH.md, Wave scheduling), 2.4 GHz
 
 RULES = {
     "default": dict(neighbourhood="von neumann", born="1,3", survive="0-6"),
@@ -69,6 +76,8 @@ def parse(argv=None):
     ap.add_argument("--no-render", action="store_true", help="skip the renderer legs (N=1)")
     ap.add_argument("--no-scaling-base", action="store_true", help="N=1, config 3: skip the 1024^3 single-GPU leg")
     ap.add_argument("--no-per-step-leg", action="store_true", help="N=1: skip the per-step-kernel leg printed beside a resident-kernel headline")
+    ap.add_argument("--no-per-call-leg", action="store_true", help="N=1: skip the per-call-submission leg printed beside a queued-submission headline")
+    ap.add_argument("--no-grid-256", action="store_true", help="N=1, config 3: skip the 256^3 leg (BASELINE configs[1]'s grid)")
     ap.add_argument("--multi-render", action="store_true",
                     help="N>1: also time the frame shared between the ranks (volume all-gather + bands of image rows); "
                          "off by default (on for --config 5) so that the scaling run times the CA step alone")
@@ -93,6 +102,9 @@ def parse(argv=None):
                          "that a profile of the default command holds launches of one length only)")
     ap.add_argument("--queue", type=int, default=2048, help="steps per submission with --submit queued")
     ap.add_argument("--check", action="store_true", help="verify the final state against the oracle (small grids)")
+    ap.add_argument("--verify-steps", type=int, default=-1,
+                    help="N>1: before the timed region run this many steps from the bench state and compare every rank's slab with the CPU oracle "
+                         "(default: ghost + 8 steps — past one halo exchange — on grids up to 1024^3, 0 = off beyond); the state is uploaded again afterwards")
     a = ap.parse_args(argv)
     a.config = a.config or (3 if a.gpus == 1 else 4)
     cfg = CONFIGS[a.config]
@@ -102,6 +114,8 @@ def parse(argv=None):
     a.overlap = a.overlap or cfg.get("overlap", "auto")
     if a.config == 5 and a.gpus > 1:
         a.multi_render = True
+    if a.verify_steps < 0:
+        a.verify_steps = a.ghost + 8 if (a.gpus > 1 and a.grid <= 1024) else 0
     return a
 
 
@@ -174,10 +188,43 @@ def time_frames(eng, u, W, H, spp, frames):
     return time.perf_counter() - t0, eng.render_stats()
 
 
-def render_leg(eng, G, a, size=None, sparse=True):
+def render_pmc_record(kernel_ms):
+    """What bounds the dense frame's kernel, from the committed PMC passes over the same scene (tools/pmc_render.sh ->
+    profiles/r*_pmc_render.json, newest): vector-issue fraction, live lanes, L2 hit rate, bytes served by the L2 per second.
+    SURVEY 8(d): "report Mray/s and achieved GB/s from rocprof, no roofline claim beyond that"."""
+    import glob
+
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_render.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        ks = [k for k, v in d.items() if "sched<false" in k and v.get("SQ_INSTS_VALU")]
+        if not ks:
+            continue
+        v = d[ks[0]]
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs: cycles of the kernel = / 8 (MI355X_MICROARCH.md, DVFS give-back)
+        cycles = v["GRBM_GUI_ACTIVE"] / 8.0
+        rec = {"bound": "valu_issue at partial lane occupancy (divergent walks)", "kernel": ks[0], "counter_source": os.path.relpath(f, ROOT),
+               "valu_issue_frac": round(v["SQ_INSTS_VALU"] * 2.0 / (1024.0 * cycles), 4),  # wave-instructions x 2 cycles / (SIMDs x kernel cycles)
+               "lanes_active_frac": round(v["SQ_THREAD_CYCLES_VALU"] / (v["SQ_ACTIVE_INST_VALU"] * 64.0), 4) if v.get("SQ_ACTIVE_INST_VALU") else None,
+               "wave_cycles_issuing_valu_frac": round(v["SQ_ACTIVE_INST_VALU"] / v["SQ_WAVE_CYCLES"], 4),
+               "wave_cycles_waiting_frac": round(v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"], 4) if v.get("SQ_WAIT_ANY") else None,
+               "l2_hit_rate": round(v["TCC_HIT_sum"] / (v["TCC_HIT_sum"] + v["TCC_MISS_sum"]), 4) if v.get("TCC_HIT_sum") else None}
+        if v.get("TCC_REQ_sum") and kernel_ms:
+            rec["l2_request_gbs"] = round(v["TCC_REQ_sum"] * 128.0 / (kernel_ms * 1e-3) / 1e9, 1)   # 128-B lines requested of the L2 per second (this run's kernel time)
+        if v.get("TCC_EA0_RDREQ_sum") and kernel_ms:
+            rec["fabric_read_gbs"] = round(v["TCC_EA0_RDREQ_sum"] * 64.0 * 2.0 / (kernel_ms * 1e-3) / 1e9, 1)  # = FETCH_SIZE, doubled as the guide prescribes
+        return rec
+    return None
+
+
+def render_leg(eng, G, a, size=None, sparse=True, literal=True):
     """Second half of BASELINE's metric: Mray/s of the volume renderer at 1080p (config 5: 3840x2160), 4 spp, on the
     same grid size. Volume = hashed fill of density 2^-5 (dense silhouette), oblique bench pose (SURVEY 8(d));
-    rays = primary + shadow rays traced; frames stay on the device (no read-back in the timed region)."""
+    rays = primary + shadow rays traced; frames stay on the device (no read-back in the timed region). `literal`: also the
+    reference's own per-frame workload — ONE jittered fixed-step sample per pixel with the temporal history look-ups and the
+    EMA blend (fragment_main, pathtraced_fragment_clustered.wgsl:800-890; main_pathtraced.js:1775-1794), render_mode 1."""
     from cellularautomatons3d_amd import host
 
     W, H = (int(v) for v in (size or a.render_size).lower().split("x"))
@@ -192,6 +239,31 @@ def render_leg(eng, G, a, size=None, sparse=True):
              "cell_visits_per_shadow_ray": round(st.shadow_cell_visits / max(1, st.shadow_rays), 2),
              "config": {"workload": f"{G}^3 packed volume, hashed fill density 2^-5, {W}x{H} @ {a.render_spp} spp, oblique pose "
                                     "(0.6 rad about (1,1,0), distance 1.4), exact DDA walk + shadow ray + Cook-Torrance"}}
+    if H == 1080 and a.render_spp == 4:
+        pmc = render_pmc_record(st.gpu_ms)
+        if pmc:
+            dense["pmc"] = pmc
+    if literal:
+        import torch
+
+        vm = host.orbit_camera()
+        eng.set_render_mode(True)
+        try:
+            eng.reset_render_history()
+            for i in range(3):
+                eng.render(host.uniform_block(W, H, vm, elapsed_time=0.5 + 0.01 * i, prev_view_mat=vm), W, H, 1, readback=False)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(a.render_frames):
+                eng.render(host.uniform_block(W, H, vm, elapsed_time=0.6 + 0.01 * i, prev_view_mat=vm), W, H, 1, readback=False)
+            torch.cuda.synchronize()
+            dtl = time.perf_counter() - t0
+            dense["literal_frame"] = {"ms_per_frame": round(dtl * 1e3 / a.render_frames, 4), "kernel_ms": round(eng.render_stats().gpu_ms, 4),
+                                      "value": round(W * H * a.render_frames / dtl / 1e6, 2), "unit": "Mpixel/s",
+                                      "workload": f"the reference's own frame: one jittered fixed-step sample per pixel (<= 35 primary + <= 30 shadow march samples), history "
+                                                  f"look-ups, depth repair, temporal blend; same scene and pose, {W}x{H}, static camera (prev matrices = current)"}
+        finally:
+            eng.set_render_mode(False)
     if sparse:
         # the reference UI's own start-up scene (SURVEY 8(d) "sparse"): the single seed evolved 30 steps, default pose
         eng.upload_state(host.initial_state(G))
@@ -253,24 +325,30 @@ def render_leg_multi(se, G, a, world, rank, barrier):
     return out
 
 
-def copy_ceiling_gbs():
-    """Measured device-to-device copy rate (read + write bytes per second) of a 1 GiB buffer: the practical HBM
-    ceiling SURVEY 8(d) asks to be reported next to the 8 TB/s vendor peak."""
-    import torch
+def copy_ceiling_gbs(eng):
+    """Measured device-to-device copy rate (read + write bytes per second) of a 1 GiB buffer through a float4-per-lane copy
+    kernel with non-temporal stores (ca3d_measure_copy): the practical HBM ceiling SURVEY 8(d) asks to be reported next to the
+    8 TB/s vendor peak (MI355X_MICROARCH.md quotes 6.29 TB/s for this kind of kernel)."""
+    return eng.measure_copy(1 << 30, 8)
 
-    n = 1 << 30
-    a = torch.empty(n, dtype=torch.uint8, device="cuda")
-    b = torch.empty(n, dtype=torch.uint8, device="cuda")
-    a.zero_()
-    b.copy_(a)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(8):
-        b.copy_(a)
-    e1.record()
-    torch.cuda.synchronize()
-    return 2.0 * n * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+def sq_profile(kernel, G):
+    """The committed rocprofv3 SQ pass of this command for a resident kernel (tools/profile_round3.sh -> tools/pmc_sq_reduce.py):
+    newest profiles/r*_pmc_sq_<key>.json that says how many steps its launches held. None when there is none."""
+    import glob
+
+    base = kernel.split("(")[0]
+    key = {"ca_resident_vn": f"resident{G}", "ca_resident_class": f"clustered{G}", "ca_resident_slab_vn": "residentslab"}.get(base)
+    if not key:
+        return None, None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_sq_{key}.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("steps_per_launch") and d.get("SQ_INSTS_VALU") and d.get("SQ_WAVES"):
+            return d, os.path.relpath(f, ROOT)
+    return None, None
 
 
 def pmc_traffic(kernel, G, steps_per_launch=1):
@@ -389,21 +467,44 @@ def roofline_block(kernel, G, bytes_per_step, total_steps, ev_ms, state_bytes, l
     if steps_per_launch == int(steps_per_launch):
         steps_per_launch = int(steps_per_launch)
     launch_ms = ev_ms / max(1, launches)
-    achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+    hbm_rate = bytes_per_launch / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
     traffic = pmc_traffic(kernel, G, steps_per_launch)
+    traffic_source = None if traffic is None else ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
+                                                   "(fabric requests, Infinity Cache hits included), not measured in this run")
+    common = {"kernel": kernel, "launch_us": round(launch_ms * 1e3, 3), "steps_per_launch": steps_per_launch,
+              "algorithmic_bytes_per_launch": bytes_per_launch, "launches_timed": int(launches),
+              "timing": "HIP events on the engine's stream around the whole timed region / launches in it",
+              "working_set_bytes": 2 * state_bytes}
+    if kernel.startswith("ca_resident"):
+        # State in registers + LDS for the whole launch; per step only the tile faces cross the fabric (2 MiB of payload at
+        # 512^3). The HBM model does not describe this kernel (its algorithmic-byte rate exceeds the HBM peak): what bounds it is
+        # vector-instruction issue. Instructions per launch come from the SQ pass of this command, the time from this run.
+        prof, src = sq_profile(kernel, G)
+        out = {"bound": "valu_issue", "achieved": None, "peak": VALU_PEAK_GWIPS, "unit": "Gwaveinst/s", "frac": None,
+               "traffic": traffic, "traffic_source": traffic_source}
+        if prof:
+            valu_per_step = prof["SQ_INSTS_VALU"] / prof["steps_per_launch"]
+            achieved = valu_per_step * steps_per_launch / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+            out.update({"achieved": round(achieved, 2), "frac": round(achieved / VALU_PEAK_GWIPS, 4),
+                        "valu_wave_instructions_per_step": round(valu_per_step), "valu_per_wave_step": round(valu_per_step / prof["SQ_WAVES"], 1),
+                        "waves": int(prof["SQ_WAVES"]), "counter_source": src,
+                        "peak_definition": "1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (SIMD-32; needs >= 2 waves per SIMD); "
+                                           "half-rate instructions (v_alignbit, DPP moves) count once, so full issue sits below frac 1"})
+        else:
+            out["note"] = "no profiles/r*_pmc_sq_* pass with steps_per_launch for this kernel: instruction count unknown"
+        out.update(common)
+        out["hbm_equivalent"] = {"achieved": round(hbm_rate, 2), "unit": "GB/s", "hbm_peak": HBM_PEAK_GBS,
+                                 "note": "algorithmic bytes (0.25 B per cell-step) per second — a rate, not a fraction of anything: the state does not move; "
+                                         "the HBM-path fraction of this grid is per_step_kernels.roofline.frac"}
+        out["resident"] = "registers + LDS"
+        return out
     fits = 2 * state_bytes < INFINITY_CACHE_BYTES
-    return {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "traffic_source": None if traffic is None else "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
-                                                          "(fabric requests, Infinity Cache hits included), not measured in this run",
-            "kernel": kernel, "launch_us": round(launch_ms * 1e3, 3), "steps_per_launch": steps_per_launch,
-            "algorithmic_bytes_per_launch": bytes_per_launch, "launches_timed": int(launches),
-            "timing": "HIP events on the engine's stream around the whole timed region / launches in it",
-            "working_set_bytes": 2 * state_bytes,
-            "resident": "registers + LDS (the resident multi-step kernel keeps the state on chip for the whole batch; per step only the tile faces, "
-                        "2 MiB at 512^3, cross the fabric — the rate is algorithmic bytes per second against the HBM peak and may exceed it)" if kernel.startswith("ca_resident") else
-                        "infinity cache (both ping-pong buffers fit in 256 MiB: the rate is an algorithmic-byte rate against the HBM peak, "
-                        "not DRAM traffic)" if fits else "hbm (the ping-pong buffers exceed the 256 MiB Infinity Cache)"}
+    out = {"bound": "hbm", "achieved": round(hbm_rate, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(hbm_rate / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source}
+    out.update(common)
+    out["resident"] = ("infinity cache (both ping-pong buffers fit in 256 MiB: the rate is an algorithmic-byte rate against the HBM peak, "
+                       "not DRAM traffic)" if fits else "hbm (the ping-pong buffers exceed the 256 MiB Infinity Cache)")
+    return out
 
 
 def main():
@@ -447,6 +548,7 @@ def main():
         torch.cuda.synchronize()
 
     se = None
+    verified = None
     if world == 1:
         queue = a.queue if a.submit == "queued" else 0
         eng, full, dt, reps, ev_ms, cal, launches = single_gpu_leg(local_rank, G, a.rule, a.steps, a.warmup, a.min_seconds, a.density_rounds, a.resident, queue)
@@ -467,6 +569,22 @@ def main():
         se.engine.set_rules(*offs, s, b)
         se.upload_state(full[se.z0 * pw:(se.z0 + se.nz) * pw])
         core = se.engine
+        if a.verify_steps > 0:
+            # the multi-GPU path has no reference counterpart: its state must equal the single-grid oracle's. Checked here on
+            # every run, across at least one halo exchange, before anything is timed.
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import numpy as np
+            import oracle_lib as ol
+
+            se.run(a.verify_steps)
+            got = core.read_state()
+            want = ol.packed_run(G, full, ol.Rules.from_strings(**rule_kw), a.verify_steps, max(1, min(os.cpu_count() or 1, 128) // world))
+            flag = torch.tensor([1 if np.array_equal(got, want[se.z0 * pw:(se.z0 + se.nz) * pw]) else 0], dtype=torch.int32,
+                                device="cuda" if a.backend == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            verified = bool(flag.item())
+            del want, got
+            se.upload_state(full[se.z0 * pw:(se.z0 + se.nz) * pw])
         dt, reps, ev_ms, cal, launches = timed_region(se.run, se.stream, a.steps, a.warmup, a.min_seconds, barrier, world, a.backend)
 
     total_steps = a.steps * reps
@@ -517,36 +635,73 @@ def main():
             out["config"]["submission"] = (f"queued: ca3d_step({a.steps}) encodes, ca3d_flush submits every {cal * a.steps} steps (the reference's commandEncoder + "
                                            "queue.submit, main_pathtraced.js:1833-1850)" if queue else f"per call: every ca3d_step({a.steps}) is its own submission")
         if world == 1:
-            ceiling = copy_ceiling_gbs()
-            out["roofline"]["copy_ceiling"] = round(ceiling, 1)  # GB/s, measured here: 1 GiB device-to-device copy, read + write
-            out["roofline"]["frac_of_copy_ceiling"] = round(out["roofline"]["achieved"] / ceiling, 4)
+            ceiling = copy_ceiling_gbs(eng)
+            out["copy_ceiling"] = {"value": round(ceiling, 1), "unit": "GB/s",
+                                   "how": "1 GiB float4-per-lane device-to-device copy, non-temporal stores (ca3d_measure_copy), bytes read + bytes written per second, measured in this run"}
         if ok is not None:
             out["oracle_match"] = ok
-        if world == 1 and a.compare_submission and kernel.startswith("ca_resident"):
-            # the same K-step calls under the other submission mode, for the record (same engine, state carried on)
-            q2 = 0 if queue else a.queue
-            g2 = max(1, -(-q2 // a.steps)) if q2 else 1
-            eng.set_option("queue", g2 * a.steps if q2 else 0)
-            dt2, reps2, ev2, _, l2 = timed_region(eng.step, eng.bench_stream, a.steps, 0, a.min_seconds, barrier, 1, "nccl", eng.flush, g2,
-                                                  lambda: eng.info().launches_total)
-            out["other_submission"] = {"submission": "queued" if q2 else "per call", "value": round(cells * a.steps * reps2 / dt2 / 1e9, 3), "unit": "Gcells/s",
-                                       "ms_per_step": round(dt2 * 1e3 / (a.steps * reps2), 6), "reps": reps2,
-                                       "roofline": roofline_block(kernel, G, 0.25 * cells, a.steps * reps2, ev2, state_bytes, l2)}
-        if world == 1 and kernel.startswith("ca_resident") and not a.no_per_step_leg:
-            # the same grid through the per-step kernels (every step reads and writes the state): the fraction of the HBM roofline
-            # in the usual sense, next to the resident kernel's on-chip rate
-            eng.set_option("queue", 0)
-            eng.set_option("resident", 0)
-            eng.set_option("graph_prepare", 256)
-            dt3, reps3, ev3, _, _ = timed_region(eng.step, eng.bench_stream, 256, 64, a.min_seconds, barrier, 1, "nccl")
-            k3 = eng.info().kernel_name.decode()
-            out["per_step_kernels"] = {"value": round(cells * 256 * reps3 / dt3 / 1e9, 3), "unit": "Gcells/s", "ms_per_step": round(dt3 * 1e3 / (256 * reps3), 6),
-                                       "steps": 256, "reps": reps3, "roofline": roofline_block(k3, G, 0.25 * cells, 256 * reps3, ev3, state_bytes)}
-            eng.set_option("resident", a.resident)
+        if verified is not None:
+            out["verified"] = {"oracle_match": verified, "steps": a.verify_steps,
+                               "how": "every rank's slab after this many steps (past one halo exchange) against the CPU oracle's full grid, before the timed region"}
+            if not verified:
+                ok = False
+
+        def per_step_leg(e, Gx, state_b):
+            """The same grid through the per-step kernels (every step reads and writes the state): the fraction of the HBM roofline
+            in the usual sense, next to a resident kernel's on-chip rate."""
+            e.set_option("queue", 0)
+            e.set_option("resident", 0)
+            e.set_option("graph_prepare", 256)
+            dt3, reps3, ev3, _, _ = timed_region(e.step, e.bench_stream, 256, 64, a.min_seconds, barrier, 1, "nccl")
+            k3 = e.info().kernel_name.decode()
+            leg = {"value": round(float(Gx) ** 3 * 256 * reps3 / dt3 / 1e9, 3), "unit": "Gcells/s", "ms_per_step": round(dt3 * 1e3 / (256 * reps3), 6),
+                   "steps": 256, "reps": reps3, "roofline": roofline_block(k3, Gx, 0.25 * float(Gx) ** 3, 256 * reps3, ev3, state_b)}
+            leg["roofline"]["frac_of_copy_ceiling"] = round(leg["roofline"]["achieved"] / ceiling, 4)
+            e.set_option("resident", a.resident)
+            return leg
+
+        def per_call_leg(e, Gx, state_b, K):
+            """Every ca3d_step(K) its own submission (no ca3d_flush batching): what a host that submits K steps per frame gets."""
+            e.set_option("queue", 0)
+            dt2, reps2, ev2, _, l2 = timed_region(e.step, e.bench_stream, K, 0, a.min_seconds / 2, barrier, 1, "nccl", e.flush, 1,
+                                                  lambda: e.info().launches_total)
+            return {"submission": f"per call: every ca3d_step({K}) is its own submission", "value": round(float(Gx) ** 3 * K * reps2 / dt2 / 1e9, 3), "unit": "Gcells/s",
+                    "ms_per_step": round(dt2 * 1e3 / (K * reps2), 6), "steps": K, "reps": reps2,
+                    "roofline": roofline_block(e.info().kernel_name.decode(), Gx, 0.25 * float(Gx) ** 3, K * reps2, ev2, state_b, l2)}
+
+        resident_headline = world == 1 and kernel.startswith("ca_resident")
+        if world == 1 and resident_headline and (a.compare_submission or (queue and not a.no_per_call_leg)):
+            if queue:
+                out["per_call"] = per_call_leg(eng, G, state_bytes, a.steps)
+            if a.compare_submission:
+                # the same K-step calls under the other submission mode, for the record (same engine, state carried on)
+                q2 = 0 if queue else a.queue
+                g2 = max(1, -(-q2 // a.steps)) if q2 else 1
+                eng.set_option("queue", g2 * a.steps if q2 else 0)
+                dt2, reps2, ev2, _, l2 = timed_region(eng.step, eng.bench_stream, a.steps, 0, a.min_seconds, barrier, 1, "nccl", eng.flush, g2,
+                                                      lambda: eng.info().launches_total)
+                out["other_submission"] = {"submission": "queued" if q2 else "per call", "value": round(cells * a.steps * reps2 / dt2 / 1e9, 3), "unit": "Gcells/s",
+                                           "ms_per_step": round(dt2 * 1e3 / (a.steps * reps2), 6), "reps": reps2,
+                                           "roofline": roofline_block(kernel, G, 0.25 * cells, a.steps * reps2, ev2, state_bytes, l2)}
+        if world == 1 and resident_headline and not a.no_per_step_leg:
+            out["per_step_kernels"] = per_step_leg(eng, G, state_bytes)
+        if world == 1 and not resident_headline:
+            out["roofline"]["frac_of_copy_ceiling"] = round(out["roofline"]["achieved"] / ceiling, 4)
         if world == 1 and not a.no_render:
             out["render"] = render_leg(eng, G, a)
             if a.config == 3 and a.render_size == "1920x1080":
-                out["render_4k"] = render_leg(eng, G, a, size="3840x2160", sparse=False)  # BASELINE configs[4]'s frame size
+                out["render_4k"] = render_leg(eng, G, a, size="3840x2160", sparse=False, literal=False)  # BASELINE configs[4]'s frame size
+        if world == 1 and a.config == 3 and G == 512 and not a.no_grid_256:
+            # BASELINE configs[1]'s grid (256^3): the resident kernel's 256^3 form under queued submission, and the per-step kernels
+            eng.close()
+            e1, _, dt1, reps1, ev1, cal1, l1 = single_gpu_leg(local_rank, 256, "default", a.steps, a.warmup, a.min_seconds, 0, a.resident, a.queue if a.submit == "queued" else 0)
+            k1 = e1.info().kernel_name.decode()
+            out["grid_256"] = {"grid": 256, "rule": "default", "value": round(256.0 ** 3 * a.steps * reps1 / dt1 / 1e9, 3), "unit": "Gcells/s",
+                               "ms_per_step": round(dt1 * 1e3 / (a.steps * reps1), 6), "steps": a.steps, "reps": reps1,
+                               "roofline": roofline_block(k1, 256, 0.25 * 256.0 ** 3, a.steps * reps1, ev1, 2 << 20, l1)}
+            if k1.startswith("ca_resident") and not a.no_per_step_leg:
+                out["grid_256"]["per_step_kernels"] = per_step_leg(e1, 256, 2 << 20)
+            eng = e1
         if world == 1 and a.config == 3 and G == 512 and not a.no_scaling_base:
             # the single-GPU point of the multi-GPU curve, on the multi-GPU grid, in the same run (N > 1 runs 1024^3)
             eng.close()
@@ -557,6 +712,7 @@ def main():
                                    "roofline": roofline_block(k2, 1024, 0.25 * 1024.0 ** 3, 256 * reps2, ev2, 128 << 20),
                                    "note": "divide the N > 1 values (config 4: 1024^3) by this, not by the 512^3 headline; "
                                            "`python bench.py --gpus 1 --config 5` gives the base of the 2048^3 clustered curve"}
+            out["scaling_base"]["roofline"]["frac_of_copy_ceiling"] = round(out["scaling_base"]["roofline"]["achieved"] / ceiling, 4)
             e2.close()
         if multi_render is not None:
             out["render"] = multi_render
@@ -564,7 +720,9 @@ def main():
                 ok = False
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(min(G, 512), rule_kw, a.cpu_seconds)
-            out["cpu_baseline_js"] = cpu_baseline_js()
+            out["cpu_baseline_js"] = cpu_baseline_js(G=min(G, 512))  # the JS stepper at G in {256, 512}
+            if G == 512:
+                out["cpu_baseline_js_256"] = cpu_baseline_js(seconds=3.0, G=256)
         print(json.dumps(out), file=json_out, flush=True)
     if world > 1:
         dist.barrier()

@@ -75,6 +75,7 @@ SYMBOLS = [
     ("ca3d_render_target", C.c_int, [_H, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     ("ca3d_synchronize", C.c_int, [_H]),
     ("ca3d_recovered_launches", C.c_int, [_H, C.POINTER(C.c_uint32)]),
+    ("ca3d_measure_copy", C.c_int, [_H, C.c_size_t, C.c_uint32, C.POINTER(C.c_double)]),
     ("ca3d_set_stream", C.c_int, [_H, C.c_void_p]),
     ("ca3d_use_own_stream", C.c_int, [_H]),
     ("ca3d_device_buffer", C.c_int, [_H, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),

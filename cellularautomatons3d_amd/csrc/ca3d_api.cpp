@@ -1345,6 +1345,35 @@ int ca3d_synchronize(ca3d_t *h)
 	return check_resident(h);
 }
 
+int ca3d_measure_copy(ca3d_t *h, size_t n_bytes, uint32_t reps, double *gb_per_s)
+{
+	if (!h || !gb_per_s) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL argument");
+	if (n_bytes < (1u << 20) || n_bytes % 16u || reps == 0 || reps > 4096u) return fail(CA3D_ERR_INVALID_ARGUMENT, "n_bytes must be a multiple of 16 of at least 1 MiB, reps in [1, 4096]");
+	FLUSH_QUEUED(h);
+	int rc = bind_device(h);
+	if (rc) return rc;
+	void *a = nullptr, *b = nullptr;
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	auto cleanup = [&]() { if (a) hipFree(a); if (b) hipFree(b); if (e0) hipEventDestroy(e0); if (e1) hipEventDestroy(e1); };
+#define COPY_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(e_ == hipErrorOutOfMemory ? CA3D_ERR_OUT_OF_MEMORY : CA3D_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); } } while (0)
+	COPY_TRY(hipMalloc(&a, n_bytes));
+	COPY_TRY(hipMalloc(&b, n_bytes));
+	COPY_TRY(hipEventCreate(&e0));
+	COPY_TRY(hipEventCreate(&e1));
+	COPY_TRY(hipMemsetAsync(a, 0x5A, n_bytes, h->stream));
+	COPY_TRY(launch_copy_f4(a, b, n_bytes, h->stream)); // warm: page tables, clocks
+	COPY_TRY(hipEventRecord(e0, h->stream));
+	for (uint32_t i = 0; i < reps; i++) COPY_TRY(launch_copy_f4((i & 1u) ? b : a, (i & 1u) ? a : b, n_bytes, h->stream));
+	COPY_TRY(hipEventRecord(e1, h->stream));
+	COPY_TRY(hipEventSynchronize(e1));
+	float ms = 0.f;
+	COPY_TRY(hipEventElapsedTime(&ms, e0, e1));
+#undef COPY_TRY
+	cleanup();
+	*gb_per_s = ms > 0.f ? 2.0 * (double)n_bytes * reps / (ms * 1e-3) / 1e9 : 0.0; // bytes read + bytes written
+	return CA3D_OK;
+}
+
 int ca3d_recovered_launches(ca3d_t *h, uint32_t *out_count)
 {
 	if (!h || !out_count) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL argument");

@@ -135,6 +135,8 @@ struct RenderLaunch
 	bool trace = false;           // diagnostics: per-wave {start, end, HW_ID, visits} after the counters (the buffer must hold them)
 };
 
+// ca_diag.hip: float4 device-to-device copy (measurement only)
+hipError_t launch_copy_f4(const void *in, void *out, size_t bytes, hipStream_t stream);
 // render.hip
 hipError_t launch_render(const RenderLaunch &l, hipStream_t stream);
 

@@ -180,6 +180,12 @@ class Engine:
         _capi.check(self._lib.ca3d_recovered_launches(self._h, C.byref(n)))
         return int(n.value)
 
+    def measure_copy(self, n_bytes: int = 1 << 30, reps: int = 8) -> float:
+        """GB/s (read + written) of a float4 device-to-device copy on the engine's stream: the practical HBM ceiling."""
+        v = C.c_double()
+        _capi.check(self._lib.ca3d_measure_copy(self._h, n_bytes, reps, C.byref(v)))
+        return float(v.value)
+
     def set_stream(self, hip_stream: int) -> None:
         """Run on a caller-owned hipStream_t; 0 is HIP's legacy default stream."""
         _capi.check(self._lib.ca3d_set_stream(self._h, C.c_void_p(int(hip_stream))))

@@ -242,6 +242,11 @@ int ca3d_get_stats(ca3d_t *h, ca3d_stats *out);
 int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t height, uint32_t spp,
                 uint8_t *presentation_rgba8, uint16_t *light_rgba16f, uint16_t *depth_rg16f);
 
+/* Measurement helper (no reference counterpart; SURVEY 8(d) "also report against a measured device-to-device copy
+ * ceiling"): `reps` float4-per-lane copies of n_bytes between two scratch buffers on the engine's stream, HIP events
+ * around them; *gb_per_s = bytes read + bytes written per second / 1e9. Waits for the GPU. */
+int ca3d_measure_copy(ca3d_t *h, size_t n_bytes, uint32_t reps, double *gb_per_s);
+
 typedef struct ca3d_render_stats
 {
 	double gpu_ms;          /* hipEvent time of the last ca3d_render kernel */

@@ -8,8 +8,8 @@ from ._capi import (LAYOUT_PACKED32, LAYOUT_UNPACKED, SLAB_PHASE_ALL, SLAB_PHASE
 
 
 def __getattr__(name):
-    if name == "Engine":
-        from .engine import Engine
+    if name in ("Engine", "EngineGroup"):
+        from . import engine
 
-        return Engine
+        return getattr(engine, name)
     raise AttributeError(name)

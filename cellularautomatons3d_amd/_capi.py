@@ -72,6 +72,18 @@ SYMBOLS = [
     ("ca3d_slab_run", C.c_int, [_H, C.c_uint32, C.c_int]),
     ("ca3d_slab_exchange", C.c_int, [_H]),
     ("ca3d_slab_gather", C.c_int, [_H, _H]),
+    ("ca3d_group_create", C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(_H)]),
+    ("ca3d_group_destroy", C.c_int, [_H]),
+    ("ca3d_group_size", C.c_int, [_H, C.POINTER(C.c_int)]),
+    ("ca3d_group_engine", C.c_int, [_H, C.c_int, C.POINTER(_H)]),
+    ("ca3d_group_configure", C.c_int, [_H, C.c_uint32, C.c_int, C.c_uint32]),
+    ("ca3d_group_set_rules", C.c_int, [_H, _i32p, C.c_uint32, _i32p, C.c_uint32, _i32p, C.c_uint32, _u32p, _u32p]),
+    ("ca3d_group_upload_state", C.c_int, [_H, _u32p, C.c_size_t]),
+    ("ca3d_group_read_state", C.c_int, [_H, _u32p, C.c_size_t]),
+    ("ca3d_group_step", C.c_int, [_H, C.c_uint32]),
+    ("ca3d_group_synchronize", C.c_int, [_H]),
+    ("ca3d_group_set_option", C.c_int, [_H, C.c_char_p, C.c_int64]),
+    ("ca3d_group_render", C.c_int, [_H, C.POINTER(C.c_float), C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("ca3d_render_target", C.c_int, [_H, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     ("ca3d_synchronize", C.c_int, [_H]),
     ("ca3d_recovered_launches", C.c_int, [_H, C.POINTER(C.c_uint32)]),

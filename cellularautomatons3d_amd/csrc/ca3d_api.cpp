@@ -41,6 +41,21 @@ int fail(int code, const char *fmt, ...)
 
 } // namespace
 
+namespace ca3d
+{
+// for the other translation units of the library (ca3d_group.cpp): same message slot as every entry point here
+int set_error(int code, const char *fmt, ...)
+{
+	char buf[512];
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(buf, sizeof buf, fmt, ap);
+	va_end(ap);
+	g_last_error = buf;
+	return code;
+}
+} // namespace ca3d
+
 struct ca3d_engine
 {
 	int device = 0;
@@ -1782,3 +1797,54 @@ int ca3d_set_option(ca3d_t *h, const char *name, int64_t value)
 }
 
 } // extern "C"
+
+// ------------------------------------------------------------------------------------------------ internals for ca3d_group.cpp
+namespace ca3d
+{
+int engine_device(const ca3d_engine *h) { return h->device; }
+hipStream_t engine_stream(const ca3d_engine *h) { return h->stream; }
+void engine_set_ghosts_valid(ca3d_engine *h, bool valid) { h->ghosts_valid = valid; }
+bool engine_ghosts_valid(const ca3d_engine *h) { return h->ghosts_valid; }
+
+// One communicator per slab engine, all created by THIS process (ncclCommInitAll: one host thread, n devices) — the
+// single-process form of ca3d_slab_comm_init. RCCL refuses two ranks on one device.
+int engines_rccl_init_all(ca3d_engine **engines, int n)
+{
+	Rccl &r = rccl();
+	if (!r.error.empty()) return fail(CA3D_ERR_UNSUPPORTED, "%s", r.error.c_str());
+	typedef int (*InitAll)(void **, int, const int *);
+	InitAll init_all = (InitAll)dlsym(r.lib, "ncclCommInitAll");
+	if (!init_all) return fail(CA3D_ERR_UNSUPPORTED, "librccl lacks ncclCommInitAll");
+	std::vector<void *> comms((size_t)n, nullptr);
+	std::vector<int> devs((size_t)n);
+	for (int k = 0; k < n; k++) devs[(size_t)k] = engines[k]->device;
+	NCCL_TRY(init_all(comms.data(), n, devs.data()));
+	for (int k = 0; k < n; k++)
+	{
+		ca3d_engine *h = engines[k];
+		if (h->comm) r.CommDestroy(h->comm);
+		h->comm = comms[(size_t)k];
+		h->comm_rank = k;
+		h->comm_world = n;
+		h->ghosts_valid = false;
+	}
+	return CA3D_OK;
+}
+
+// The ghost refresh of every rank as ONE RCCL group (a single thread cannot post rank 0's sends and wait for them before
+// rank 1's receives exist): ncclGroupStart, every rank's sends and receives on its own stream, ncclGroupEnd.
+int engines_rccl_exchange_all(ca3d_engine **engines, int n)
+{
+	Rccl &r = rccl();
+	NCCL_TRY(r.GroupStart());
+	for (int k = 0; k < n; k++)
+	{
+		int rc = bind_device(engines[k]);
+		if (rc == CA3D_OK) rc = comm_exchange(engines[k], engines[k]->stream);
+		if (rc) { r.GroupEnd(); return rc; }
+	}
+	NCCL_TRY(r.GroupEnd());
+	for (int k = 0; k < n; k++) engines[k]->ghosts_valid = true;
+	return CA3D_OK;
+}
+} // namespace ca3d

@@ -200,4 +200,14 @@ int packed_fused_steps(const CanonRules &r, uint32_t G, int variant);
 hipError_t launch_packed_fused(const PackedLaunch &l, hipStream_t stream, const char **kernel_name);
 hipError_t launch_unpacked_step(const UnpackedLaunch &l, hipStream_t stream, const char **kernel_name);
 
+
+// ca3d_api.cpp internals used by ca3d_group.cpp
+int set_error(int code, const char *fmt, ...);
+int engine_device(const ca3d_engine *h);
+hipStream_t engine_stream(const ca3d_engine *h);
+void engine_set_ghosts_valid(ca3d_engine *h, bool valid);
+bool engine_ghosts_valid(const ca3d_engine *h);
+int engines_rccl_init_all(ca3d_engine **engines, int n);
+int engines_rccl_exchange_all(ca3d_engine **engines, int n);
+
 } // namespace ca3d

@@ -247,3 +247,88 @@ class Engine:
         s = Stats()
         _capi.check(self._lib.ca3d_get_stats(self._h, C.byref(s)))
         return s
+
+
+class EngineGroup:
+    """`ca3d_group_*`: one host thread drives the Z-slab split of a grid over several GPUs (or several slabs on one GPU) —
+    the single-process form of `slab.NativeSlabEngine`, and what the JavaScript host binds (js/ca3d.js `EngineGroup`)."""
+
+    def __init__(self, devices: Sequence[int]):
+        self._lib = _capi.load()
+        d = (C.c_int * len(devices))(*[int(x) for x in devices])
+        h = C.c_void_p()
+        _capi.check(self._lib.ca3d_group_create(d, len(devices), C.byref(h)))
+        self._h = h
+        self.devices = list(devices)
+        self.grid_size = 0
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.ca3d_group_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def configure(self, grid_size: int, ghost: int, layout: int = _capi.LAYOUT_PACKED32) -> None:
+        _capi.check(self._lib.ca3d_group_configure(self._h, grid_size, layout, ghost))
+        self.grid_size = grid_size
+
+    def set_rules(self, main_offsets, edges_offsets, corners_offsets, survive, born) -> None:
+        m, e, c = _as_i32(main_offsets), _as_i32(edges_offsets), _as_i32(corners_offsets)
+        s, b = _as_u32(survive), _as_u32(born)
+        _capi.check(self._lib.ca3d_group_set_rules(self._h, m.ctypes.data_as(_i32p), m.size, e.ctypes.data_as(_i32p), e.size,
+                                                   c.ctypes.data_as(_i32p), c.size, s.ctypes.data_as(_u32p), b.ctypes.data_as(_u32p)))
+
+    def set_rule_strings(self, neighbourhood: str = host.DEFAULTS["neighbourhood"], born: str = host.DEFAULTS["bornRulesString"],
+                         survive: str = host.DEFAULTS["surviveRulesString"], born_edges: str = "27", survive_edges: str = "27",
+                         born_corners: str = "27", survive_corners: str = "27") -> None:
+        b, s = host.recalculate_rules_values(born, survive, born_edges, survive_edges, born_corners, survive_corners)
+        self.set_rules(host.NEIGHBOURHOOD_MAP[neighbourhood], host.NEIGHBOURHOOD_MAP["edges"], host.NEIGHBOURHOOD_MAP["corners"], s, b)
+
+    def upload_state(self, words) -> None:
+        w = _as_u32(words).ravel()
+        _capi.check(self._lib.ca3d_group_upload_state(self._h, w.ctypes.data_as(_u32p), w.size))
+        self._words = w.size
+
+    def read_state(self) -> np.ndarray:
+        out = np.empty(self._words, dtype=np.uint32)
+        _capi.check(self._lib.ca3d_group_read_state(self._h, out.ctypes.data_as(_u32p), out.size))
+        return out
+
+    def step(self, n_steps: int = 1) -> None:
+        _capi.check(self._lib.ca3d_group_step(self._h, n_steps))
+
+    def synchronize(self) -> None:
+        _capi.check(self._lib.ca3d_group_synchronize(self._h))
+
+    def set_option(self, name: str, value: int) -> None:
+        _capi.check(self._lib.ca3d_group_set_option(self._h, name.encode(), int(value)))
+
+    def kernel_name(self, rank: int = 0) -> str:
+        e = C.c_void_p()
+        _capi.check(self._lib.ca3d_group_engine(self._h, rank, C.byref(e)))
+        i = Info()
+        _capi.check(self._lib.ca3d_get_info(e, C.byref(i)))
+        return i.kernel_name.decode()
+
+    def render(self, uniforms, width: int, height: int, spp: int = 1, readback: bool = True):
+        u = np.ascontiguousarray(uniforms, dtype=np.float32)
+        up = u.ctypes.data_as(C.POINTER(C.c_float))
+        if not readback:
+            _capi.check(self._lib.ca3d_group_render(self._h, up, width, height, spp, None, None, None))
+            return None
+        pres = np.empty((height, width, 4), dtype=np.uint8)
+        light = np.empty((height, width, 4), dtype=np.float16)
+        depth = np.empty((height, width, 2), dtype=np.float16)
+        _capi.check(self._lib.ca3d_group_render(self._h, up, width, height, spp, pres.ctypes.data, light.ctypes.data, depth.ctypes.data))
+        return pres, light, depth

@@ -593,6 +593,227 @@ static napi_value js_synchronize_async(napi_env env, napi_callback_info info)
 	return job_start(env, j, "ca3d.synchronize");
 }
 
+/* ---- ca3d_group_*: one JS thread drives the Z-slab split over several GPUs (include/ca3d.h) ---------------------------- */
+typedef struct
+{
+	ca3d_group_t *g;
+} GroupSlot;
+
+static void finalize_group(napi_env env, void *data, void *hint)
+{
+	(void)env;
+	(void)hint;
+	GroupSlot *slot = (GroupSlot *)data;
+	if (slot->g) ca3d_group_destroy(slot->g);
+	free(slot);
+}
+
+static ca3d_group_t *get_group(napi_env env, napi_value v)
+{
+	void *p = NULL;
+	if (napi_get_value_external(env, v, &p) != napi_ok || !p || !((GroupSlot *)p)->g)
+	{
+		napi_throw_type_error(env, NULL, "expected an engine-group handle");
+		return NULL;
+	}
+	return ((GroupSlot *)p)->g;
+}
+
+static napi_value js_group_create(napi_env env, napi_callback_info info)
+{
+	napi_value argv[1];
+	if (!get_args(env, info, 1, argv)) return NULL;
+	void *d;
+	size_t n;
+	if (!get_typed(env, argv[0], napi_int32_array, 0, &d, &n)) return NULL;
+	ca3d_group_t *g = NULL;
+	int rc = ca3d_group_create((const int *)d, (int)n, &g);
+	if (rc) return throw_ca3d(env, rc);
+	GroupSlot *slot = (GroupSlot *)calloc(1, sizeof *slot);
+	if (!slot) { ca3d_group_destroy(g); napi_throw_error(env, NULL, "out of memory"); return NULL; }
+	slot->g = g;
+	napi_value ext;
+	NAPI_OK_OR_NULL(napi_create_external(env, slot, finalize_group, NULL, &ext));
+	return ext;
+}
+
+static napi_value js_group_destroy(napi_env env, napi_callback_info info)
+{
+	napi_value argv[1];
+	if (!get_args(env, info, 1, argv)) return NULL;
+	void *p = NULL;
+	if (napi_get_value_external(env, argv[0], &p) == napi_ok && p)
+	{
+		GroupSlot *slot = (GroupSlot *)p;
+		if (slot->g) ca3d_group_destroy(slot->g);
+		slot->g = NULL;
+	}
+	return undefined(env);
+}
+
+static napi_value js_group_configure(napi_env env, napi_callback_info info)
+{
+	napi_value argv[4];
+	if (!get_args(env, info, 4, argv)) return NULL;
+	ca3d_group_t *g = get_group(env, argv[0]);
+	uint32_t grid, layout, ghost;
+	if (!g || !get_u32(env, argv[1], &grid) || !get_u32(env, argv[2], &layout) || !get_u32(env, argv[3], &ghost)) return NULL;
+	int rc = ca3d_group_configure(g, grid, (int)layout, ghost);
+	return rc ? throw_ca3d(env, rc) : undefined(env);
+}
+
+static napi_value js_group_set_rules(napi_env env, napi_callback_info info)
+{
+	napi_value argv[6];
+	if (!get_args(env, info, 6, argv)) return NULL;
+	ca3d_group_t *g = get_group(env, argv[0]);
+	if (!g) return NULL;
+	void *m, *e, *c, *s, *b;
+	size_t nm, ne, nc, ns, nb;
+	if (!get_typed(env, argv[1], napi_int32_array, 0, &m, &nm) || !get_typed(env, argv[2], napi_int32_array, 0, &e, &ne) ||
+	    !get_typed(env, argv[3], napi_int32_array, 0, &c, &nc) || !get_typed(env, argv[4], napi_uint32_array, 0, &s, &ns) ||
+	    !get_typed(env, argv[5], napi_uint32_array, 0, &b, &nb))
+		return NULL;
+	if (ns != CA3D_LUT_LEN || nb != CA3D_LUT_LEN)
+	{
+		napi_throw_range_error(env, NULL, "survive/born must be Uint32Array(81)");
+		return NULL;
+	}
+	int rc = ca3d_group_set_rules(g, (const int32_t *)m, (uint32_t)nm, (const int32_t *)e, (uint32_t)ne, (const int32_t *)c, (uint32_t)nc,
+	                              (const uint32_t *)s, (const uint32_t *)b);
+	return rc ? throw_ca3d(env, rc) : undefined(env);
+}
+
+static napi_value js_group_upload_state(napi_env env, napi_callback_info info)
+{
+	napi_value argv[2];
+	if (!get_args(env, info, 2, argv)) return NULL;
+	ca3d_group_t *g = get_group(env, argv[0]);
+	void *w;
+	size_t n;
+	if (!g || !get_typed(env, argv[1], napi_uint32_array, 0, &w, &n)) return NULL;
+	int rc = ca3d_group_upload_state(g, (const uint32_t *)w, n);
+	return rc ? throw_ca3d(env, rc) : undefined(env);
+}
+
+static napi_value js_group_read_state(napi_env env, napi_callback_info info)
+{
+	napi_value argv[2];
+	if (!get_args(env, info, 2, argv)) return NULL;
+	ca3d_group_t *g = get_group(env, argv[0]);
+	void *w;
+	size_t n;
+	if (!g || !get_typed(env, argv[1], napi_uint32_array, 0, &w, &n)) return NULL;
+	int rc = ca3d_group_read_state(g, (uint32_t *)w, n);
+	return rc ? throw_ca3d(env, rc) : undefined(env);
+}
+
+static napi_value js_group_step(napi_env env, napi_callback_info info)
+{
+	napi_value argv[2];
+	if (!get_args(env, info, 2, argv)) return NULL;
+	ca3d_group_t *g = get_group(env, argv[0]);
+	uint32_t n;
+	if (!g || !get_u32(env, argv[1], &n)) return NULL;
+	int rc = ca3d_group_step(g, n);
+	return rc ? throw_ca3d(env, rc) : undefined(env);
+}
+
+static napi_value js_group_synchronize(napi_env env, napi_callback_info info)
+{
+	napi_value argv[1];
+	if (!get_args(env, info, 1, argv)) return NULL;
+	ca3d_group_t *g = get_group(env, argv[0]);
+	if (!g) return NULL;
+	int rc = ca3d_group_synchronize(g);
+	return rc ? throw_ca3d(env, rc) : undefined(env);
+}
+
+static napi_value js_group_set_option(napi_env env, napi_callback_info info)
+{
+	napi_value argv[3];
+	if (!get_args(env, info, 3, argv)) return NULL;
+	ca3d_group_t *g = get_group(env, argv[0]);
+	if (!g) return NULL;
+	char name[64];
+	size_t len = 0;
+	int64_t value = 0;
+	if (napi_get_value_string_utf8(env, argv[1], name, sizeof name, &len) != napi_ok || napi_get_value_int64(env, argv[2], &value) != napi_ok)
+	{
+		napi_throw_type_error(env, NULL, "expected (group, name, integer)");
+		return NULL;
+	}
+	int rc = ca3d_group_set_option(g, name, value);
+	return rc ? throw_ca3d(env, rc) : undefined(env);
+}
+
+/* info of rank's slab engine (kernel name, planes, step ...) */
+static napi_value js_group_info(napi_env env, napi_callback_info info)
+{
+	napi_value argv[2];
+	if (!get_args(env, info, 2, argv)) return NULL;
+	ca3d_group_t *g = get_group(env, argv[0]);
+	uint32_t rank;
+	if (!g || !get_u32(env, argv[1], &rank)) return NULL;
+	ca3d_t *e = NULL;
+	int rc = ca3d_group_engine(g, (int)rank, &e);
+	ca3d_info i;
+	if (rc == 0) rc = ca3d_get_info(e, &i);
+	if (rc) return throw_ca3d(env, rc);
+	int n = 0;
+	ca3d_group_size(g, &n);
+	napi_value o, s;
+	napi_create_object(env, &o);
+	set_num(env, o, "ranks", n);
+	set_num(env, o, "gridSize", i.grid_size);
+	set_num(env, o, "z0", i.z0);
+	set_num(env, o, "nz", i.nz);
+	set_num(env, o, "ghost", i.ghost);
+	set_num(env, o, "step", (double)i.step);
+	set_num(env, o, "device", i.device);
+	set_num(env, o, "launchesTotal", (double)i.launches_total);
+	napi_create_string_utf8(env, i.kernel_name, NAPI_AUTO_LENGTH, &s);
+	napi_set_named_property(env, o, "kernelName", s);
+	return o;
+}
+
+static napi_value js_group_render(napi_env env, napi_callback_info info)
+{
+	napi_value argv[8];
+	if (!get_args(env, info, 8, argv)) return NULL;
+	ca3d_group_t *g = get_group(env, argv[0]);
+	if (!g) return NULL;
+	void *u, *pres, *light, *depth;
+	size_t nu, npres, nlight, ndepth;
+	uint32_t w, hh, spp;
+	if (!get_typed(env, argv[1], napi_float32_array, 0, &u, &nu) || !get_u32(env, argv[2], &w) || !get_u32(env, argv[3], &hh) ||
+	    !get_u32(env, argv[4], &spp) || !get_typed(env, argv[5], napi_uint8_array, 1, &pres, &npres) ||
+	    !get_typed(env, argv[6], napi_uint16_array, 1, &light, &nlight) || !get_typed(env, argv[7], napi_uint16_array, 1, &depth, &ndepth))
+		return NULL;
+	const size_t px = (size_t)w * hh;
+	if (nu != 128 || (pres && npres != px * 4) || (light && nlight != px * 4) || (depth && ndepth != px * 2))
+	{
+		napi_throw_range_error(env, NULL, "uniforms must be Float32Array(128); targets must match width*height");
+		return NULL;
+	}
+	int rc = ca3d_group_render(g, (const float *)u, w, hh, spp, (uint8_t *)pres, (uint16_t *)light, (uint16_t *)depth);
+	return rc ? throw_ca3d(env, rc) : undefined(env);
+}
+
+static napi_value js_recovered_launches(napi_env env, napi_callback_info info)
+{
+	napi_value argv[1];
+	if (!get_args(env, info, 1, argv)) return NULL;
+	ca3d_t *h = get_handle(env, argv[0]);
+	if (!h) return NULL;
+	uint32_t n = 0;
+	int rc = ca3d_recovered_launches(h, &n);
+	if (rc) return throw_ca3d(env, rc);
+	napi_value v;
+	napi_create_uint32(env, n, &v);
+	return v;
+}
+
 static napi_value js_abi_version(napi_env env, napi_callback_info info)
 {
 	(void)info;
@@ -611,6 +832,10 @@ static napi_value init(napi_env env, napi_value exports)
 	    {"renderStats", js_render_stats}, {"setOption", js_set_option},
 	    {"commUniqueId", js_comm_unique_id}, {"slabCommInit", js_slab_comm_init}, {"slabRun", js_slab_run}, {"slabExchange", js_slab_exchange},
 	    {"slabGather", js_slab_gather},
+	    {"recoveredLaunches", js_recovered_launches},
+	    {"groupCreate", js_group_create}, {"groupDestroy", js_group_destroy}, {"groupConfigure", js_group_configure}, {"groupSetRules", js_group_set_rules},
+	    {"groupUploadState", js_group_upload_state}, {"groupReadState", js_group_read_state}, {"groupStep", js_group_step},
+	    {"groupSynchronize", js_group_synchronize}, {"groupSetOption", js_group_set_option}, {"groupInfo", js_group_info}, {"groupRender", js_group_render},
 	    {"readStateAsync", js_read_state_async}, {"renderAsync", js_render_async}, {"synchronizeAsync", js_synchronize_async}};
 	for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++)
 	{

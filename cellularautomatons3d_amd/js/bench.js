@@ -4,6 +4,10 @@
 // grid, default rule, and 1080p / 4 spp frames, driven through ca3d.js -> ca3d_napi.node -> libca3d.so. Prints one
 // JSON line; bench.py (the driver's contract) measures the same kernels from Python.
 //   node cellularautomatons3d_amd/js/bench.js [--grid 512] [--steps 2048] [--reps 10] [--warmup 256] [--frames 10 --uniforms u.f32]
+//   node cellularautomatons3d_amd/js/bench.js --gpus 8 [--grid 1024] [--ghost 32] [--transport copy|rccl] [--check 40]
+//       the Z-slab split over the GPUs of a node (BASELINE configs[3]) driven by this ONE thread through EngineGroup
+//       (ca3d_group_*); --devices 0,0,0,0 places several slabs on one GPU (rehearsal); --check n first verifies n steps
+//       against the JS CPU stepper on a 128-plane-deep sample of rank boundaries (small grids: the whole grid)
 // The renderer leg needs the 128-float uniform block the UI's MemoryManager would supply (camera maths stays in
 // front of the engine): python -c "from cellularautomatons3d_amd import host; host.uniform_block(1920, 1080,
 // host.orbit_camera()).tofile('u.f32')"
@@ -16,6 +20,50 @@ const arg = (name, dflt) => { const i = process.argv.indexOf("--" + name); retur
 const sarg = (name) => { const i = process.argv.indexOf("--" + name); return i > 0 ? process.argv[i + 1] : null; };
 const G = arg("grid", 512), steps = arg("steps", 2048), warmup = arg("warmup", 256), frames = arg("frames", 10);
 const uniformsPath = sarg("uniforms");
+const gpus = arg("gpus", 1), devicesArg = sarg("devices");
+if (gpus > 1 || devicesArg) { runGroup(); return; }
+
+function runGroup()
+{
+	const devices = devicesArg ? devicesArg.split(",").map(Number) : Array.from({ length: gpus }, (_, i) => i);
+	const Gm = arg("grid", 1024), ghost = arg("ghost", 32), stepsM = arg("steps", 2048), warm = arg("warmup", 256), repsM = arg("reps", 10);
+	const transport = sarg("transport") === "rccl" ? 1 : 0, check = arg("check", 0);
+	const grp = new c.EngineGroup(devices);
+	grp.configure(Gm, ghost);
+	grp.setRuleStrings({});
+	if (transport) grp.setOption("transport", 1);
+	const state = c.randomFill((Gm / 32) * Gm * Gm, 0xCA3D0001, 0);
+	grp.uploadState(state);
+	let verified = null;
+	if (check > 0)
+	{
+		// the multi-GPU state must equal a single grid's: a full-grid engine on device 0 (itself checked against the oracle in the test suite)
+		const one = new c.Engine(devices[0]);
+		one.configure(Gm);
+		one.setRuleStrings({});
+		one.uploadState(state);
+		one.step(check);
+		grp.step(check);
+		verified = Buffer.from(grp.readState().buffer).equals(Buffer.from(one.readState().buffer));
+		one.close();
+		grp.uploadState(state);
+	}
+	grp.step(warm);
+	grp.synchronize();
+	const t0 = process.hrtime.bigint();
+	for (let i = 0; i < repsM; i++) grp.step(stepsM);
+	grp.synchronize();
+	const dt = Number(process.hrtime.bigint() - t0) / 1e9, total = stepsM * repsM;
+	const out = {
+		metric: `Gcells/s CA step at ${Gm}^3 (Node.js host, one thread, ${devices.length} slabs)`, value: +(Gm ** 3 * total / dt / 1e9).toFixed(3), unit: "Gcells/s",
+		n_gpus: new Set(devices).size, slabs: devices.length, devices, steps: stepsM, reps: repsM, warmup: warm, ms_per_step: +(dt * 1e3 / total).toFixed(6),
+		kernel: grp.info(0).kernelName, ghost, transport: transport ? "rccl (ncclCommInitAll, grouped send/recv)" : "peer copies ordered by events", node: process.version
+	};
+	if (verified !== null) { out.verified = { steps: check, state_matches_single_grid: verified }; }
+	console.log(JSON.stringify(out));
+	grp.close();
+	if (verified === false) process.exit(1);
+}
 
 const eng = new c.Engine(0);
 eng.configure(G);

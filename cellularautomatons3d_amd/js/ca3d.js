@@ -274,10 +274,48 @@ class Engine
 	stats() { this._idle("stats"); return this._a.stats(this._h); }
 	renderStats() { this._idle("renderStats"); return this._a.renderStats(this._h); }
 	setOption(name, value) { this._idle("setOption"); this._a.setOption(this._h, name, value); }
+	/** resident launches that timed out and were re-run through the per-step kernels (include/ca3d.h) */
+	recoveredLaunches() { this._idle("recoveredLaunches"); return this._a.recoveredLaunches(this._h); }
+}
+
+// ca3d_group_*: the Z-slab split of a grid over the GPUs of a node, driven by this one JavaScript thread (the reference's host
+// is one thread that enqueues everything, main_pathtraced.js:1821-1854). `devices`: one GPU index per slab, in z order; the
+// same index may repeat (several slabs on one GPU). Same rule / state / step / render surface as Engine, on the FULL grid.
+class EngineGroup
+{
+	constructor(devices)
+	{
+		this._a = loadAddon();
+		this.devices = Int32Array.from(devices);
+		this._g = this._a.groupCreate(this.devices);
+		this.gridSize = 0;
+	}
+	close() { if (this._g) { this._a.groupDestroy(this._g); this._g = null; } }
+	/** ghost = planes kept of each neighbour = steps between two exchanges */
+	configure(gridSize, ghost, layout) { this._a.groupConfigure(this._g, gridSize, layout || LAYOUT_PACKED32, ghost); this.gridSize = gridSize; }
+	setRules(mainOffsets, edgesOffsets, cornersOffsets, survive, born) { this._a.groupSetRules(this._g, mainOffsets, edgesOffsets, cornersOffsets, survive, born); }
+	setRuleStrings(rules)
+	{
+		const r = Object.assign({}, DEFAULT_RULES, rules || {});
+		const lut = recalculateRulesValues(r);
+		this.setRules(NEIGHBOURHOOD_MAP[r.neighbourhood], NEIGHBOURHOOD_MAP["edges"], NEIGHBOURHOOD_MAP["corners"], lut.survive, lut.born);
+	}
+	uploadState(words) { this._a.groupUploadState(this._g, words); this._words = words.length; }
+	readState() { const out = new Uint32Array(this._words); this._a.groupReadState(this._g, out); return out; }
+	step(n) { this._a.groupStep(this._g, n === undefined ? 1 : n); }
+	synchronize() { this._a.groupSynchronize(this._g); }
+	/** "transport": 0 peer copies (default), 1 RCCL; any other option goes to every slab engine */
+	setOption(name, value) { this._a.groupSetOption(this._g, name, value); }
+	info(rank) { return this._a.groupInfo(this._g, rank || 0); }
+	render(uniforms, width, height, spp, targets)
+	{
+		const t = targets || {};
+		this._a.groupRender(this._g, uniforms, width, height, spp || 1, t.presentation || null, t.light || null, t.depth || null);
+	}
 }
 
 module.exports = {
-	Engine, NEIGHBOURHOOD_MAP, DEFAULT_RULES, LAYOUT_PACKED32, LAYOUT_UNPACKED, NEIGHBOURS_STORAGE_LEN,
+	Engine, EngineGroup, NEIGHBOURHOOD_MAP, DEFAULT_RULES, LAYOUT_PACKED32, LAYOUT_UNPACKED, NEIGHBOURS_STORAGE_LEN,
 	rulesComponentsToValues, recalculateRulesValues, gridSizeUIFormatter, getClusterIdxFromGridCoordinates,
 	initialState, dispatchShape, randomFill, loadAddon, saveCheckpoint, loadCheckpoint
 };

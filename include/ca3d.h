@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define CA3D_ABI_VERSION 3
+#define CA3D_ABI_VERSION 4
 #define CA3D_LUT_LEN 81 /* 3 rule-sets x 27 slots (main_pathtraced.js:10, 155-159) */
 
 typedef struct ca3d_engine ca3d_t;
@@ -162,6 +162,46 @@ int ca3d_slab_comm_init(ca3d_t *h, const void *id_bytes, int rank, int world);
 int ca3d_slab_run(ca3d_t *h, uint32_t n_steps, int overlap);
 int ca3d_slab_exchange(ca3d_t *h);
 int ca3d_slab_gather(ca3d_t *h, ca3d_t *full);
+
+/*
+ * The same split driven by ONE host thread (SURVEY 8(b) sketched `ca3d_create(const int* device_ids, int n_devices, ...)`):
+ * the reference's host is a single JavaScript thread that enqueues everything (main_pathtraced.js:1821-1854), and BASELINE's
+ * north star keeps the host in JavaScript while the grid is Z-slabbed over the GPUs of a node. A group = one slab engine per
+ * entry of the device list, rank k owning planes [k G/n, (k+1) G/n) (a device may be listed more than once: several slabs
+ * on one GPU, which is how the path is tested on one GPU), plus the ghost exchange between them.
+ *   ca3d_group_configure     grid, layout, ghost depth K = steps between exchanges (ca3d_configure_slab on every engine)
+ *   ca3d_group_set_rules     ca3d_set_rules on every engine (payload as there)
+ *   ca3d_group_upload_state  the FULL grid in the reference's layout; each slab takes its planes
+ *   ca3d_group_read_state    the full grid back
+ *   ca3d_group_step          n steps: batches of <= K sub-steps on every device, ghosts refreshed between batches; everything
+ *                            is enqueued by this one call, nothing waits for a GPU
+ *   ca3d_group_render        ca3d_render for the whole grid: every rank gets the full packed volume (peer copies), renders
+ *                            its band of image rows and the bands land in the caller's buffers
+ *   ca3d_group_engine        the slab engine of a rank (for ca3d_get_info, ca3d_get_stats ...); owned by the group
+ *   ca3d_group_set_option    "transport" 0 (default): the ghost planes travel as peer-to-peer device copies over xGMI on the
+ *                            receiving engine's stream, ordered by events; 1: ncclSend / ncclRecv on communicators from
+ *                            ncclCommInitAll, one ncclGroupStart / End per exchange (one device per slab). Every other name
+ *                            goes to ca3d_set_option of every engine.
+ * Packed grids: the chain is open at the bottom and closed at the top; unpacked: a ring (as ca3d_slab_comm_init).
+ */
+typedef struct ca3d_group ca3d_group_t;
+int ca3d_group_create(const int *device_ids, int n_devices, ca3d_group_t **out);
+int ca3d_group_destroy(ca3d_group_t *g);
+int ca3d_group_size(ca3d_group_t *g, int *out_n);
+int ca3d_group_engine(ca3d_group_t *g, int rank, ca3d_t **out);
+int ca3d_group_configure(ca3d_group_t *g, uint32_t grid_size, int layout, uint32_t ghost);
+int ca3d_group_set_rules(ca3d_group_t *g,
+                         const int32_t *main_offsets, uint32_t n_main,
+                         const int32_t *edges_offsets, uint32_t n_edges,
+                         const int32_t *corners_offsets, uint32_t n_corners,
+                         const uint32_t survive[CA3D_LUT_LEN], const uint32_t born[CA3D_LUT_LEN]);
+int ca3d_group_upload_state(ca3d_group_t *g, const uint32_t *words, size_t n_words);
+int ca3d_group_read_state(ca3d_group_t *g, uint32_t *words, size_t n_words);
+int ca3d_group_step(ca3d_group_t *g, uint32_t n_steps);
+int ca3d_group_synchronize(ca3d_group_t *g);
+int ca3d_group_set_option(ca3d_group_t *g, const char *name, int64_t value);
+int ca3d_group_render(ca3d_group_t *g, const float uniforms[128], uint32_t width, uint32_t height, uint32_t spp,
+                      uint8_t *presentation_rgba8, uint16_t *light_rgba16f, uint16_t *depth_rg16f);
 
 /* Device pointer + byte size of the targets of the last ca3d_render call: 0 presentation RGBA8, 1 light RGBA16F,
  * 2 depth RG16F (row-major, top row first) — e.g. to gather the bands of a frame shared between GPUs without a

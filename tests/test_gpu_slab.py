@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as ol
-from cellularautomatons3d_amd import LAYOUT_PACKED32, LAYOUT_UNPACKED, host, slab
+from cellularautomatons3d_amd import LAYOUT_PACKED32, LAYOUT_UNPACKED, Ca3dError, host, slab
 from gpu_common import rules, set_rules
 
 pytestmark = pytest.mark.gpu
@@ -395,3 +395,86 @@ def test_bench_plain_invocation_spawns_its_ranks():
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["oracle_match"] is True and d["reps"] == 1 and d["config"]["grid"] == 256
+
+
+@pytest.mark.parametrize("name,G,P,K,steps", [("default", 256, 4, 8, (8, 13, 3)), ("clustered", 256, 8, 4, (9, 4)), ("default", 1024, 8, 16, (33,)),
+                                              ("life2d", 128, 2, 5, (11,))])
+def test_engine_group_single_thread_split(name, G, P, K, steps):
+    """`ca3d_group_*` (SURVEY 8(b)'s `ca3d_create(device_ids, n_devices, ...)`): ONE host thread drives P slab engines — here all on
+    GPU 0, ghost planes as device copies ordered by events — through batches of <= K sub-steps; the full-grid state equals the
+    oracle's after every call. 1024^3 over 8 slabs of 128 + 2 x 16 planes is BASELINE configs[3]'s split (the resident slab
+    kernel runs the batches)."""
+    from cellularautomatons3d_amd import EngineGroup
+
+    rr = rules(name)
+    st = host.random_fill(host.words_per_buffer(G), seed=777, and_rounds=1)
+    with EngineGroup([0] * P) as g:
+        g.configure(G, K)
+        g.set_rules(rr.main, rr.edges, rr.corners, rr.survive, rr.born)
+        g.upload_state(st)
+        want = st
+        for n in steps:
+            g.step(n)
+            want = ol.packed_run(G, want, rr, n)
+            np.testing.assert_array_equal(g.read_state(), want, err_msg=f"after {n} more steps")
+        if G == 1024:
+            assert g.kernel_name(3).startswith("ca_resident_slab"), g.kernel_name(3)
+
+
+def test_engine_group_unpacked_ring_and_rccl_transport():
+    """The legacy layout is a true ring (both ghosts of every rank are filled); the RCCL transport of a group — communicators
+    from ncclCommInitAll, every exchange one ncclGroupStart / End — with the one rank a single GPU allows."""
+    from cellularautomatons3d_amd import EngineGroup, LAYOUT_UNPACKED
+
+    G, P, K = 64, 4, 3
+    rr = rules("default")
+    cells = (host.random_fill(G * G * G // 32, seed=5).view(np.uint8)[:, None] >> np.arange(8, dtype=np.uint8) & 1).reshape(-1).astype(np.uint32)
+    with EngineGroup([0] * P) as g:
+        g.configure(G, K, LAYOUT_UNPACKED)
+        g.set_rules(rr.main, rr.edges, rr.corners, rr.survive, rr.born)
+        g.upload_state(cells)
+        g.step(7)
+        want = cells
+        for _ in range(7):
+            want = ol.unpacked_step(G, want, rr.main, rr.survive, rr.born)
+        np.testing.assert_array_equal(g.read_state(), want)
+    G = 256
+    st = host.random_fill(host.words_per_buffer(G), seed=778)
+    with EngineGroup([0]) as g:
+        g.configure(G, 8)
+        g.set_rules(rr.main, rr.edges, rr.corners, rr.survive, rr.born)
+        g.set_option("transport", 1)
+        g.upload_state(st)
+        g.step(19)
+        np.testing.assert_array_equal(g.read_state(), ol.packed_run(G, st, rr, 19))
+    with EngineGroup([0, 0]) as g, pytest.raises(Ca3dError, match="one device per slab"):
+        g.set_option("transport", 1)
+
+
+def test_engine_group_renders_the_frame_in_bands():
+    """ca3d_group_render: the full volume gathered to every rank, each renders its band of image rows — bit-identical to one
+    engine's frame."""
+    from cellularautomatons3d_amd import Engine, EngineGroup
+
+    G, P = 256, 4
+    rr = rules("default")
+    st = host.random_fill(host.words_per_buffer(G), seed=779, and_rounds=4)
+    W, H = 640, 360
+    u = host.uniform_block(W, H, host.orbit_camera())
+    with EngineGroup([0] * P) as g, Engine(0) as e:
+        g.configure(G, 4)
+        g.set_rules(rr.main, rr.edges, rr.corners, rr.survive, rr.born)
+        g.upload_state(st)
+        g.step(6)
+        e.configure(G)
+        e.set_rules(rr.main, rr.edges, rr.corners, rr.survive, rr.born)
+        e.upload_state(st)
+        e.step(6)
+        a = g.render(u, W, H, 4)
+        b = e.render(u, W, H, 4)
+        for x, y, what in zip(a, b, ("presentation", "light", "depth")):
+            np.testing.assert_array_equal(x.view(np.uint8), y.view(np.uint8), err_msg=what)
+        assert a[0][..., :3].any()
+        g.step(3)  # stepping goes on after a frame (the gather and the next batch are ordered)
+        e.step(3)
+        np.testing.assert_array_equal(g.read_state(), e.read_state())

@@ -57,6 +57,18 @@ def test_js_engine_on_gpu(tmp_path):
     assert ok.mean() >= 0.999
 
 
+@pytest.mark.gpu
+def test_js_engine_group_drives_the_slab_split_from_one_thread(tmp_path):
+    """north_star: "host code stays JavaScript" + "Z-slabs across the 8 GPUs": EngineGroup (ca3d_group_*) from Node.js, 2 / 4 / 8
+    slabs on GPU 0 over the peer-copy transport and one slab over RCCL (ncclCommInitAll + grouped exchange), states and a
+    banded frame identical to one full-grid engine's."""
+    from cellularautomatons3d_amd import host
+
+    host.uniform_block(320, 176, host.orbit_camera()).tofile(tmp_path / "uniforms.f32")
+    r = _node("tests/js/group_gpu_check.js", str(tmp_path), timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout + r.stderr)[-3000:]
+
+
 def test_facade_runs_the_unmodified_reference_host_with_a_mock_engine():
     """SURVEY 8(f) N2 (build container only): main_pathtraced.js + ui.js + MemoryManager.js, unmodified, drive the
     navigator.gpu facade through init and five frames; a recording mock stands in for the engine."""

@@ -98,6 +98,7 @@ struct ca3d_engine
 	std::map<uint64_t, hipGraphExec_t> slab_graphs; // (phase, start buffer, sub-steps) -> captured slab batch
 	uint32_t pending_edges = 0;                     // sub-steps of an edge phase awaiting its interior phase
 	int roll_z = 0;       // forced planes per thread of the rolling-window kernel (0: automatic)
+	int roll_tile = 1;    // tile form of the rolling-window kernel (x-shifted rows shared through LDS)
 	int use_roll = 1;     // rolling-window form of the class kernels where it applies (needs use_jit)
 	int use_jit = 1;      // specialise kernels for the rule at run time (hiprtc) where a specialisation exists
 	VnJit vn_jit;         // valid when vn_jit.cvl >= 0
@@ -270,7 +271,7 @@ int enqueue_step(ca3d_engine *h, int src, uint32_t lo, uint32_t hi, hipStream_t 
 	{
 		pr.lo2 = lo2;
 		pr.hi2 = hi2;
-		PackedLaunch l{h->buf[src], h->buf[src ^ 1], pr, &h->rules, h->variant, h->vn_jit.cvl >= 0 ? &h->vn_jit : nullptr, h->class_jit.main >= 0 ? &h->class_jit : nullptr, h->roll_jit.cvl >= 0 ? &h->roll_jit : nullptr, h->roll_z};
+		PackedLaunch l{h->buf[src], h->buf[src ^ 1], pr, &h->rules, h->variant, h->vn_jit.cvl >= 0 ? &h->vn_jit : nullptr, h->class_jit.main >= 0 ? &h->class_jit : nullptr, h->roll_jit.cvl >= 0 ? &h->roll_jit : nullptr, h->roll_z, h->roll_tile};
 		e = fused ? launch_packed_fused(l, s, &h->kernel_name) : launch_packed_step(l, s, &h->kernel_name);
 	}
 	else
@@ -1772,9 +1773,15 @@ int ca3d_set_option(ca3d_t *h, const char *name, int64_t value)
 	}
 	if (!strcmp(name, "roll_z"))
 	{
-		if (value != 0 && value != 2 && value != 4 && value != 8) return fail(CA3D_ERR_INVALID_ARGUMENT, "roll_z must be 0 (automatic), 2, 4 or 8");
+		if (value != 0 && value != 2 && value != 4 && value != 8 && value != 16) return fail(CA3D_ERR_INVALID_ARGUMENT, "roll_z must be 0 (automatic), 2, 4, 8 or 16 (tile form only)");
 		drop_graph(h);
 		h->roll_z = (int)value;
+		return CA3D_OK;
+	}
+	if (!strcmp(name, "roll_tile"))
+	{
+		drop_graph(h);
+		h->roll_tile = value ? 1 : 0;
 		return CA3D_OK;
 	}
 	if (!strcmp(name, "roll"))

@@ -70,6 +70,7 @@ struct ClassJit
 struct RollJit
 {
 	void *z[3] = {nullptr, nullptr, nullptr}; // hipFunction_t for Z = 2, 4, 8
+	void *tile[4] = {nullptr, nullptr, nullptr, nullptr}; // the tile form (x-shifted rows shared through LDS) for Z = 2, 4, 8, 16
 	int cvl = -1;                              // log2(G / 128); -1: none
 	int main = -1;
 	bool e = false, c = false;
@@ -86,7 +87,8 @@ struct PackedLaunch
 	const VnJit *vn_jit = nullptr; // specialised kernels for exactly these rules and this grid, or null
 	const ClassJit *class_jit = nullptr;
 	const RollJit *roll_jit = nullptr;
-	int roll_z = 0; // 0: the launcher picks the planes per thread of the rolling-window kernel; 2 / 4 / 8: forced (tests, tuning)
+	int roll_z = 0; // 0: the launcher picks the planes per thread of the rolling-window kernel; 2 / 4 / 8 (tile form: 16 too): forced (tests, tuning)
+	int roll_tile = 1; // 1: the tile form of the rolling-window kernel (ca_packed_roll_kernel.inc, tile_step); 0: every thread shifts its three rows itself
 };
 
 // One launch of the resident multi-step kernel (ca_resident.hip): `steps` steps from `in`, state on chip in between

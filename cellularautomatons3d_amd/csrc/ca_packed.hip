@@ -358,21 +358,22 @@ hipError_t launch_class(const PackedLaunch &l, hipStream_t stream)
 		// thread: the largest of 8 / 4 / 2 that the shortest range holds and that still gives every SIMD its two waves
 		// (a wave alone on a SIMD issues at half rate); launches too small for that keep the one-plane kernels below.
 		static const u32 lds_pad = getenv("CA3D_ROLL_LDS") ? (u32)atoi(getenv("CA3D_ROLL_LDS")) : 0u;
-		for (int zi = 2; zi >= 0; zi--)
+		for (int zi = l.roll_tile ? 3 : 2; zi >= 0; zi--)
 		{
 			const u32 Z = 2u << zi;
 			const u32 runs1 = (planes1 + Z - 1u) / Z, nruns = runs1 + (planes2 + Z - 1u) / Z;
-			if (shortest < Z || !rj->z[zi]) continue;
+			void *fn = l.roll_tile ? rj->tile[zi] : rj->z[zi];
+			if (shortest < Z || !fn) continue;
 			// automatic choice: only launches of more than one resident generation (measured at 512^3, 2048 waves: the plain class
-			// kernel 11.5 us, this one 12.0; at 1024^3, 16384 waves: 80 vs 72)
-			if (l.roll_z ? l.roll_z != (int)Z : (size_t)g.tiles_per_plane * nruns * 4u < 4096u) continue;
+			// kernel 11.5 us, the rolling one 12.0; at 1024^3, 16384 waves: 80 vs 72); 16 planes per thread only when asked for
+			if (l.roll_z ? l.roll_z != (int)Z : (Z > 8u || (size_t)g.tiles_per_plane * nruns * 4u < 4096u)) continue;
 			RollArgs a;
 			a.lo = l.pr.lo; a.hi = l.pr.hi; a.nplanes = l.pr.nplanes; a.wrap_full = l.pr.wrap_full; a.zbase = l.pr.zbase;
 			a.lo2 = l.pr.lo2; a.hi2 = two ? l.pr.hi2 : l.pr.lo2; a.runs1 = runs1;
 			const u32 *in = l.in;
 			u32 *out = l.out;
 			void *args[] = {(void *)&in, (void *)&out, (void *)&a};
-			return hipModuleLaunchKernel((hipFunction_t)rj->z[zi], g.tiles_per_plane * nruns, 1, 1, 256, 1, 1, lds_pad, stream, args, nullptr);
+			return hipModuleLaunchKernel((hipFunction_t)fn, g.tiles_per_plane * nruns, 1, 1, 256, 1, 1, l.roll_tile ? 0u : lds_pad, stream, args, nullptr);
 		}
 	}
 	const ClassJit *jit = l.class_jit;

@@ -310,11 +310,16 @@ def test_rolling_window_kernel_every_depth(eng, name):
     assert b"roll" in eng.info().kernel_name, eng.info().kernel_name
     st = host.random_fill(host.words_per_buffer(G), seed=61)
     want = ol.packed_run(G, st, r, 3)
-    for z in (2, 4, 8):
-        eng.set_option("roll_z", z)
-        eng.upload_state(st)
-        eng.step(3)
-        np.testing.assert_array_equal(eng.read_state(), want, err_msg=f"roll_z {z}")
+    # both forms: every thread shifting its three rows itself (roll_tile 0) and the tile form, where a workgroup shares the
+    # x-shifted rows through LDS (16 planes per thread exist in the tile form only)
+    for tile in (1, 0):
+        eng.set_option("roll_tile", tile)
+        for z in (2, 4, 8, 16) if tile else (2, 4, 8):
+            eng.set_option("roll_z", z)
+            eng.upload_state(st)
+            eng.step(3)
+            np.testing.assert_array_equal(eng.read_state(), want, err_msg=f"roll_tile {tile} roll_z {z}")
+    eng.set_option("roll_tile", 1)
     eng.set_option("roll_z", 0)
     eng.set_option("roll", 0)
     assert b"roll" not in eng.info().kernel_name

@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
-"""Per-kernel means of a `rocprofv3 --pmc SQ_...` pass: tools/pmc_sq_reduce.py DIR KERNEL_SUBSTR  -> JSON on stdout.
+"""Per-kernel means of a `rocprofv3 --pmc SQ_...` pass: tools/pmc_sq_reduce.py DIR KERNEL_SUBSTR [STEPS_PER_LAUNCH]  -> JSON on stdout.
+STEPS_PER_LAUNCH (resident multi-step kernels): how many CA steps each profiled launch held; only launches of the most
+common duration class are averaged when given (the run also holds a shorter warm-up launch).
 SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md); ratios between them are unit-free."""
 import csv, glob, json, os, sys, collections
 
 d, kernel = sys.argv[1], sys.argv[2]
+steps_per_launch = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 acc = collections.defaultdict(list)
 vg = []
 for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -15,6 +18,17 @@ for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=T
                     if k in row and row[k] not in ("", None):
                         acc["_" + k].append(float(row[k]))
 out = {"kernel": kernel, "dispatches": max((len(v) for v in acc.values()), default=0)}
+if steps_per_launch:
+    out["steps_per_launch"] = steps_per_launch
+    # keep the launches of full length: SQ_INSTS_VALU within 10 % of the largest value seen (warm-up / calibration launches are shorter)
+    ref = max(acc.get("SQ_INSTS_VALU", [0]))
+    keep = [i for i, x in enumerate(acc.get("SQ_INSTS_VALU", [])) if x >= 0.9 * ref]
+    if keep and len(keep) < len(acc["SQ_INSTS_VALU"]):
+        n = len(acc["SQ_INSTS_VALU"])
+        for k in list(acc):
+            if len(acc[k]) == n:
+                acc[k] = [acc[k][i] for i in keep]
+        out["dispatches_full_length"] = len(keep)
 for k, v in sorted(acc.items()):
     out[k.lstrip("_")] = sum(v) / len(v)
 w = out.get("SQ_WAVES")

@@ -15,12 +15,14 @@ for G in grids:
     e.set_rule_strings("moore", "5-7", "4-7", "4", "3-5", "3", "2-4")
     e.upload_state(host.random_fill(host.words_per_buffer(G)))
     steps = max(16, int(2e-2 / (G ** 3 / 1.2e13)))
-    for roll, z in ((0, 0), (1, 0), (1, 2), (1, 4), (1, 8)):
+    e.set_option("resident", 0)  # the per-step kernels are what is compared here
+    for roll, tile, z in ((0, 0, 0), (1, 0, 0), (1, 0, 4), (1, 0, 8), (1, 1, 0), (1, 1, 2), (1, 1, 4), (1, 1, 8), (1, 1, 16)):
         e.set_option("roll", roll)
+        e.set_option("roll_tile", tile)
         e.set_option("roll_z", z)
         e.step(steps); e.synchronize()
         t0 = time.perf_counter()
         e.step(steps); e.synchronize()
         dt = (time.perf_counter() - t0) / steps
-        print(f"G {G} roll {roll} z {z}: {dt * 1e6:8.2f} us/step  frac {0.25 * G ** 3 / dt / 8e12:.3f}  {e.info().kernel_name.decode()}", flush=True)
+        print(f"G {G} roll {roll} tile {tile} z {z}: {dt * 1e6:8.2f} us/step  frac {0.25 * G ** 3 / dt / 8e12:.3f}  {e.info().kernel_name.decode()}", flush=True)
     e.set_option("roll", 1); e.set_option("roll_z", 0)

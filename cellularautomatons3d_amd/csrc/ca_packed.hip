@@ -365,15 +365,20 @@ hipError_t launch_class(const PackedLaunch &l, hipStream_t stream)
 			void *fn = l.roll_tile ? rj->tile[zi] : rj->z[zi];
 			if (shortest < Z || !fn) continue;
 			// automatic choice: only launches of more than one resident generation (measured at 512^3, 2048 waves: the plain class
-			// kernel 11.5 us, the rolling one 12.0; at 1024^3, 16384 waves: 80 vs 72); 16 planes per thread only when asked for
-			if (l.roll_z ? l.roll_z != (int)Z : (Z > 8u || (size_t)g.tiles_per_plane * nruns * 4u < 4096u)) continue;
+			// kernel 11.5 us, the rolling one 12.0; at 1024^3, 16384 waves: 80 vs 72). The tile form pays at 16 planes per thread
+			// (two halo planes per 16 instead of per 8, and the LDS exchange replaces two of three row shifts: 1024^3 66.3 vs 68.8 us,
+			// 2048^3 535 vs 574); at 8 planes its barrier per plane eats the saving (70.9 vs 68.8): there every thread shifts its own rows
+			const bool tile_form = l.roll_tile && (l.roll_z || Z == 16u); // a forced depth (tests, tuning) takes the form roll_tile names
+			if (!tile_form) fn = Z <= 8u ? rj->z[zi] : nullptr;
+			if (!fn) continue;
+			if (l.roll_z ? l.roll_z != (int)Z : (size_t)g.tiles_per_plane * nruns * 4u < 4096u) continue;
 			RollArgs a;
 			a.lo = l.pr.lo; a.hi = l.pr.hi; a.nplanes = l.pr.nplanes; a.wrap_full = l.pr.wrap_full; a.zbase = l.pr.zbase;
 			a.lo2 = l.pr.lo2; a.hi2 = two ? l.pr.hi2 : l.pr.lo2; a.runs1 = runs1;
 			const u32 *in = l.in;
 			u32 *out = l.out;
 			void *args[] = {(void *)&in, (void *)&out, (void *)&a};
-			return hipModuleLaunchKernel((hipFunction_t)fn, g.tiles_per_plane * nruns, 1, 1, 256, 1, 1, l.roll_tile ? 0u : lds_pad, stream, args, nullptr);
+			return hipModuleLaunchKernel((hipFunction_t)fn, g.tiles_per_plane * nruns, 1, 1, 256, 1, 1, tile_form ? 0u : lds_pad, stream, args, nullptr);
 		}
 	}
 	const ClassJit *jit = l.class_jit;

@@ -70,7 +70,7 @@ constexpr int kBThreads = 1024;     // 16 waves per workgroup: the pack / unpack
 
 template <int MAIN, bool FAST, int kBTZ>
 __global__ __launch_bounds__(kBThreads) void ca_unpacked_ballot(const u32 *__restrict__ in, u32 *__restrict__ out, PlaneRange pr,
-                                                          u32 ny, u32 cv_shift, PackedRuleArgs rules_in)
+                                                          u32 ny, u32 cv_shift, PackedRuleArgs rules_in, u32 pack_loads)
 {
 	extern __shared__ __attribute__((aligned(16))) u32 lds[]; // in bits [(TZ+2)][(TY+2)][C], then out bits [TZ][TY][C]
 	const u32 G = pr.G, C = G / 32u, X64 = G / 64u;
@@ -89,15 +89,16 @@ __global__ __launch_bounds__(kBThreads) void ca_unpacked_ballot(const u32 *__res
 	// the phase is load-latency-bound, so bytes in flight per wave are what counts.)
 	constexpr u32 NW = kBThreads / 64u;
 	const u32 X256 = G / 256u; // dwordx4 wave-loads per row (G >= 256), else the ballot path below
-	if (X256 > 0)
+	if (X256 > 0 && pack_loads == 0u)
 	{
+		// (round-1 form, kept for A/B timing: CA3D_UNPACKED_LOADS=0) one row at a time, X256 loads in flight per wave
 		for (u32 row = wave; row < RZ * RY; row += NW)
 		{
 			const u32 zz = row / RY, yy = row - zz * RY;
 			int gy = y0 + (int)yy - 1, gz = z0 + (int)zz - 1;
-			gy = gy < 0 ? gy + (int)G : (gy >= (int)G ? gy - (int)G : gy); // toroidal (power-of-two G)
+			gy = gy < 0 ? gy + (int)G : (gy >= (int)G ? gy - (int)G : gy);
 			if (pr.wrap_full) gz = gz < 0 ? gz + (int)G : (gz >= (int)G ? gz - (int)G : gz);
-			else gz = gz < 0 ? 0 : (gz >= (int)pr.nplanes ? (int)pr.nplanes - 1 : gz); // slab: ghosts are adjacent planes
+			else gz = gz < 0 ? 0 : (gz >= (int)pr.nplanes ? (int)pr.nplanes - 1 : gz);
 			const uint4 *src = reinterpret_cast<const uint4 *>(in + (size_t)gz * plane_cells + (size_t)gy * G) + lane;
 			u32 *dst = in_bits + row * C + (lane >> 3);
 			for (u32 x0 = 0; x0 < X256; x0 += 4u)
@@ -114,6 +115,42 @@ __global__ __launch_bounds__(kBThreads) void ca_unpacked_ballot(const u32 *__res
 					n |= (u32)__shfl_down((int)n, 4) << 16;
 					if ((lane & 7u) == 0 && x0 + (u32)k < X256) dst[(x0 + (u32)k) * 8u] = n;
 				}
+			}
+		}
+	}
+	else if (X256 > 0)
+	{
+		// Eight dwordx4 loads (8 KiB per wave) are issued before the first one is used — the rows of a wave are taken 8 / X256 at a
+		// time: with one row (2 loads at 512^3) in flight per wave the phase waited a memory round trip per row
+		// (r2: 238 us per 512^3 step; the loads of a workgroup's 16 waves did not cover the latency).
+		const u32 xshift = X256 >= 4u ? 2u : (X256 == 2u ? 1u : 0u); // 1, 2 or 4 loads per row (G = 256, 512, 1024: what fits the LDS)
+		const u32 xper = 1u << xshift, rif = max(1u, pack_loads >> xshift), nrows = RZ * RY;
+		auto row_src = [&](u32 row) -> const uint4 * {
+			const u32 zz = row / RY, yy = row - zz * RY;
+			int gy = y0 + (int)yy - 1, gz = z0 + (int)zz - 1;
+			gy = gy < 0 ? gy + (int)G : (gy >= (int)G ? gy - (int)G : gy); // toroidal (power-of-two G)
+			if (pr.wrap_full) gz = gz < 0 ? gz + (int)G : (gz >= (int)G ? gz - (int)G : gz);
+			else gz = gz < 0 ? 0 : (gz >= (int)pr.nplanes ? (int)pr.nplanes - 1 : gz); // slab: ghosts are adjacent planes
+			return reinterpret_cast<const uint4 *>(in + (size_t)gz * plane_cells + (size_t)gy * G) + lane;
+		};
+		for (u32 base = wave; base < nrows; base += NW * rif)
+		{
+			uint4 vals[8];
+#pragma unroll
+			for (int q = 0; q < 8; q++)
+			{
+				const u32 row = base + NW * ((u32)q >> xshift), xc = (u32)q & (xper - 1u);
+				vals[q] = (row < nrows && (u32)q < rif * xper) ? row_src(row)[xc * 64u] : make_uint4(0, 0, 0, 0);
+			}
+#pragma unroll
+			for (int q = 0; q < 8; q++)
+			{
+				const u32 row = base + NW * ((u32)q >> xshift), xc = (u32)q & (xper - 1u);
+				u32 n = (vals[q].x != 0u ? 1u : 0u) | (vals[q].y != 0u ? 2u : 0u) | (vals[q].z != 0u ? 4u : 0u) | (vals[q].w != 0u ? 8u : 0u);
+				n |= (u32)__shfl_down((int)n, 1) << 4;
+				n |= (u32)__shfl_down((int)n, 2) << 8;
+				n |= (u32)__shfl_down((int)n, 4) << 16;
+				if ((lane & 7u) == 0 && row < nrows && (u32)q < rif * xper) in_bits[row * C + (lane >> 3) + xc * 8u] = n;
 			}
 		}
 	}
@@ -226,7 +263,8 @@ hipError_t launch_ballot_fz(const UnpackedLaunch &l, hipStream_t stream, const P
 			if (dev >= 0 && dev < 64) attr_devices |= 1ull << dev;
 		}
 	}
-	hipLaunchKernelGGL(kern, dim3(ny * nz), dim3(kBThreads), lds_bytes, stream, l.in, l.out, l.pr, ny, cv_shift, prog);
+	static const u32 pack_loads = getenv("CA3D_UNPACKED_LOADS") ? (u32)atoi(getenv("CA3D_UNPACKED_LOADS")) : 8u; // dwordx4 loads in flight per wave in the pack phase (tuning)
+	hipLaunchKernelGGL(kern, dim3(ny * nz), dim3(kBThreads), lds_bytes, stream, l.in, l.out, l.pr, ny, cv_shift, prog, pack_loads);
 	return hipGetLastError();
 }
 

@@ -1773,7 +1773,7 @@ int ca3d_set_option(ca3d_t *h, const char *name, int64_t value)
 	}
 	if (!strcmp(name, "roll_z"))
 	{
-		if (value != 0 && value != 2 && value != 4 && value != 8 && value != 16) return fail(CA3D_ERR_INVALID_ARGUMENT, "roll_z must be 0 (automatic), 2, 4, 8 or 16 (tile form only)");
+		if (value != 0 && value != 2 && value != 4 && value != 8 && value != 16 && value != 15 && value != 30) return fail(CA3D_ERR_INVALID_ARGUMENT, "roll_z must be 0 (automatic), 2, 4, 8, 16 (tile form only), or 15 / 30 (looped forms)");
 		drop_graph(h);
 		h->roll_z = (int)value;
 		return CA3D_OK;

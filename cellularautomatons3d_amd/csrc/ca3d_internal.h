@@ -71,6 +71,7 @@ struct RollJit
 {
 	void *z[3] = {nullptr, nullptr, nullptr}; // hipFunction_t for Z = 2, 4, 8
 	void *tile[4] = {nullptr, nullptr, nullptr, nullptr}; // the tile form (x-shifted rows shared through LDS) for Z = 2, 4, 8, 16
+	void *loop[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; // looped forms [tile][Z = 15, 30]: the plane loop rolled up in groups of three
 	int cvl = -1;                              // log2(G / 128); -1: none
 	int main = -1;
 	bool e = false, c = false;

@@ -358,6 +358,21 @@ hipError_t launch_class(const PackedLaunch &l, hipStream_t stream)
 		// thread: the largest of 8 / 4 / 2 that the shortest range holds and that still gives every SIMD its two waves
 		// (a wave alone on a SIMD issues at half rate); launches too small for that keep the one-plane kernels below.
 		static const u32 lds_pad = getenv("CA3D_ROLL_LDS") ? (u32)atoi(getenv("CA3D_ROLL_LDS")) : 0u;
+		// looped forms (15 / 30 planes per thread): forced by roll_z 15 / 30
+		for (int li = 1; li >= 0; li--)
+		{
+			const u32 Z = li ? 30u : 15u;
+			void *fn = rj->loop[l.roll_tile ? 1 : 0][li];
+			if (l.roll_z != (int)Z || shortest < Z || !fn) continue;
+			const u32 runs1 = (planes1 + Z - 1u) / Z, nruns = runs1 + (planes2 + Z - 1u) / Z;
+			RollArgs a;
+			a.lo = l.pr.lo; a.hi = l.pr.hi; a.nplanes = l.pr.nplanes; a.wrap_full = l.pr.wrap_full; a.zbase = l.pr.zbase;
+			a.lo2 = l.pr.lo2; a.hi2 = two ? l.pr.hi2 : l.pr.lo2; a.runs1 = runs1;
+			const u32 *in = l.in;
+			u32 *out = l.out;
+			void *args[] = {(void *)&in, (void *)&out, (void *)&a};
+			return hipModuleLaunchKernel((hipFunction_t)fn, g.tiles_per_plane * nruns, 1, 1, 256, 1, 1, 0, stream, args, nullptr);
+		}
 		for (int zi = l.roll_tile ? 3 : 2; zi >= 0; zi--)
 		{
 			const u32 Z = 2u << zi;

@@ -237,6 +237,181 @@ __global__ __launch_bounds__(kBThreads) void ca_unpacked_ballot(const u32 *__res
 	}
 }
 
+// ---------------------------------------------------------------------------------------------- pipelined form
+// ca_unpacked_ballot runs pack -> update -> unpack once per tile, and every workgroup of a 512^3 launch is resident at
+// once (512 tiles, two per CU): the whole chip reads, then computes, then writes — HBM is never read and written at the
+// same time (262 us per step = 4.1 TB/s of the 6.5 TB/s a copy reaches). Here a workgroup walks its tile in groups of SUB
+// planes: while group k is expanded and stored, the rows group k + 1 needs are loaded and packed — every wave alternates
+// a row of loads with a row of stores, so both directions are in flight for most of the launch. Same tile, same LDS image
+// of input bits, same update code; the output bits are double-buffered per group.
+template <int MAIN, bool FAST, int kBTZ, int kSub>
+__global__ __launch_bounds__(kBThreads) void ca_unpacked_pipe(const u32 *__restrict__ in, u32 *__restrict__ out, PlaneRange pr,
+                                                              u32 ny, u32 cv_shift, PackedRuleArgs rules_in)
+{
+	extern __shared__ __attribute__((aligned(16))) u32 lds[]; // in bits [(TZ+2)][(TY+2)][C], then out bits [2][SUB][TY][C]
+	constexpr u32 SUB = kSub, K = kBTZ / SUB;
+	const u32 G = pr.G, C = G / 32u;
+	const size_t plane_cells = (size_t)G * G;
+	const u32 tid = threadIdx.x, lane = tid & 63u;
+	const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+	const u32 tz = blockIdx.x / ny, ty = blockIdx.x - tz * ny;
+	const int y0 = (int)(ty * kBTY), z0 = (int)pr.lo + (int)(tz * kBTZ);
+	constexpr u32 RY = kBTY + 2, RZ = kBTZ + 2, NW = kBThreads / 64u;
+	u32 *in_bits = lds;
+	u32 *out_bits = lds + RZ * RY * C;
+	const u32 X256 = G / 256u; // dwordx4 wave-loads per row: 1, 2 or 4 (the launcher takes this kernel for G >= 256 only)
+
+	auto src_row = [&](u32 row) -> const uint4 * { // image row (zz, yy) -> the cells it packs
+		const u32 zz = row / RY, yy = row - zz * RY;
+		int gy = y0 + (int)yy - 1, gz = z0 + (int)zz - 1;
+		gy = gy < 0 ? gy + (int)G : (gy >= (int)G ? gy - (int)G : gy); // toroidal (power-of-two G)
+		if (pr.wrap_full) gz = gz < 0 ? gz + (int)G : (gz >= (int)G ? gz - (int)G : gz);
+		else gz = gz < 0 ? 0 : (gz >= (int)pr.nplanes ? (int)pr.nplanes - 1 : gz); // slab: ghosts are adjacent planes
+		return reinterpret_cast<const uint4 *>(in + (size_t)gz * plane_cells + (size_t)gy * G) + lane;
+	};
+	auto pack_issue = [&](u32 row, uint4 (&v)[4]) {
+		const uint4 *src = src_row(row);
+#pragma unroll
+		for (int k = 0; k < 4; k++) v[k] = (u32)k < X256 ? src[(u32)k * 64u] : make_uint4(0, 0, 0, 0);
+	};
+	auto pack_finish = [&](u32 row, const uint4 (&v)[4]) {
+		u32 *dst = in_bits + row * C + (lane >> 3);
+#pragma unroll
+		for (int k = 0; k < 4; k++)
+		{
+			u32 n = (v[k].x != 0u ? 1u : 0u) | (v[k].y != 0u ? 2u : 0u) | (v[k].z != 0u ? 4u : 0u) | (v[k].w != 0u ? 8u : 0u);
+			n |= (u32)__shfl_down((int)n, 1) << 4;
+			n |= (u32)__shfl_down((int)n, 2) << 8;
+			n |= (u32)__shfl_down((int)n, 4) << 16;
+			if ((lane & 7u) == 0 && (u32)k < X256) dst[(u32)k * 8u] = n;
+		}
+	};
+	// row `r` (plane-in-group, y) of output group `grp` -> one u32 per cell
+	auto unpack_row = [&](u32 grp, u32 r) {
+		const u32 rz = grp * SUB + r / kBTY, ry = r % kBTY;
+		const int gy = y0 + (int)ry, gz = z0 + (int)rz;
+		if (gy >= (int)G || gz >= (int)pr.hi) return;
+		uint4 *drow = reinterpret_cast<uint4 *>(out + (size_t)gz * plane_cells + (size_t)gy * G);
+		const u32 *srcb = out_bits + ((grp & 1u) * SUB * kBTY + r) * C + (lane >> 3);
+		const u32 sh = (lane & 7u) * 4u;
+		for (u32 xc = 0; xc < X256; xc++)
+		{
+			const u32 w = srcb[xc * 8u] >> sh;
+			uint4 v;
+			v.x = w & 1u; v.y = (w >> 1) & 1u; v.z = (w >> 2) & 1u; v.w = (w >> 3) & 1u;
+			drow[xc * 64u + lane] = v;
+		}
+	};
+
+	// ---- prologue: the input planes group 0 needs (zz = 0 .. SUB + 1), two rows in flight per wave
+	{
+		const u32 nrows = (SUB + 2u) * RY;
+		for (u32 row = wave; row < nrows; row += 2u * NW)
+		{
+			uint4 a[4], b[4];
+			pack_issue(row, a);
+			const bool two = row + NW < nrows;
+			if (two) pack_issue(row + NW, b);
+			pack_finish(row, a);
+			if (two) pack_finish(row + NW, b);
+		}
+	}
+	__syncthreads();
+
+	FastRules<MAIN, false, false> frules;
+	if (FAST) frules = expand_rules<MAIN, false, false>(rules_in);
+	const u32 CV = C / 4u;
+	for (u32 grp = 0; grp < K; grp++)
+	{
+		// ---- update group grp: output planes rz = grp * SUB .. + SUB - 1 from image planes rz .. rz + 2
+		const u32 nitems = (SUB * kBTY) << cv_shift;
+		for (u32 it = tid; it < nitems; it += (u32)kBThreads)
+		{
+			const u32 cxv = it & (CV - 1u), rrow = it >> cv_shift;
+			const u32 ry = rrow % kBTY, rz = grp * SUB + rrow / kBTY;
+			const u32 cx0 = cxv * 4u;
+			auto seg = [&](u32 zz, u32 yy) {
+				SegT<4> sg;
+				const u32 *row = in_bits + (zz * RY + yy) * C;
+				const uint4 w = *reinterpret_cast<const uint4 *>(row + cx0);
+				sg.w[0] = w.x; sg.w[1] = w.y; sg.w[2] = w.z; sg.w[3] = w.w;
+				sg.lo = row[cx0 == 0 ? C - 1u : cx0 - 1u];
+				sg.hi = row[cx0 + 4u == C ? 0u : cx0 + 4u];
+				return sg;
+			};
+			PlaneRowsT<4> P[3];
+#pragma unroll
+			for (int dz = 0; dz < 3; dz++)
+			{
+				P[dz].ym = seg(rz + (u32)dz, ry);
+				P[dz].c = seg(rz + (u32)dz, ry + 1u);
+				P[dz].yp = seg(rz + (u32)dz, ry + 2u);
+			}
+			u32 o[4];
+			if (FAST) evolve<4, MAIN, false, false>(P[0], P[1], P[2], 0xFFFFFFFFu, frules, o);
+			else evolve<4, MAIN, false, false>(P[0], P[1], P[2], 0xFFFFFFFFu, rules_in, o);
+			uint4 ov;
+			ov.x = o[0]; ov.y = o[1]; ov.z = o[2]; ov.w = o[3];
+			*reinterpret_cast<uint4 *>(out_bits + ((grp & 1u) * SUB * kBTY + rrow) * C + cx0) = ov;
+		}
+		__syncthreads();
+		// ---- store group grp while the input planes of group grp + 1 (zz = SUB * (grp + 1) + 2 .. + SUB - 1 more) are loaded
+		const u32 pack_lo = (SUB * (grp + 1u) + 2u) * RY, pack_hi = grp + 1u < K ? pack_lo + SUB * RY : pack_lo;
+		const u32 nun = SUB * kBTY;
+		for (u32 i = wave;; i += 2u * NW)
+		{
+			// two rows of loads in flight per wave, two rows of stores under them
+			const u32 p0 = pack_lo + i, p1 = p0 + NW;
+			const bool pk0 = p0 < pack_hi, pk1 = p1 < pack_hi, un0 = i < nun, un1 = i + NW < nun;
+			if (!pk0 && !un0) break;
+			uint4 a[4], b[4];
+			if (pk0) pack_issue(p0, a);
+			if (pk1) pack_issue(p1, b);
+			if (un0) unpack_row(grp, i);
+			if (un1) unpack_row(grp, i + NW);
+			if (pk0) pack_finish(p0, a);
+			if (pk1) pack_finish(p1, b);
+		}
+		__syncthreads();
+	}
+}
+
+template <int MAIN, bool FAST, int kBTZ, int kSub>
+hipError_t launch_pipe_fzs(const UnpackedLaunch &l, hipStream_t stream, const PackedRuleArgs &prog)
+{
+	const u32 G = l.pr.G, C = G / 32u;
+	const u32 ny = (G + kBTY - 1) / kBTY, nz = (l.pr.hi - l.pr.lo + kBTZ - 1) / kBTZ;
+	const size_t lds_bytes = ((size_t)(kBTZ + 2) * (kBTY + 2) + (size_t)2 * kSub * kBTY) * C * sizeof(u32);
+	auto kern = ca_unpacked_pipe<MAIN, FAST, kBTZ, kSub>;
+	u32 cv_shift = 0;
+	while ((1u << cv_shift) < C / 4u) cv_shift++;
+	static std::mutex attr_mutex;
+	static uint64_t attr_devices = 0;
+	{
+		int dev = 0;
+		hipError_t e = hipGetDevice(&dev);
+		if (e != hipSuccess) return e;
+		std::lock_guard<std::mutex> lock(attr_mutex);
+		if (dev < 0 || dev >= 64 || !(attr_devices >> dev & 1u))
+		{
+			e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+			if (e != hipSuccess) return e;
+			if (dev >= 0 && dev < 64) attr_devices |= 1ull << dev;
+		}
+	}
+	hipLaunchKernelGGL(kern, dim3(ny * nz), dim3(kBThreads), lds_bytes, stream, l.in, l.out, l.pr, ny, cv_shift, prog);
+	return hipGetLastError();
+}
+
+template <int MAIN, bool FAST, int kBTZ>
+hipError_t launch_pipe_fz(const UnpackedLaunch &l, hipStream_t stream, const PackedRuleArgs &prog)
+{
+	static const int sub_env = getenv("CA3D_UNPACKED_SUB") ? atoi(getenv("CA3D_UNPACKED_SUB")) : 4; // planes per group (tuning)
+	if (sub_env == 2) return launch_pipe_fzs<MAIN, FAST, kBTZ, 2>(l, stream, prog);
+	if (sub_env == 8) return launch_pipe_fzs<MAIN, FAST, kBTZ, 8>(l, stream, prog);
+	return launch_pipe_fzs<MAIN, FAST, kBTZ, 4>(l, stream, prog);
+}
+
 template <int MAIN, bool FAST, int kBTZ>
 hipError_t launch_ballot_fz(const UnpackedLaunch &l, hipStream_t stream, const PackedRuleArgs &prog)
 {
@@ -263,7 +438,12 @@ hipError_t launch_ballot_fz(const UnpackedLaunch &l, hipStream_t stream, const P
 			if (dev >= 0 && dev < 64) attr_devices |= 1ull << dev;
 		}
 	}
-	static const u32 pack_loads = getenv("CA3D_UNPACKED_LOADS") ? (u32)atoi(getenv("CA3D_UNPACKED_LOADS")) : 8u; // dwordx4 loads in flight per wave in the pack phase (tuning)
+	// dwordx4 loads in flight per wave in the pack phase: 8 (eight rows at once) on rows of one load (G = 256: 37 -> 31.5 us per
+	// step), the row-at-a-time form on longer rows (512^3: 262 us against 268 with 8 — the phase is not latency-bound there: all
+	// workgroups of the launch are resident at once and run pack / update / unpack in step, so reads and writes never overlap;
+	// profiles/r3_e_unpacked_pack_depth.txt). CA3D_UNPACKED_LOADS overrides (0: row at a time).
+	static const int pack_env = getenv("CA3D_UNPACKED_LOADS") ? atoi(getenv("CA3D_UNPACKED_LOADS")) : -1;
+	const u32 pack_loads = pack_env >= 0 ? (u32)pack_env : (G <= 256u ? 8u : 0u);
 	hipLaunchKernelGGL(kern, dim3(ny * nz), dim3(kBThreads), lds_bytes, stream, l.in, l.out, l.pr, ny, cv_shift, prog, pack_loads);
 	return hipGetLastError();
 }
@@ -273,6 +453,10 @@ hipError_t launch_ballot_f(const UnpackedLaunch &l, hipStream_t stream, const Pa
 {
 	// 16-plane tiles re-read 1.2x (8-plane tiles 1.33x) but need >= 2 workgroups per CU to keep HBM busy
 	const u32 tiles16 = ((l.pr.G + kBTY - 1) / kBTY) * ((l.pr.hi - l.pr.lo + 15u) / 16u);
+	// the pipelined form (loads of the next plane group under the stores of this one) where rows are whole dwordx4 wave-loads
+	static const int pipe_env = getenv("CA3D_UNPACKED_PIPE") ? atoi(getenv("CA3D_UNPACKED_PIPE")) : 1;
+	if (pipe_env && l.pr.G >= 512u) // (256^3: 35 us against 31.5 — a tile is 8 planes there, two groups: too little to overlap)
+		return tiles16 >= 512u ? launch_pipe_fz<MAIN, FAST, 16>(l, stream, prog) : launch_pipe_fz<MAIN, FAST, 8>(l, stream, prog);
 	return tiles16 >= 512u ? launch_ballot_fz<MAIN, FAST, 16>(l, stream, prog) : launch_ballot_fz<MAIN, FAST, 8>(l, stream, prog);
 }
 

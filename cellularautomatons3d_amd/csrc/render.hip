@@ -99,6 +99,18 @@ __device__ __forceinline__ void ray_cube(v3 o, v3 d, v3 center, v3 half, float &
 	tfar = fminf(fminf(t2.x, t2.y), t2.z);
 }
 
+// The same test with 1 / d handed in (bit-identical: ray_cube forms exactly this `inv` first). A walk tests many cells along
+// one ray: three correctly rounded divisions (~10 instructions each) per live cell become three per ray.
+__device__ __forceinline__ void ray_cube_inv(v3 o, v3 inv, v3 center, v3 half, float &tnear, float &tfar)
+{
+	const v3 tmin = ((center - half) - o) * inv;
+	const v3 tmax = ((center + half) - o) * inv;
+	const v3 t1 = V(fminf(tmin.x, tmax.x), fminf(tmin.y, tmax.y), fminf(tmin.z, tmax.z));
+	const v3 t2 = V(fmaxf(tmin.x, tmax.x), fmaxf(tmin.y, tmax.y), fmaxf(tmin.z, tmax.z));
+	tnear = fmaxf(fmaxf(t1.x, t1.y), t1.z);
+	tfar = fminf(fminf(t2.x, t2.y), t2.z);
+}
+
 __device__ __forceinline__ float sd_box(v3 p, v3 b)
 {
 	// :182-186
@@ -275,6 +287,7 @@ __device__ bool walk(const RenderParams &P, v3 start, v3 dir, float t0, float tm
 	const float dx = dir.x != 0.0f ? cs / fabsf(dir.x) : big, dy = dir.y != 0.0f ? cs / fabsf(dir.y) : big,
 	            dz = dir.z != 0.0f ? cs / fabsf(dir.z) : big;
 	float t = t0;
+	const v3 inv = V(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z); // what ray_cube forms first: once per ray, not once per live cell
 	// one packed word covers 32 x-cells of a row: keep it in a register while the walk stays inside it
 	u32 word = 0;
 	int wkey = -1;
@@ -308,7 +321,7 @@ __device__ bool walk(const RenderParams &P, v3 start, v3 dir, float t0, float tm
 			if (!(SHADOW && ix == sx0 && iy == sy0 && iz == sz0)) // any(cell != startCell) :664
 			{
 				float tn, tf;
-				ray_cube(start, dir, cell_origin(cs, ix, iy, iz), half, tn, tf);
+				ray_cube_inv(start, inv, cell_origin(cs, ix, iy, iz), half, tn, tf);
 				if (SHADOW ? (tn <= tf && tn >= 0.0f) /* :668 */ : (tf >= 0.0f && tn <= tf) /* :722-729 */)
 				{
 					tnear_out = tn;
@@ -614,16 +627,26 @@ struct RayState
 	int job;   // -1: idle
 	int phase; // 1: primary walk, 2: shadow walk
 	// Amanatides-Woo walk
-	v3 start, dir;
+	v3 start, dir, inv; // inv = 1 / dir, formed once per ray (ray_cube_inv)
 	float tmax, t, tx, ty, tz, dx, dy, dz;
 	int ix, iy, iz, guard, wkey;
 	u32 word;
 	int cx, cy, cz; // shadow walk: the cell the ray starts in (exempt from the hit test); also the shaded cell
-	// sample context
-	v3 ray;       // view ray (world space)
-	float vu, tf; // screen u (show-depth split), distance at which the view ray leaves the volume
-	v3 p;         // shaded point
-	float depth;
+	// The sample's context — view ray, screen u, the distance at which the view ray leaves the volume, the depth — is NOT
+	// here: nothing in the stepping loop reads it, and nine more live registers put the kernel over the 128 that four waves
+	// per SIMD allow (it spilled 60 bytes per lane). It waits in LDS (SampleCtx) between the three stages of a sample. The
+	// shaded point of the shadow stage is `start` (the shadow ray starts there).
+};
+
+// Per-lane sample context in LDS: ctx[k][thread] (conflict-free: consecutive lanes, consecutive words)
+constexpr int kCtxRay = 0, kCtxVu = 3, kCtxTf = 4, kCtxDepth = 5, kCtxWords = 6;
+struct SampleCtx
+{
+	float *base; // &ctx[0][thread]
+	int stride;  // threads per block
+	__device__ __forceinline__ float get(int k) const { return base[k * stride]; }
+	__device__ __forceinline__ void set(int k, float v) const { base[k * stride] = v; }
+	__device__ __forceinline__ v3 ray() const { return V(get(kCtxRay), get(kCtxRay + 1), get(kCtxRay + 2)); }
 };
 
 __device__ __forceinline__ void walk_begin(const RenderParams &P, RayState &w, v3 start, v3 dir, float t0, float tmax)
@@ -645,6 +668,7 @@ __device__ __forceinline__ void walk_begin(const RenderParams &P, RayState &w, v
 	w.dz = dir.z != 0.0f ? cs / fabsf(dir.z) : big;
 	w.start = start;
 	w.dir = dir;
+	w.inv = V(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
 	w.tmax = tmax;
 	w.t = t0;
 	w.ix = ix; w.iy = iy; w.iz = iz;
@@ -683,7 +707,7 @@ __device__ __forceinline__ int walk_step(const RenderParams &P, RayState &w, v3 
 		if (!(shadow && w.ix == w.cx && w.iy == w.cy && w.iz == w.cz))
 		{
 			float tn, tf;
-			ray_cube(w.start, w.dir, cell_origin(cs, w.ix, w.iy, w.iz), half, tn, tf);
+			ray_cube_inv(w.start, w.inv, cell_origin(cs, w.ix, w.iy, w.iz), half, tn, tf);
 			if (shadow ? (tn <= tf && tn >= 0.0f) : (tf >= 0.0f && tn <= tf))
 			{
 				tnear_out = tn;
@@ -705,15 +729,15 @@ __device__ __forceinline__ int walk_step(const RenderParams &P, RayState &w, v3 
 }
 
 // The tail every sample goes through (shade_sample's last two blocks): light gizmo, show-depth split.
-__device__ __forceinline__ void sample_tail(const RenderParams &P, const RayState &st, Sample &s)
+__device__ __forceinline__ void sample_tail(const RenderParams &P, v3 ray, float vu, Sample &s)
 {
 	const float *u = P.u;
 	const v3 cam = V(u[U_VIEW + 12], u[U_VIEW + 13], u[U_VIEW + 14]);
 	const v3 light_pos = V(u[U_LIGHT], u[U_LIGHT + 1], u[U_LIGHT + 2]);
 	float ln, lf;
-	ray_cube(cam, st.ray, light_pos, V(0.005f, 0.005f, 0.005f), ln, lf);
+	ray_cube(cam, ray, light_pos, V(0.005f, 0.005f, 0.005f), ln, lf);
 	if (ln <= lf && lf >= 0.0f && s.r == 0.0f && s.g == 0.0f && s.b == 0.0f) { s.r = s.g = s.b = 1.0f; s.a = 1.0f; }
-	if (u[U_SHOWDEPTH] == 1.0f && st.vu < 0.5f) { s.r = s.depth; s.g = 0.0f; s.b = 0.0f; s.a = 1.0f; }
+	if (u[U_SHOWDEPTH] == 1.0f && vu < 0.5f) { s.r = s.depth; s.g = 0.0f; s.b = 0.0f; s.a = 1.0f; }
 }
 
 __device__ __forceinline__ void sample_clamp(Sample &s)
@@ -726,7 +750,7 @@ __device__ __forceinline__ void sample_clamp(Sample &s)
 
 // shade_sample up to the primary walk. true: the sample is complete (the view ray misses the volume).
 // skip_box: the sparse-volume variant — a view ray that misses the box of the occupied blocks goes straight to the "no hit" branch
-__device__ bool sample_begin(const RenderParams &P, RayState &st, float vu, float vv, Sample &s, bool skip_box)
+__device__ bool sample_begin(const RenderParams &P, RayState &st, const SampleCtx &ctx, float vu, float vv, Sample &s, bool skip_box)
 {
 	const float *u = P.u;
 	const float *view = u + U_VIEW;
@@ -740,8 +764,6 @@ __device__ bool sample_begin(const RenderParams &P, RayState &st, float vu, floa
 	float tn, tf;
 	ray_cube(cam, ray, V(0.0f, 0.0f, 0.0f), half, tn, tf);
 	const float cam_dist = sd_box(cam, half);
-	st.ray = ray;
-	st.vu = vu;
 	if (tn <= tf && tf >= 0.0f)
 	{
 		v3 enter = cam;
@@ -750,36 +772,39 @@ __device__ bool sample_begin(const RenderParams &P, RayState &st, float vu, floa
 		const v3 seg = exitp - enter;
 		walk_begin(P, st, enter, norm3(seg), 0.0f, len3(seg));
 		if (skip_box && misses_live_box(P, cam, ray)) st.tmax = -1.0f; // the walk ends at its first step, before it visits a cell: no hit
-		st.tf = tf;
+		ctx.set(kCtxRay, ray.x); ctx.set(kCtxRay + 1, ray.y); ctx.set(kCtxRay + 2, ray.z);
+		ctx.set(kCtxVu, vu);
+		ctx.set(kCtxTf, tf);
 		st.phase = 1;
 		return false;
 	}
-	sample_tail(P, st, s);
+	sample_tail(P, ray, vu, s);
 	return true;
 }
 
 // shade_sample between the primary walk and the shadow walk. true: complete (nothing to light at the end point).
-__device__ bool sample_after_primary(const RenderParams &P, RayState &st, bool hit, float tnear, Sample &s)
+__device__ bool sample_after_primary(const RenderParams &P, RayState &st, const SampleCtx &ctx, bool hit, float tnear, Sample &s)
 {
 	const float *u = P.u;
+	const v3 ray = ctx.ray();
 	s = Sample{0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0u};
 	const v3 cam = V(u[U_VIEW + 12], u[U_VIEW + 13], u[U_VIEW + 14]);
 	const v3 half = V(kHalf, kHalf, kHalf);
 	const float cs = 1.0f / (float)P.G;
 	const float vis = cs * u[U_CELLSIZE] * 0.5f;
 	const v3 vhalf = V(vis, vis, vis);
-	const v3 exitp = cam + st.ray * st.tf;
+	const v3 exitp = cam + ray * ctx.get(kCtxTf);
 	const v3 final_point = hit ? st.start + st.dir * tnear : exitp;
 	s.depth = len3(final_point - cam);
-	const v3 p = cam + st.ray * s.depth;
+	const v3 p = cam + ray * s.depth;
 	const v3 f = V(floorf((p.x + kHalf) / cs), floorf((p.y + kHalf) / cs), floorf((p.z + kHalf) / cs));
 	const v3 origin = V(f.x * cs + cs * 0.5f - kHalf, f.y * cs + cs * 0.5f - kHalf, f.z * cs + cs * 0.5f - kHalf);
 	const int cx = (int)f.x, cy = (int)f.y, cz = (int)f.z;
 	const u32 state = cell_state(P, (u32)cx, (u32)cy, (u32)cz);
 	const float dist = sd_box(p - origin, vhalf);
-	st.depth = s.depth;
 	if (state == 1u && !(dist > 0.001f))
 	{
+		ctx.set(kCtxDepth, s.depth);
 		const v3 light_pos = V(u[U_LIGHT], u[U_LIGHT + 1], u[U_LIGHT + 2]);
 		const v3 ldir = norm3(light_pos - p);
 		float vn, vf;
@@ -787,24 +812,23 @@ __device__ bool sample_after_primary(const RenderParams &P, RayState &st, bool h
 		const v3 vexit = p + ldir * vf;
 		const v3 sseg = vexit - p;
 		walk_begin(P, st, p, norm3(sseg), 0.0025f, len3(sseg));
-		st.cx = cx; st.cy = cy; st.cz = cz;
-		st.p = p;
+		st.cx = cx; st.cy = cy; st.cz = cz; // (the shaded point is st.start from here on)
 		st.phase = 2;
 		return false;
 	}
 	sample_clamp(s);
-	sample_tail(P, st, s);
+	sample_tail(P, ray, ctx.get(kCtxVu), s);
 	return true;
 }
 
-// shade_sample after the shadow walk: lighting of st.p in cell (cx, cy, cz).
-__device__ void sample_after_shadow(const RenderParams &P, const RayState &st, bool occluded, Sample &s)
+// shade_sample after the shadow walk: lighting of the point the shadow ray started from (st.start) in cell (cx, cy, cz).
+__device__ void sample_after_shadow(const RenderParams &P, const RayState &st, const SampleCtx &ctx, bool occluded, Sample &s)
 {
 	const float *u = P.u;
-	s = Sample{0.0f, 0.0f, 0.0f, 1.0f, st.depth, 0u};
+	s = Sample{0.0f, 0.0f, 0.0f, 1.0f, ctx.get(kCtxDepth), 0u};
 	const v3 cam = V(u[U_VIEW + 12], u[U_VIEW + 13], u[U_VIEW + 14]);
 	const float cs = 1.0f / (float)P.G;
-	const v3 p = st.p;
+	const v3 p = st.start;
 	const int cx = st.cx, cy = st.cy, cz = st.cz;
 	const v3 f = V((float)cx, (float)cy, (float)cz);
 	const v3 origin = V(f.x * cs + cs * 0.5f - kHalf, f.y * cs + cs * 0.5f - kHalf, f.z * cs + cs * 0.5f - kHalf);
@@ -849,7 +873,7 @@ __device__ void sample_after_shadow(const RenderParams &P, const RayState &st, b
 		s.shadow_ray = 1u;
 	}
 	sample_clamp(s);
-	sample_tail(P, st, s);
+	sample_tail(P, ctx.ray(), ctx.get(kCtxVu), s);
 }
 
 constexpr int kSchedWaves = 4; // waves per SIMD the scheduled kernel is compiled for (128 VGPRs; measured 3 / 4 / 5 / 6: 1.90 / 1.77 / 1.96 / 2.01 ms)
@@ -875,7 +899,9 @@ __global__ __launch_bounds__(256, WPE) void ca_render_packed_sched(RenderParams 
 	if (SKIP && live_box_small(P)) return; // the plain kernel renders the whole frame (live_box_small)
 	constexpr int TW = PPW == 64 ? 16 : 32, RW = PPW / TW, PPL = PPW / 64; // tile width, rows, pixels per lane
 	__shared__ float res[NK][6][4 * PPW];
+	__shared__ float ctx_lds[kCtxWords][256];
 	const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const SampleCtx ctx{&ctx_lds[0][tid], 256};
 	const float cs = 1.0f / (float)P.G;
 	const float vis = cs * P.u[U_CELLSIZE] * 0.5f;
 	const v3 vhalf = V(vis, vis, vis);
@@ -928,7 +954,7 @@ __global__ __launch_bounds__(256, WPE) void ca_render_packed_sched(RenderParams 
 							const float ox = P.spp == 1u ? 0.5f : ((k & 1u) ? 0.75f : 0.25f);
 							const float oy = P.spp == 1u ? 0.5f : ((k & 2u) ? 0.75f : 0.25f);
 							const float vu = ((float)jx + ox) / (float)P.W, vv = 1.0f - ((float)jy + oy) / (float)P.H;
-							done = sample_begin(P, st, vu, vv, s, SKIP);
+							done = sample_begin(P, st, ctx, vu, vv, s, SKIP);
 						}
 						if (done) complete(s);
 					}
@@ -954,8 +980,8 @@ __global__ __launch_bounds__(256, WPE) void ca_render_packed_sched(RenderParams 
 				{
 					Sample s;
 					bool done = true;
-					if (st.phase == 1) done = sample_after_primary(P, st, term == 1, tnear, s);
-					else sample_after_shadow(P, st, term == 1, s);
+					if (st.phase == 1) done = sample_after_primary(P, st, ctx, term == 1, tnear, s);
+					else sample_after_shadow(P, st, ctx, term == 1, s);
 					if (done) complete(s);
 				}
 			}

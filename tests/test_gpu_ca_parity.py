@@ -314,7 +314,7 @@ def test_rolling_window_kernel_every_depth(eng, name):
     # x-shifted rows through LDS (16 planes per thread exist in the tile form only)
     for tile in (1, 0):
         eng.set_option("roll_tile", tile)
-        for z in (2, 4, 8, 16) if tile else (2, 4, 8):
+        for z in (2, 4, 8, 16, 15, 30) if tile else (2, 4, 8, 15, 30):  # 15 / 30: the looped forms (plane loop in groups of three)
             eng.set_option("roll_z", z)
             eng.upload_state(st)
             eng.step(3)

@@ -123,6 +123,9 @@ struct ca3d_engine
 	uint32_t queued = 0;                  // steps encoded, not yet submitted
 	uint64_t launches_total = 0;          // kernel launches the step calls issued since ca3d_create
 	uint32_t res_rows = 32;               // rows per tile of the von Neumann form (ca_resident_kernel.inc: 32 or 16)
+	uint32_t res_zsplit = 1;              // thread groups along z of the von Neumann form (option "resident_zsplit"; 2 = twice the threads, four waves per
+	                                      // SIMD: measured SLOWER with 32-row tiles — 2.61 vs 2.52 us per step at 512^3, 1.37 vs 1.26 at 256^3 — and faster
+	                                      // only with 16-row tiles, 2.89 vs 3.31: profiles/r3_l_resident_zsplit.txt)
 	uint32_t res_timeout_ticks = 20000000; // 200 ms of s_memrealtime per wait
 	// Recovery of a resident launch that gave up (full-grid engines). A launch of n >= 2 steps never writes the buffer it reads:
 	// the final state goes to a third buffer (`spare`), the state one step earlier to the other ping-pong buffer, and the three
@@ -360,7 +363,7 @@ void select_kernels(ca3d_engine *h)
 		h->vn_jit = j;
 		h->kernel_name = "ca_packed_vn(jit)";
 	}
-	if (resident && jit_resident_kernel(h->device, ls, lb, h->G == 256u ? 256u : h->res_rows, &h->res_jit_fn, &h->jit_log) == CA3D_OK) h->res_ready = true;
+	if (resident && jit_resident_kernel(h->device, ls, lb, h->G == 256u ? 256u : h->res_rows, h->res_zsplit, &h->res_jit_fn, &h->jit_log) == CA3D_OK) h->res_ready = true;
 }
 
 // A resident launch only completes when ALL its workgroups are on the chip at once (they wait for each other's faces). Ask the
@@ -377,7 +380,7 @@ void check_residency(ca3d_engine *h)
 	if (h->res_ready)
 	{
 		const uint32_t rows = (h->res_class || h->G == 256u) ? 32u : h->res_rows;
-		if (resident_capacity(h->G, rows, h->res_jit_fn, h->stream, &tiles, &cap) && cap < tiles)
+		if (resident_capacity(h->G, rows, h->res_class ? 1u : h->res_zsplit, h->res_jit_fn, h->stream, &tiles, &cap) && cap < tiles)
 		{
 			h->res_ready = false;
 			h->res_class = false;
@@ -637,6 +640,7 @@ int resident_steps(ca3d_engine *h, uint32_t n)
 	if (!h->res_class) vn_tables(h->rules, &l.lut_s, &l.lut_b);
 	l.jit_fn = h->res_jit_fn;
 	l.rows = h->res_class ? 32u : h->res_rows;
+	l.zsplit = h->res_class ? 1u : h->res_zsplit;
 	hipError_t e = launch_resident(l, h->stream);
 	if (e != hipSuccess) return fail(CA3D_ERR_DEVICE, "resident kernel launch failed: %s", hipGetErrorString(e));
 	h->res_pending.push_back({h->res_epoch, n, h->cur, h->step, in, other, h->spare});
@@ -1757,6 +1761,14 @@ int ca3d_set_option(ca3d_t *h, const char *name, int64_t value)
 			refresh_kernels(h);
 			note_jit_failure(h);
 		}
+		return CA3D_OK;
+	}
+	if (!strcmp(name, "resident_zsplit"))
+	{
+		if (value != 1 && value != 2) return fail(CA3D_ERR_INVALID_ARGUMENT, "resident_zsplit must be 1 or 2");
+		h->res_zsplit = (uint32_t)value;
+		refresh_kernels(h);
+		note_jit_failure(h);
 		return CA3D_OK;
 	}
 	if (!strcmp(name, "resident_min"))

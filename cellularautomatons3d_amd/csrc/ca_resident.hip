@@ -123,17 +123,18 @@ uint32_t usable_cus(hipStream_t stream)
 }
 } // namespace
 
-bool resident_capacity(uint32_t G, uint32_t rows, void *jit_fn, hipStream_t stream, uint32_t *tiles, uint32_t *capacity)
+bool resident_capacity(uint32_t G, uint32_t rows, uint32_t zsplit, void *jit_fn, hipStream_t stream, uint32_t *tiles, uint32_t *capacity)
 {
-	const uint32_t threads = G == 256u ? 256u : 16u * rows;
+	const uint32_t threads = (G == 256u ? 256u : 16u * rows) * zsplit;
+	const bool z2 = zsplit == 2u;
 	*tiles = G == 256u ? 256u : (G / rows) * (G / kResTileRows);
 	*capacity = 0;
 	int per_cu = 0;
 	hipError_t e;
 	if (jit_fn) e = hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (hipFunction_t)jit_fn, (int)threads, 0);
-	else if (G == 256u) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)ca_resident_vn256<kDefaultS, kDefaultB>, (int)threads, 0);
-	else if (rows == 16u) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)ca_resident_vn<kDefaultS, kDefaultB, 16>, (int)threads, 0);
-	else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)ca_resident_vn<kDefaultS, kDefaultB, 32>, (int)threads, 0);
+	else if (G == 256u) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, z2 ? (const void *)ca_resident_vn256<kDefaultS, kDefaultB, 2> : (const void *)ca_resident_vn256<kDefaultS, kDefaultB, 1>, (int)threads, 0);
+	else if (rows == 16u) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, z2 ? (const void *)ca_resident_vn<kDefaultS, kDefaultB, 16, 2> : (const void *)ca_resident_vn<kDefaultS, kDefaultB, 16, 1>, (int)threads, 0);
+	else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, z2 ? (const void *)ca_resident_vn<kDefaultS, kDefaultB, 32, 2> : (const void *)ca_resident_vn<kDefaultS, kDefaultB, 32, 1>, (int)threads, 0);
 	const uint32_t cus = usable_cus(stream);
 	if (e != hipSuccess || per_cu <= 0 || cus == 0) { (void)hipGetLastError(); return false; }
 	*capacity = (uint32_t)per_cu * cus;
@@ -183,22 +184,26 @@ hipError_t launch_resident(const ResidentLaunch &l, hipStream_t stream)
 	a.epoch0 = l.epoch0;
 	a.timeout_ticks = l.timeout_ticks;
 	a.fault_tile = l.fault_tile;
+	const bool z2 = l.zsplit == 2u;
+	if (l.zsplit != 1u && l.zsplit != 2u) return hipErrorInvalidValue;
 	if (l.G == 256u)
 	{
-		// 8 x 32 tiles of 32 rows x 8 planes, 256 threads each (ca_resident_kernel.inc: CW = 8, PZ = 8)
+		// 8 x 32 tiles of 32 rows x 8 planes, 256 (x 2 with the z split) threads each (ca_resident_kernel.inc: CW = 8, PZ = 8)
+		const u32 threads = 256u * l.zsplit;
 		if (l.jit_fn)
 		{
 			void *args[] = {(void *)&a};
-			return chained_launch(stream, [&]() { return hipModuleLaunchKernel((hipFunction_t)l.jit_fn, 256, 1, 1, 256, 1, 1, 0, stream, args, nullptr); });
+			return chained_launch(stream, [&]() { return hipModuleLaunchKernel((hipFunction_t)l.jit_fn, 256, 1, 1, threads, 1, 1, 0, stream, args, nullptr); });
 		}
 		if (l.lut_s != (u32)kDefaultS || l.lut_b != (u32)kDefaultB) return hipErrorInvalidValue;
 		return chained_launch(stream, [&]() {
-			hipLaunchKernelGGL((ca_resident_vn256<kDefaultS, kDefaultB>), dim3(256), dim3(256), 0, stream, a);
+			if (z2) hipLaunchKernelGGL((ca_resident_vn256<kDefaultS, kDefaultB, 2>), dim3(256), dim3(threads), 0, stream, a);
+			else hipLaunchKernelGGL((ca_resident_vn256<kDefaultS, kDefaultB, 1>), dim3(256), dim3(threads), 0, stream, a);
 			return hipGetLastError();
 		});
 	}
 	if (l.G != 512u || (l.rows != 16u && l.rows != 32u)) return hipErrorInvalidValue;
-	const u32 tiles = (l.G / l.rows) * (l.G / kResTileRows), threads = 16u * l.rows;
+	const u32 tiles = (l.G / l.rows) * (l.G / kResTileRows), threads = 16u * l.rows * l.zsplit;
 	if (l.jit_fn)
 	{
 		void *args[] = {(void *)&a};
@@ -206,8 +211,10 @@ hipError_t launch_resident(const ResidentLaunch &l, hipStream_t stream)
 	}
 	if (l.lut_s != (u32)kDefaultS || l.lut_b != (u32)kDefaultB) return hipErrorInvalidValue;
 	return chained_launch(stream, [&]() {
-		if (l.rows == 16u) hipLaunchKernelGGL((ca_resident_vn<kDefaultS, kDefaultB, 16>), dim3(tiles), dim3(threads), 0, stream, a);
-		else hipLaunchKernelGGL((ca_resident_vn<kDefaultS, kDefaultB, 32>), dim3(tiles), dim3(threads), 0, stream, a);
+		if (l.rows == 16u && z2) hipLaunchKernelGGL((ca_resident_vn<kDefaultS, kDefaultB, 16, 2>), dim3(tiles), dim3(threads), 0, stream, a);
+		else if (l.rows == 16u) hipLaunchKernelGGL((ca_resident_vn<kDefaultS, kDefaultB, 16, 1>), dim3(tiles), dim3(threads), 0, stream, a);
+		else if (z2) hipLaunchKernelGGL((ca_resident_vn<kDefaultS, kDefaultB, 32, 2>), dim3(tiles), dim3(threads), 0, stream, a);
+		else hipLaunchKernelGGL((ca_resident_vn<kDefaultS, kDefaultB, 32, 1>), dim3(tiles), dim3(threads), 0, stream, a);
 		return hipGetLastError();
 	});
 }

@@ -343,8 +343,8 @@ def test_rolling_window_kernel_launcher_choice(eng, name, G):
     assert np.array_equal(eng.read_state(), ol.packed_run(G, st, r, 2))
 
 
-@pytest.mark.parametrize("tables,rows", [("default", 32), ("vn_b24_s135", 32), ("default", 16)])
-def test_resident_multi_step_kernel(eng, tables, rows):
+@pytest.mark.parametrize("tables,rows,zsplit", [("default", 32, 2), ("vn_b24_s135", 32, 2), ("default", 16, 2), ("default", 32, 1), ("vn_b24_s135", 16, 1)])
+def test_resident_multi_step_kernel(eng, tables, rows, zsplit):
     """The resident kernel (ca_resident_kernel.inc): K steps of a 512^3 von Neumann rule in one launch, the state in
     registers, tile faces handed over through tagged granules. Batches of several lengths back to back (the state tags
     keep counting across launches and across uploads), odd and even lengths (the result lands in either ping-pong
@@ -353,6 +353,7 @@ def test_resident_multi_step_kernel(eng, tables, rows):
     r = rules(tables)
     eng.configure(G)
     eng.set_option("resident_rows", rows)  # tiles of 32 rows (one workgroup per CU) or 16 rows (two per CU)
+    eng.set_option("resident_zsplit", zsplit)  # 2: two threads per (row, word) column, half the planes each — four waves per SIMD
     set_rules(eng, r)
     assert eng.info().kernel_name.startswith(b"ca_resident_vn")
     st = host.random_fill(host.words_per_buffer(G), seed=88)
@@ -391,9 +392,11 @@ def test_resident_multi_step_kernel(eng, tables, rows):
     assert eng.info().kernel_name.startswith(b"ca_resident_vn")
     got = eng.read_state()
     np.testing.assert_array_equal(got, per_step)
-    if rows == 32:
+    if rows == 32 and zsplit == 1 and tables == "default":
         np.testing.assert_array_equal(got, ol.packed_run(G, st, r, 1000), err_msg="1000 resident steps vs the oracle")
     assert eng.recovered_launches() == 0
+    eng.set_option("resident_rows", 32)
+    eng.set_option("resident_zsplit", 1)
 
 
 @pytest.mark.parametrize("name,G,n", [("default", 512, 40), ("default", 256, 33), ("clustered", 512, 16)])
@@ -678,14 +681,15 @@ def test_checkpoint_resume(eng, tmp_path):
     np.testing.assert_array_equal(eng.read_state(), want)
 
 
-@pytest.mark.parametrize("tables", ["default", "vn_b24_s135"])
-def test_resident_kernel_at_256(eng, tables):
+@pytest.mark.parametrize("tables,zsplit", [("default", 2), ("vn_b24_s135", 2), ("default", 1)])
+def test_resident_kernel_at_256(eng, tables, zsplit):
     """BASELINE configs[1] (256^3, 1000 steps) through the resident kernel's 256^3 form: 256 tiles of 8 words x 32 rows x 8
     planes (rows of 8 words: two grid rows per DPP row), y faces smaller than a tile's thread count. Batches of several
     lengths, a sparse state, the other ping-pong buffer, and 1000 steps in one launch against the oracle."""
     G = 256
     r = rules(tables)
     eng.configure(G)
+    eng.set_option("resident_zsplit", zsplit)
     set_rules(eng, r)
     assert eng.info().kernel_name.startswith(b"ca_resident_vn")
     st = host.random_fill(host.words_per_buffer(G), seed=256)
@@ -719,6 +723,7 @@ def test_resident_kernel_at_256(eng, tables):
         np.testing.assert_array_equal(eng.read_state(), got)
     finally:
         eng.set_option("resident", 1)
+        eng.set_option("resident_zsplit", 1)
 
 
 def test_queued_submission(eng):

@@ -25,6 +25,7 @@ int main(int argc, char **argv)
 	CK(hipHostMalloc((void **)&hflag, 16, hipHostMallocDefault));
 	*hflag = 0;
 	const int launches = argc > 2 ? atoi(argv[2]) : 3;
+	const int zs = argc > 4 ? atoi(argv[4]) : 1; // thread groups along z: 1 or 2
 	hipEvent_t e0, e1;
 	CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
 	u32 epoch = 0, cur = 0;
@@ -33,9 +34,12 @@ int main(int argc, char **argv)
 	{
 		ResidentArgs a{buf[cur], buf[(cur + steps) & 1], buf[(cur + steps + 1) & 1], mail, status, hflag, steps, epoch, 5000000u};
 		CK(hipEventRecord(e0));
-		if (rows == 256) hipLaunchKernelGGL((ca_resident_vn256<0xFF, 0x0A>), dim3(256), dim3(256), 0, 0, a);
-		else if (rows == 16) hipLaunchKernelGGL((ca_resident_vn<0xFF, 0x0A, 16>), dim3(512), dim3(256), 0, 0, a);
-		else hipLaunchKernelGGL((ca_resident_vn<0xFF, 0x0A, 32>), dim3(256), dim3(512), 0, 0, a);
+		if (rows == 256 && zs == 2) hipLaunchKernelGGL((ca_resident_vn256<0xFF, 0x0A, 2>), dim3(256), dim3(512), 0, 0, a);
+		else if (rows == 256) hipLaunchKernelGGL((ca_resident_vn256<0xFF, 0x0A, 1>), dim3(256), dim3(256), 0, 0, a);
+		else if (rows == 16 && zs == 2) hipLaunchKernelGGL((ca_resident_vn<0xFF, 0x0A, 16, 2>), dim3(512), dim3(512), 0, 0, a);
+		else if (rows == 16) hipLaunchKernelGGL((ca_resident_vn<0xFF, 0x0A, 16, 1>), dim3(512), dim3(256), 0, 0, a);
+		else if (zs == 2) hipLaunchKernelGGL((ca_resident_vn<0xFF, 0x0A, 32, 2>), dim3(256), dim3(1024), 0, 0, a);
+		else hipLaunchKernelGGL((ca_resident_vn<0xFF, 0x0A, 32, 1>), dim3(256), dim3(512), 0, 0, a);
 		CK(hipGetLastError());
 		CK(hipEventRecord(e1));
 		CK(hipDeviceSynchronize());
@@ -51,7 +55,7 @@ int main(int argc, char **argv)
 			std::vector<u32> tt(700);
 			CK(hipMemcpy(tt.data(), status, 616 * 4, hipMemcpyDeviceToHost));
 			static const char *nm[7] = {"poll", "halo+barrier", "face pass", "ym/yp reads", "z faces+prefetch", "main pass", "to_image"};
-			for (int w = 0; w < 2; w++) { printf("  wave %d cycles/step:", w * (rows == 32 ? 4 : 2)); u32 tot = 0; for (int i = 0; i < 7; i++) { printf(" %s %u", nm[i], tt[600 + w * 8 + i]); tot += tt[600 + w * 8 + i]; } printf("  total %u\n", tot); }
+			for (int w = 0; w < 2; w++) { printf("  wave %d cycles/step:", w * (rows == 32 ? 4 : 2) * zs); u32 tot = 0; for (int i = 0; i < 7; i++) { printf(" %s %u", nm[i], tt[600 + w * 8 + i]); tot += tt[600 + w * 8 + i]; } printf("  total %u\n", tot); }
 		}
 #endif
 		if (st[0])

@@ -40,13 +40,14 @@ hipError_t launch(const PackedLaunch &l, VnArgs a, hipStream_t stream)
 	const VnJit *jit = l.vn_jit;
 	if (a.lut_s == (u32)kDefaultS && a.lut_b == (u32)kDefaultB)
 		hipLaunchKernelGGL((ca_packed_vn<CVL, ZR, kDefaultS, kDefaultB>), dim3(blocks), dim3(256), 0, stream, l.in, l.out, a);
-	else if (jit && jit->cvl == CVL && jit->lut_s == a.lut_s && jit->lut_b == a.lut_b && (ZR == 1 ? jit->zr1 : jit->zr2))
+	else if (void *fn = ZR == 1 ? (jit ? jit->zr1 : nullptr) : ZR == 2 ? (jit ? jit->zr2 : nullptr) : (jit ? jit->zr4 : nullptr);
+	         fn && jit->cvl == CVL && jit->lut_s == a.lut_s && jit->lut_b == a.lut_b)
 	{
 		// the run-time compiled specialisation for exactly these tables (ca_jit.cpp): same code shape as the branch above
 		const u32 *in = l.in;
 		u32 *out = l.out;
 		void *args[] = {(void *)&in, (void *)&out, (void *)&a};
-		return hipModuleLaunchKernel((hipFunction_t)(ZR == 1 ? jit->zr1 : jit->zr2), blocks, 1, 1, 256, 1, 1, 0, stream, args, nullptr);
+		return hipModuleLaunchKernel((hipFunction_t)fn, blocks, 1, 1, 256, 1, 1, 0, stream, args, nullptr);
 	}
 	else
 		hipLaunchKernelGGL((ca_packed_vn<CVL, ZR, -1, -1>), dim3(blocks), dim3(256), 0, stream, l.in, l.out, a);
@@ -104,17 +105,21 @@ hipError_t launch_packed_vn(const PackedLaunch &l, hipStream_t stream)
 	// Non-temporal stores pay only while both ping-pong buffers sit in the 256 MiB Infinity Cache with room to
 	// spare (measured: 6.9 vs 7.5 us per step at 512^3, 58 vs 43 us at 1024^3).
 	a.nt = (size_t)l.pr.nplanes * G * (G / 32u) * sizeof(u32) <= (16u << 20) ? 1u : 0u;
-	// 2 planes per thread once that still fills the chip (>= 1024 workgroups), else 1
+	// 2 planes per thread once that still fills the chip (>= 1024 workgroups), else 1; 4 planes per thread on grids past the
+	// Infinity Cache (2048^3 and up: 412 vs 433 us per step — fewer re-reads of the neighbour planes through L2; at 512^3 the deeper
+	// run is slower, 6.7 vs 5.8 us; non-temporal stores change nothing there: 430 vs 433). CA3D_VN_ZR=2 keeps 2.
+	static const int zr_env = getenv("CA3D_VN_ZR") ? atoi(getenv("CA3D_VN_ZR")) : 0;
 	const u32 tpp = G / 128u * G / 256u;
 	const bool deep = shortest >= 2u && (size_t)tpp * ((planes + 1u) / 2u) >= 1024u;
+	const bool deep4 = zr_env != 2 && cvl >= 4 && shortest >= 4u && (size_t)tpp * ((planes + 3u) / 4u) >= 4096u;
 	switch (cvl)
 	{
 	case 1: return launch<1, 1>(l, a, stream);
 	case 2: return deep ? launch<2, 2>(l, a, stream) : launch<2, 1>(l, a, stream);
 	case 3: return deep ? launch<3, 2>(l, a, stream) : launch<3, 1>(l, a, stream);
-	case 4: return deep ? launch<4, 2>(l, a, stream) : launch<4, 1>(l, a, stream);
-	case 5: return deep ? launch<5, 2>(l, a, stream) : launch<5, 1>(l, a, stream);
-	case 6: return deep ? launch<6, 2>(l, a, stream) : launch<6, 1>(l, a, stream);
+	case 4: return deep4 ? launch<4, 4>(l, a, stream) : deep ? launch<4, 2>(l, a, stream) : launch<4, 1>(l, a, stream);
+	case 5: return deep4 ? launch<5, 4>(l, a, stream) : deep ? launch<5, 2>(l, a, stream) : launch<5, 1>(l, a, stream);
+	case 6: return deep4 ? launch<6, 4>(l, a, stream) : deep ? launch<6, 2>(l, a, stream) : launch<6, 1>(l, a, stream);
 	default: return hipErrorInvalidValue;
 	}
 }

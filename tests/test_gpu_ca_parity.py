@@ -280,7 +280,7 @@ def test_1024_cubed_one_step(eng):
     np.testing.assert_array_equal(eng.read_state(), ol.packed_step(G, st, r))
 
 
-@pytest.mark.parametrize("name", ["default", "clustered"])
+@pytest.mark.parametrize("name", ["default", "clustered", "vn_b24_s135"])
 def test_2048_cubed_two_steps(eng, name):
     """BASELINE config 5's grid (1 GiB per buffer, offsets past 2^32 bits) under the default rule and under config 5's
     own clustered rule-set (all three rule-sets of compute_clustered.wgsl:192-247 live): two steps, whole state
@@ -291,7 +291,7 @@ def test_2048_cubed_two_steps(eng, name):
     set_rules(eng, r)
     st = host.random_fill(host.words_per_buffer(G), seed=7)
     eng.upload_state(st)
-    eng.step(2)
+    eng.step(2)  # (von Neumann tables: 4 planes per thread on grids past the Infinity Cache — pre-built for the start-up rule, run-time compiled otherwise)
     assert "(jit)" in eng.info().kernel_name.decode() or name == "default"
     np.testing.assert_array_equal(eng.read_state(), ol.packed_run(G, st, r, 2))
     eng.configure(32)  # release the 2 GiB before the next test

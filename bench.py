@@ -360,7 +360,7 @@ def pmc_traffic(kernel, G, steps_per_launch=1):
         return None
     try:
         d = json.load(open(p))
-        for key in (f"{kernel}@{G}", f"{kernel.split('(')[0].split('<')[0]}@{G}"):
+        for key in (f"{kernel}@{G}", f"{kernel.split('(')[0].split('<')[0]}@{G}"):  # e.g. ca_packed_class_roll<moore,E,C>(jit) -> ca_packed_class_roll@1024
             if key in d:
                 e = d[key]
                 if "steps_per_launch" in e:  # a resident kernel: the pass was taken at that many steps per launch
@@ -469,7 +469,7 @@ def roofline_block(kernel, G, bytes_per_step, total_steps, ev_ms, state_bytes, l
     launch_ms = ev_ms / max(1, launches)
     hbm_rate = bytes_per_launch / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
     traffic = pmc_traffic(kernel, G, steps_per_launch)
-    traffic_source = None if traffic is None else ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
+    traffic_source = None if traffic is None else ("profiles/pmc_traffic.json (entry's `round`): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
                                                    "(fabric requests, Infinity Cache hits included), not measured in this run")
     common = {"kernel": kernel, "launch_us": round(launch_ms * 1e3, 3), "steps_per_launch": steps_per_launch,
               "algorithmic_bytes_per_launch": bytes_per_launch, "launches_timed": int(launches),

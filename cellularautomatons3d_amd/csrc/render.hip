@@ -66,6 +66,7 @@ struct RenderParams
 	// meet a live cell: the sparse-volume kernels answer "no hit" without walking.
 	const u32 *live_box;
 	u32 spread; // the launch includes ca_render_packed_spread: a small live box is its frame, not the plain kernel's
+	u32 park;   // scheduled kernel: lanes that stand on a live cell park until this many wait for the hit test (0: test at once)
 };
 
 constexpr float kPi = 3.14159265359f;
@@ -728,6 +729,60 @@ __device__ __forceinline__ int walk_step(const RenderParams &P, RayState &w, v3 
 	return 0;
 }
 
+// walk_step in three pieces, for the scheduled kernel's parking loop (below): the probe of the current cell (everything up
+// to "is it alive and not the exempt start cell"), the hit test of a live cell, and the advance to the next cell.
+// walk_probe: 0 dead cell (advance), 2 walk over, 3 live cell (hit test pending, nothing advanced), 4 jumped over an empty block (no advance)
+template <bool SKIP>
+__device__ __forceinline__ int walk_probe(const RenderParams &P, RayState &w, bool shadow, u32 &visits)
+{
+	const int G = (int)P.G;
+	if (w.guard >= 3 * G + 3) return 2;
+	w.guard++;
+	if (w.t >= w.tmax) return 2;
+	visits++;
+	if (SKIP)
+	{
+		if (P.occ_coarse && !coarse_occupied(P, w.ix, w.iy, w.iz))
+			return block_jump<7, 5, 5>(P, w.start, w.dir, w.tmax, w.ix, w.iy, w.iz, w.t, w.tx, w.ty, w.tz) ? 4 : 2;
+		if (!block_occupied(P, w.ix, w.iy, w.iz))
+			return block_jump<5, 3, 3>(P, w.start, w.dir, w.tmax, w.ix, w.iy, w.iz, w.t, w.tx, w.ty, w.tz) ? 4 : 2;
+	}
+	bool alive;
+	if (P.legacy) alive = P.cells[(size_t)w.ix + ((size_t)w.iy + (size_t)w.iz * G) * G] == 1u;
+	else
+	{
+		const int key = (w.ix >> 5) + (w.iy + w.iz * G) * (int)P.cols;
+		if (key != w.wkey) { w.word = P.cells[key]; w.wkey = key; }
+		alive = (w.word >> (w.ix & 31)) & 1u;
+	}
+	return alive && !(shadow && w.ix == w.cx && w.iy == w.cy && w.iz == w.cz) ? 3 : 0;
+}
+__device__ __forceinline__ bool walk_hit(const RenderParams &P, const RayState &w, v3 half, bool shadow, float &tnear_out)
+{
+	float tn, tf;
+	ray_cube_inv(w.start, w.inv, cell_origin(1.0f / (float)P.G, w.ix, w.iy, w.iz), half, tn, tf);
+	if (shadow ? (tn <= tf && tn >= 0.0f) : (tf >= 0.0f && tn <= tf))
+	{
+		tnear_out = tn;
+		return true;
+	}
+	return false;
+}
+__device__ __forceinline__ int walk_advance(const RenderParams &P, RayState &w)
+{
+	const int G = (int)P.G;
+	const int sx = w.dir.x > 0.0f ? 1 : -1, sy = w.dir.y > 0.0f ? 1 : -1, sz = w.dir.z > 0.0f ? 1 : -1;
+	const bool mx = w.tx <= w.ty && w.tx <= w.tz, my = !mx && w.ty <= w.tz, mz = !mx && !my;
+	w.t = mx ? w.tx : (my ? w.ty : w.tz);
+	w.tx += mx ? w.dx : 0.0f;
+	w.ty += my ? w.dy : 0.0f;
+	w.tz += mz ? w.dz : 0.0f;
+	w.ix += mx ? sx : 0;
+	w.iy += my ? sy : 0;
+	w.iz += mz ? sz : 0;
+	return ((u32)w.ix >= (u32)G || (u32)w.iy >= (u32)G || (u32)w.iz >= (u32)G) ? 2 : 0;
+}
+
 // The tail every sample goes through (shade_sample's last two blocks): light gizmo, show-depth split.
 __device__ __forceinline__ void sample_tail(const RenderParams &P, v3 ray, float vu, Sample &s)
 {
@@ -881,7 +936,8 @@ constexpr int kSchedChunk = 4; // samples per pixel scheduled together (LDS: 4 x
 #ifndef CA3D_SCHED_LEAVE_DIV
 #define CA3D_SCHED_LEAVE_DIV 2
 #endif
-constexpr int kSchedLeaveDiv = CA3D_SCHED_LEAVE_DIV; // the walk loop is left when fewer than 1/N of its walkers are still walking
+constexpr int kSchedLeaveDiv = CA3D_SCHED_LEAVE_DIV;
+// RenderParams::park > 0: lanes that stand on a live cell park until that many wait for the hit test (0: test at once); CA3D_RENDER_PARK // the walk loop is left when fewer than 1/N of its walkers are still walking
 
 // PPW pixels per wave tile (64: 16 x 4, 256: 32 x 8), NK samples per pixel scheduled together: a wave has PPW x NK jobs
 // in flight per chunk, and 4 x PPW x NK x 6 floats of LDS per block hold the results. More jobs per wave = more refills
@@ -970,6 +1026,48 @@ __global__ __launch_bounds__(256, WPE) void ca_render_packed_sched(RenderParams 
 				const int leave_below = (next < total || entry > 16) ? max(entry / kSchedLeaveDiv, 1) : 1;
 				int term = 0;
 				float tnear = 0.0f;
+				const int park = (int)P.park;
+				if (park > 0)
+				{
+					// Parking: at the bench scene's density a walker stands on a live cell in 3 % of its steps, so with ~30 walkers
+					// some lane needs the 45-instruction hit test in six iterations out of ten — and it ran for that one lane.
+					// A lane that finds a live cell parks instead; the hit tests run together once kSchedPark lanes wait (or nobody
+					// is left stepping, or the loop is about to be left). Every ray still sees the same cells and tests in the
+					// same order: the frame is unchanged.
+					bool parked = false;
+					for (;;)
+					{
+						const bool shadow = st.phase == 2;
+						bool advance = false;
+						if (st.job >= 0 && term == 0 && !parked)
+						{
+							const int pr = walk_probe<SKIP>(P, st, shadow, shadow ? svis : pvis);
+							if (pr == 2) term = 2;
+							else if (pr == 3) parked = true;
+							else advance = pr == 0;
+						}
+						const int npark = __popcll(__ballot(parked));
+						const int stepping = __popcll(__ballot(st.job >= 0 && term == 0 && !parked));
+						const int walking = npark + stepping;
+						const bool leaving = walking == 0 || walking < leave_below;
+						if (npark > 0 && (npark >= park || stepping == 0 || leaving))
+						{
+							if (parked)
+							{
+								if (walk_hit(P, st, vhalf, shadow, tnear)) term = 1;
+								else advance = true;
+								parked = false;
+							}
+						}
+						if (advance) term = walk_advance(P, st);
+						const int still = __popcll(__ballot(st.job >= 0 && term == 0));
+						if (still == 0 || still < leave_below) // (nobody is parked here: a wave that leaves has just run its hit tests)
+						{
+							if (__ballot(parked) == 0ull) break;
+						}
+					}
+				}
+				else
 				for (;;)
 				{
 					if (st.job >= 0 && term == 0) term = walk_step<SKIP>(P, st, vhalf, st.phase == 2, tnear, st.phase == 2 ? svis : pvis);
@@ -1433,6 +1531,8 @@ hipError_t launch_render(const RenderLaunch &l, hipStream_t stream)
 	P.occ = nullptr;
 	P.live_box = nullptr;
 	P.spread = 0;
+	static const int park_env = getenv("CA3D_RENDER_PARK") ? atoi(getenv("CA3D_RENDER_PARK")) : 0; // tuning: see RenderParams::park
+	P.park = (u32)(park_env > 0 ? park_env : 0);
 	P.occ_words = 0;
 	P.occ_coarse = 0;
 	if (!l.legacy && l.mode != 1 && l.occ)

@@ -1793,7 +1793,8 @@ int ca3d_set_option(ca3d_t *h, const char *name, int64_t value)
 	if (!strcmp(name, "roll_tile"))
 	{
 		drop_graph(h);
-		h->roll_tile = value ? 1 : 0;
+		if (value < 0 || value > 3) return fail(CA3D_ERR_INVALID_ARGUMENT, "roll_tile must be 0 (every thread shifts its rows), 1 (256-thread tiles), 2 (wave tiles) or 3 (two words per thread)");
+		h->roll_tile = (int)value;
 		return CA3D_OK;
 	}
 	if (!strcmp(name, "roll"))

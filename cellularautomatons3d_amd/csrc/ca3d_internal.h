@@ -72,6 +72,8 @@ struct RollJit
 	void *z[3] = {nullptr, nullptr, nullptr}; // hipFunction_t for Z = 2, 4, 8
 	void *tile[4] = {nullptr, nullptr, nullptr, nullptr}; // the tile form (x-shifted rows shared through LDS) for Z = 2, 4, 8, 16
 	void *loop[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; // looped forms [tile][Z = 15, 30]: the plane loop rolled up in groups of three
+	void *w2[2] = {nullptr, nullptr};    // two words per thread (five waves per SIMD) for Z = 8, 16; null on rows of 32 uint4 and more
+	void *wtile[2] = {nullptr, nullptr}; // wave tiles (one wave per workgroup, LDS exchange without a barrier) for Z = 8, 16; null on rows of 64 uint4
 	int cvl = -1;                              // log2(G / 128); -1: none
 	int main = -1;
 	bool e = false, c = false;
@@ -89,7 +91,8 @@ struct PackedLaunch
 	const ClassJit *class_jit = nullptr;
 	const RollJit *roll_jit = nullptr;
 	int roll_z = 0; // 0: the launcher picks the planes per thread of the rolling-window kernel; 2 / 4 / 8 (tile form: 16 too): forced (tests, tuning)
-	int roll_tile = 1; // 1: the tile form of the rolling-window kernel (ca_packed_roll_kernel.inc, tile_step); 0: every thread shifts its three rows itself
+	int roll_tile = 1; // 1: the tile form of the rolling-window kernel (ca_packed_roll_kernel.inc, tile_step); 0: every thread shifts its three rows itself;
+	                   // 2: wave tiles (the tile form with one wave per workgroup: no barrier); 3: two words per thread, no LDS (roll_step_w2)
 };
 
 // One launch of the resident multi-step kernel (ca_resident.hip): `steps` steps from `in`, state on chip in between

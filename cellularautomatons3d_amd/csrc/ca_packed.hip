@@ -358,11 +358,43 @@ hipError_t launch_class(const PackedLaunch &l, hipStream_t stream)
 		// thread: the largest of 8 / 4 / 2 that the shortest range holds and that still gives every SIMD its two waves
 		// (a wave alone on a SIMD issues at half rate); launches too small for that keep the one-plane kernels below.
 		static const u32 lds_pad = getenv("CA3D_ROLL_LDS") ? (u32)atoi(getenv("CA3D_ROLL_LDS")) : 0u;
+		// two words per thread (roll_tile 3): twice the workgroups per plane
+		if (l.roll_tile == 3)
+			for (int wi = 1; wi >= 0; wi--)
+			{
+				const u32 Z = wi ? 16u : 8u;
+				void *fn = rj->w2[wi];
+				if ((l.roll_z && l.roll_z != (int)Z) || shortest < Z || !fn) continue;
+				const u32 runs1 = (planes1 + Z - 1u) / Z, nruns = runs1 + (planes2 + Z - 1u) / Z;
+				RollArgs a;
+				a.lo = l.pr.lo; a.hi = l.pr.hi; a.nplanes = l.pr.nplanes; a.wrap_full = l.pr.wrap_full; a.zbase = l.pr.zbase;
+				a.lo2 = l.pr.lo2; a.hi2 = two ? l.pr.hi2 : l.pr.lo2; a.runs1 = runs1;
+				const u32 *in = l.in;
+				u32 *out = l.out;
+				void *args[] = {(void *)&in, (void *)&out, (void *)&a};
+				return hipModuleLaunchKernel((hipFunction_t)fn, g.tiles_per_plane * 2u * nruns, 1, 1, 256, 1, 1, 0, stream, args, nullptr);
+			}
+		// wave tiles (roll_tile 2): one wave per workgroup, Z = 16 or 8
+		if (l.roll_tile == 2)
+			for (int wi = 1; wi >= 0; wi--)
+			{
+				const u32 Z = wi ? 16u : 8u;
+				void *fn = rj->wtile[wi];
+				if ((l.roll_z && l.roll_z != (int)Z) || shortest < Z || !fn) continue;
+				const u32 runs1 = (planes1 + Z - 1u) / Z, nruns = runs1 + (planes2 + Z - 1u) / Z;
+				RollArgs a;
+				a.lo = l.pr.lo; a.hi = l.pr.hi; a.nplanes = l.pr.nplanes; a.wrap_full = l.pr.wrap_full; a.zbase = l.pr.zbase;
+				a.lo2 = l.pr.lo2; a.hi2 = two ? l.pr.hi2 : l.pr.lo2; a.runs1 = runs1;
+				const u32 *in = l.in;
+				u32 *out = l.out;
+				void *args[] = {(void *)&in, (void *)&out, (void *)&a};
+				return hipModuleLaunchKernel((hipFunction_t)fn, g.tiles_per_plane * 4u * nruns, 1, 1, 64, 1, 1, 0, stream, args, nullptr);
+			}
 		// looped forms (15 / 30 planes per thread): forced by roll_z 15 / 30
 		for (int li = 1; li >= 0; li--)
 		{
 			const u32 Z = li ? 30u : 15u;
-			void *fn = rj->loop[l.roll_tile ? 1 : 0][li];
+			void *fn = rj->loop[l.roll_tile == 1 ? 1 : 0][li];
 			if (l.roll_z != (int)Z || shortest < Z || !fn) continue;
 			const u32 runs1 = (planes1 + Z - 1u) / Z, nruns = runs1 + (planes2 + Z - 1u) / Z;
 			RollArgs a;
@@ -373,17 +405,17 @@ hipError_t launch_class(const PackedLaunch &l, hipStream_t stream)
 			void *args[] = {(void *)&in, (void *)&out, (void *)&a};
 			return hipModuleLaunchKernel((hipFunction_t)fn, g.tiles_per_plane * nruns, 1, 1, 256, 1, 1, 0, stream, args, nullptr);
 		}
-		for (int zi = l.roll_tile ? 3 : 2; zi >= 0; zi--)
+		for (int zi = l.roll_tile == 1 ? 3 : 2; zi >= 0; zi--)
 		{
 			const u32 Z = 2u << zi;
 			const u32 runs1 = (planes1 + Z - 1u) / Z, nruns = runs1 + (planes2 + Z - 1u) / Z;
-			void *fn = l.roll_tile ? rj->tile[zi] : rj->z[zi];
+			void *fn = l.roll_tile == 1 ? rj->tile[zi] : rj->z[zi];
 			if (shortest < Z || !fn) continue;
 			// automatic choice: only launches of more than one resident generation (measured at 512^3, 2048 waves: the plain class
 			// kernel 11.5 us, the rolling one 12.0; at 1024^3, 16384 waves: 80 vs 72). The tile form pays at 16 planes per thread
 			// (two halo planes per 16 instead of per 8, and the LDS exchange replaces two of three row shifts: 1024^3 66.3 vs 68.8 us,
 			// 2048^3 535 vs 574); at 8 planes its barrier per plane eats the saving (70.9 vs 68.8): there every thread shifts its own rows
-			const bool tile_form = l.roll_tile && (l.roll_z || Z == 16u); // a forced depth (tests, tuning) takes the form roll_tile names
+			const bool tile_form = l.roll_tile == 1 && (l.roll_z || Z == 16u); // a forced depth (tests, tuning) takes the form roll_tile names
 			if (!tile_form) fn = Z <= 8u ? rj->z[zi] : nullptr;
 			if (!fn) continue;
 			if (l.roll_z ? l.roll_z != (int)Z : (size_t)g.tiles_per_plane * nruns * 4u < 4096u) continue;

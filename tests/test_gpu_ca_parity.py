@@ -312,9 +312,11 @@ def test_rolling_window_kernel_every_depth(eng, name):
     want = ol.packed_run(G, st, r, 3)
     # both forms: every thread shifting its three rows itself (roll_tile 0) and the tile form, where a workgroup shares the
     # x-shifted rows through LDS (16 planes per thread exist in the tile form only)
-    for tile in (1, 0):
+    # (roll_tile 2: wave tiles — the tile form with one wave per workgroup, its rows exchanged through LDS without a barrier)
+    # (roll_tile 3: two words per thread instead of four — a window of 42 registers, five or six waves per SIMD)
+    for tile in (1, 0, 2, 3):
         eng.set_option("roll_tile", tile)
-        for z in (2, 4, 8, 16, 15, 30) if tile else (2, 4, 8, 15, 30):  # 15 / 30: the looped forms (plane loop in groups of three)
+        for z in {1: (2, 4, 8, 16, 15, 30), 0: (2, 4, 8, 15, 30), 2: (8, 16), 3: (8, 16)}[tile]:  # 15 / 30: the looped forms (plane loop in groups of three)
             eng.set_option("roll_z", z)
             eng.upload_state(st)
             eng.step(3)

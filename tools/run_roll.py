@@ -16,7 +16,7 @@ for G in grids:
     e.upload_state(host.random_fill(host.words_per_buffer(G)))
     steps = max(16, int(2e-2 / (G ** 3 / 1.2e13)))
     e.set_option("resident", 0)  # the per-step kernels are what is compared here
-    for roll, tile, z in ((0, 0, 0), (1, 0, 0), (1, 0, 8), (1, 0, 15), (1, 0, 30), (1, 1, 0), (1, 1, 8), (1, 1, 16), (1, 1, 15), (1, 1, 30)):
+    for roll, tile, z in ((0, 0, 0), (1, 0, 0), (1, 0, 8), (1, 0, 15), (1, 0, 30), (1, 1, 0), (1, 1, 8), (1, 1, 16), (1, 1, 15), (1, 1, 30), (1, 2, 8), (1, 2, 16), (1, 3, 8), (1, 3, 16)):
         e.set_option("roll", roll)
         e.set_option("roll_tile", tile)
         e.set_option("roll_z", z)

@@ -73,6 +73,14 @@ constexpr float kPi = 3.14159265359f;
 constexpr float kHalf = 0.5f;
 constexpr float kOcclusion = 0.0095f;
 
+// (v + 0.5) / cellSize, the shaders' `(p + 0.5) / cs` — for a power-of-two grid cs = 2^-k and the division is a multiplication by
+// G, bit for bit (scaling by a power of two is exact); other grids keep the division. Wave-uniform choice.
+__device__ __forceinline__ float to_cells(const RenderParams &P, float v)
+{
+	const float cs = 1.0f / (float)P.G;
+	return (P.G & (P.G - 1u)) == 0u ? (v + kHalf) * (float)P.G : (v + kHalf) / cs;
+}
+
 __device__ __forceinline__ u32 cell_state(const RenderParams &P, u32 x, u32 y, u32 z)
 {
 	// legacy: cellStates[x + y*G + z*G*G], no wrap (pathtraced_fragment.wgsl:157-168). A point on the volume's
@@ -84,6 +92,11 @@ __device__ __forceinline__ u32 cell_state(const RenderParams &P, u32 x, u32 y, u
 		return P.cells[(size_t)x + (size_t)y * P.G + (size_t)z * P.G * P.G] == 1u ? 1u : 0u;
 	}
 	// :268-290 — every coordinate wraps modulo the grid
+	if ((P.G & (P.G - 1u)) == 0u) // power-of-two grid: the three modulo operations are masks (a u32 % by a run-time value is ~25 instructions)
+	{
+		const u32 idx = ((x >> 5) & (P.cols - 1u)) + (y & (P.G - 1u)) * P.cols + (z & (P.G - 1u)) * P.cols * P.G;
+		return (P.cells[idx] >> (x & 31u)) & 1u;
+	}
 	const u32 idx = ((x >> 5) % P.cols) + (y % P.G) * P.cols + (z % P.G) * P.cols * P.G;
 	return (P.cells[idx] >> (x & 31u)) & 1u;
 }
@@ -252,9 +265,9 @@ __device__ __forceinline__ bool block_jump(const RenderParams &P, v3 start, v3 d
 	const float te = mx ? tex : (my ? tey : tez);
 	if (te >= tmax) return false;
 	const v3 p = start + dir * te;
-	int nx = min(max((int)floorf((p.x + kHalf) / cs), bx0), bx0 + BX - 1);
-	int ny = min(max((int)floorf((p.y + kHalf) / cs), by0), by0 + BY - 1);
-	int nz = min(max((int)floorf((p.z + kHalf) / cs), bz0), bz0 + BZ - 1);
+	int nx = min(max((int)floorf(to_cells(P, p.x)), bx0), bx0 + BX - 1);
+	int ny = min(max((int)floorf(to_cells(P, p.y)), by0), by0 + BY - 1);
+	int nz = min(max((int)floorf(to_cells(P, p.z)), bz0), bz0 + BZ - 1);
 	if (mx) nx = sx > 0 ? bx0 + BX : bx0 - 1;
 	else if (my) ny = sy > 0 ? by0 + BY : by0 - 1;
 	else nz = sz > 0 ? bz0 + BZ : bz0 - 1;
@@ -276,7 +289,7 @@ __device__ bool walk(const RenderParams &P, v3 start, v3 dir, float t0, float tm
 	const int G = (int)P.G;
 	const float cs = 1.0f / (float)P.G;
 	const v3 p = start + dir * t0;
-	int ix = (int)floorf((p.x + kHalf) / cs), iy = (int)floorf((p.y + kHalf) / cs), iz = (int)floorf((p.z + kHalf) / cs);
+	int ix = (int)floorf(to_cells(P, p.x)), iy = (int)floorf(to_cells(P, p.y)), iz = (int)floorf(to_cells(P, p.z));
 	ix = min(max(ix, 0), G - 1);
 	iy = min(max(iy, 0), G - 1);
 	iz = min(max(iz, 0), G - 1);
@@ -384,7 +397,7 @@ __device__ Sample shade_sample(const RenderParams &P, float vu, float vv, u32 &p
 		s.depth = len3(final_point - cam);  // :762, 774
 		const v3 p = cam + ray * s.depth;   // moreAccurateSamplePoint :840
 		// calculateLightingAndOcclusionAt :379-427
-		const v3 f = V(floorf((p.x + kHalf) / cs), floorf((p.y + kHalf) / cs), floorf((p.z + kHalf) / cs));
+		const v3 f = V(floorf(to_cells(P, p.x)), floorf(to_cells(P, p.y)), floorf(to_cells(P, p.z)));
 		const v3 origin = V(f.x * cs + cs * 0.5f - kHalf, f.y * cs + cs * 0.5f - kHalf, f.z * cs + cs * 0.5f - kHalf);
 		const int cx = (int)f.x, cy = (int)f.y, cz = (int)f.z;
 		const u32 st = cell_state(P, (u32)cx, (u32)cy, (u32)cz);
@@ -655,7 +668,7 @@ __device__ __forceinline__ void walk_begin(const RenderParams &P, RayState &w, v
 	const int G = (int)P.G;
 	const float cs = 1.0f / (float)P.G;
 	const v3 p = start + dir * t0;
-	int ix = (int)floorf((p.x + kHalf) / cs), iy = (int)floorf((p.y + kHalf) / cs), iz = (int)floorf((p.z + kHalf) / cs);
+	int ix = (int)floorf(to_cells(P, p.x)), iy = (int)floorf(to_cells(P, p.y)), iz = (int)floorf(to_cells(P, p.z));
 	ix = min(max(ix, 0), G - 1);
 	iy = min(max(iy, 0), G - 1);
 	iz = min(max(iz, 0), G - 1);
@@ -852,7 +865,7 @@ __device__ bool sample_after_primary(const RenderParams &P, RayState &st, const 
 	const v3 final_point = hit ? st.start + st.dir * tnear : exitp;
 	s.depth = len3(final_point - cam);
 	const v3 p = cam + ray * s.depth;
-	const v3 f = V(floorf((p.x + kHalf) / cs), floorf((p.y + kHalf) / cs), floorf((p.z + kHalf) / cs));
+	const v3 f = V(floorf(to_cells(P, p.x)), floorf(to_cells(P, p.y)), floorf(to_cells(P, p.z)));
 	const v3 origin = V(f.x * cs + cs * 0.5f - kHalf, f.y * cs + cs * 0.5f - kHalf, f.z * cs + cs * 0.5f - kHalf);
 	const int cx = (int)f.x, cy = (int)f.y, cz = (int)f.z;
 	const u32 state = cell_state(P, (u32)cx, (u32)cy, (u32)cz);
@@ -1261,7 +1274,7 @@ struct CellU
 __device__ CellU cell_u(const RenderParams &P, v3 p)
 {
 	const float cs = 1.0f / (float)P.G;
-	const v3 f = V(floorf((p.x + kHalf) / cs), floorf((p.y + kHalf) / cs), floorf((p.z + kHalf) / cs));
+	const v3 f = V(floorf(to_cells(P, p.x)), floorf(to_cells(P, p.y)), floorf(to_cells(P, p.z)));
 	CellU r;
 	r.origin = V(f.x * cs + cs * 0.5f - kHalf, f.y * cs + cs * 0.5f - kHalf, f.z * cs + cs * 0.5f - kHalf);
 	r.x = f2u(f.x); r.y = f2u(f.y); r.z = f2u(f.z);
@@ -1311,7 +1324,7 @@ __global__ __launch_bounds__(256) void ca_render_frame_packed(FrameParams F)
 			{
 				pvis++;
 				const v3 sp = enter + dir * depth;
-				const v3 cc = V(floorf((sp.x + kHalf) / cs), floorf((sp.y + kHalf) / cs), floorf((sp.z + kHalf) / cs));
+				const v3 cc = V(floorf(to_cells(P, sp.x)), floorf(to_cells(P, sp.y)), floorf(to_cells(P, sp.z)));
 				const v3 origin = V(cc.x * cs + cs * 0.5f - kHalf, cc.y * cs + cs * 0.5f - kHalf, cc.z * cs + cs * 0.5f - kHalf);
 				if (cell_state(P, f2u(cc.x), f2u(cc.y), f2u(cc.z)) != 0u)
 				{
@@ -1378,7 +1391,7 @@ __global__ __launch_bounds__(256) void ca_render_frame_packed(FrameParams F)
 					{
 						svis++;
 						const v3 sp = p + dir * depth;
-						const v3 cc = V(floorf((sp.x + kHalf) / cs), floorf((sp.y + kHalf) / cs), floorf((sp.z + kHalf) / cs));
+						const v3 cc = V(floorf(to_cells(P, sp.x)), floorf(to_cells(P, sp.y)), floorf(to_cells(P, sp.z)));
 						const u32 ux = f2u(cc.x), uy = f2u(cc.y), uz = f2u(cc.z);
 						const u32 st2 = cell_state(P, ux, uy, uz);
 						const v3 origin = V(cc.x * cs + cs * 0.5f - kHalf, cc.y * cs + cs * 0.5f - kHalf, cc.z * cs + cs * 0.5f - kHalf);

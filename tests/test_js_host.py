@@ -69,6 +69,19 @@ def test_js_engine_group_drives_the_slab_split_from_one_thread(tmp_path):
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout + r.stderr)[-3000:]
 
 
+@pytest.mark.gpu
+def test_node_bench_drives_several_slabs_from_one_thread():
+    """js/bench.js --devices: the multi-GPU measurement of the north-star host (EngineGroup), rehearsed with four slabs on GPU 0;
+    the state is first compared with a single grid's."""
+    import json
+
+    r = _node("cellularautomatons3d_amd/js/bench.js", "--devices", "0,0,0,0", "--grid", "512", "--ghost", "8", "--steps", "64", "--reps", "3",
+              "--warmup", "16", "--check", "20")
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["slabs"] == 4 and d["n_gpus"] == 1 and d["verified"]["state_matches_single_grid"] is True and d["value"] > 10
+
+
 def test_facade_runs_the_unmodified_reference_host_with_a_mock_engine():
     """SURVEY 8(f) N2 (build container only): main_pathtraced.js + ui.js + MemoryManager.js, unmodified, drive the
     navigator.gpu facade through init and five frames; a recording mock stands in for the engine."""

@@ -345,7 +345,7 @@ void select_kernels(ca3d_engine *h)
 			if (jit_roll_kernels(h->device, h->rules, vn_grid_log2(h->G), &rj, &h->jit_log) == CA3D_OK) h->roll_jit = rj;
 		}
 		if (h->use_resident && !h->slab && resident_class_applies(h->rules, h->G, h->variant) &&
-		    jit_resident_class_kernel(h->device, h->rules, &h->res_jit_fn, &h->jit_log) == CA3D_OK)
+		    jit_resident_class_kernel(h->device, h->rules, h->G, resident_class_zsplit(h->G), &h->res_jit_fn, &h->jit_log) == CA3D_OK)
 		{
 			h->res_ready = true;
 			h->res_class = true;
@@ -380,7 +380,7 @@ void check_residency(ca3d_engine *h)
 	if (h->res_ready)
 	{
 		const uint32_t rows = (h->res_class || h->G == 256u) ? 32u : h->res_rows;
-		if (resident_capacity(h->G, rows, h->res_class ? 1u : h->res_zsplit, h->res_jit_fn, h->stream, &tiles, &cap) && cap < tiles)
+		if (resident_capacity(h->G, rows, h->res_class ? resident_class_zsplit(h->G) : h->res_zsplit, h->res_jit_fn, h->stream, &tiles, &cap) && cap < tiles)
 		{
 			h->res_ready = false;
 			h->res_class = false;
@@ -640,7 +640,7 @@ int resident_steps(ca3d_engine *h, uint32_t n)
 	if (!h->res_class) vn_tables(h->rules, &l.lut_s, &l.lut_b);
 	l.jit_fn = h->res_jit_fn;
 	l.rows = h->res_class ? 32u : h->res_rows;
-	l.zsplit = h->res_class ? 1u : h->res_zsplit;
+	l.zsplit = h->res_class ? resident_class_zsplit(h->G) : h->res_zsplit;
 	hipError_t e = launch_resident(l, h->stream);
 	if (e != hipSuccess) return fail(CA3D_ERR_DEVICE, "resident kernel launch failed: %s", hipGetErrorString(e));
 	h->res_pending.push_back({h->res_epoch, n, h->cur, h->step, in, other, h->spare});

@@ -182,9 +182,10 @@ hipError_t launch_resident(const ResidentLaunch &l, hipStream_t stream);
 bool resident_capacity(uint32_t G, uint32_t rows, uint32_t zsplit, void *jit_fn, hipStream_t stream, uint32_t *tiles, uint32_t *capacity);
 bool resident_slab_capacity(void *fn, hipStream_t stream, uint32_t *tiles, uint32_t *capacity);
 int jit_resident_kernel(int device, uint32_t lut_s, uint32_t lut_b, uint32_t rows, uint32_t zsplit, void **fn, std::string *log);
-// the resident kernel for rules with diagonal neighbour classes (ca_resident_class_kernel.inc; 512^3, run-time compiled)
+// the resident kernel for rules with diagonal neighbour classes (ca_resident_class_kernel.inc; 512^3 and 256^3, run-time compiled)
 bool resident_class_applies(const CanonRules &r, uint32_t G, int variant);
-int jit_resident_class_kernel(int device, const CanonRules &r, void **fn, std::string *log);
+int jit_resident_class_kernel(int device, const CanonRules &r, uint32_t G, uint32_t zsplit, void **fn, std::string *log); // G: 512 (zsplit 1) or 256 (2 | 1)
+uint32_t resident_class_zsplit(uint32_t G); // z groups of the class form's tiles
 // Slab form (one rank's share of a 1024^3 grid, K sub-steps per launch): run-time compiled only, per planes-per-tile count
 struct ResidentSlabLaunch
 {

@@ -82,7 +82,15 @@ bool resident_kernel_applies(const CanonRules &r, uint32_t G, int variant) { ret
 
 bool resident_class_applies(const CanonRules &r, uint32_t G, int variant)
 {
-	return G == 512u && use_class_kernel(r, G, variant) && !vn_kernel_applies(r, G, variant) && roll_kernel_applies(r, G, variant);
+	return (G == 512u || G == 256u) && use_class_kernel(r, G, variant) && !vn_kernel_applies(r, G, variant) && roll_kernel_applies(r, G, variant);
+}
+
+// 256^3: two z groups per tile (512 threads, two waves per SIMD; CA3D_RC256_ZS=1 for the one-group form); 512^3: one
+uint32_t resident_class_zsplit(uint32_t G)
+{
+	if (G != 256u) return 1u;
+	const char *e = getenv("CA3D_RC256_ZS");
+	return e && atoi(e) == 1 ? 1u : 2u;
 }
 
 size_t resident_mail_bytes(uint32_t G, uint32_t rows)

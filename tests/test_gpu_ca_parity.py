@@ -306,6 +306,7 @@ def test_rolling_window_kernel_every_depth(eng, name):
     r = rules(name)
     G = 256
     eng.configure(G)
+    eng.set_option("resident", 0)  # the per-step kernels are what is tested here (long batches would take the resident class kernel)
     set_rules(eng, r)
     assert b"roll" in eng.info().kernel_name, eng.info().kernel_name
     st = host.random_fill(host.words_per_buffer(G), seed=61)
@@ -329,6 +330,7 @@ def test_rolling_window_kernel_every_depth(eng, name):
     eng.step(3)
     np.testing.assert_array_equal(eng.read_state(), want)
     eng.set_option("roll", 1)
+    eng.set_option("resident", 1)
 
 
 @pytest.mark.parametrize("name,G", [("clustered", 1024), ("edges_main", 512)])
@@ -401,7 +403,7 @@ def test_resident_multi_step_kernel(eng, tables, rows, zsplit):
     eng.set_option("resident_zsplit", 1)
 
 
-@pytest.mark.parametrize("name,G,n", [("default", 512, 40), ("default", 256, 33), ("clustered", 512, 16)])
+@pytest.mark.parametrize("name,G,n", [("default", 512, 40), ("default", 256, 33), ("clustered", 512, 16), ("clustered", 256, 20)])
 def test_resident_launch_that_gives_up_is_recovered(name, G, n):
     """A resident launch only completes when all its workgroups are on the chip. Simulate one that is not (option
     "resident_fault_tile": that tile leaves at once, exactly what a workgroup stuck in the dispatcher's queue looks like to
@@ -445,12 +447,13 @@ def test_resident_launch_that_gives_up_is_recovered(name, G, n):
         assert e.recovered_launches() == 1
 
 
-@pytest.mark.parametrize("name", ["clustered", "moore_b4s4", "edges_main", "corners_main", "vn_edges_only", "moore_wide"])
-def test_resident_class_kernel(eng, name):
-    """The resident kernel for rules with diagonal neighbour classes (ca_resident_class_kernel.inc): 512^3, K steps per
-    launch, halo planes and corner rows from all eight neighbour tiles; dense and sparse states (faces of zeros still carry
-    their tags), odd and even batch lengths, against the oracle and against the per-step kernels."""
-    G = 512
+@pytest.mark.parametrize("name,G", [(n, 512) for n in ("clustered", "moore_b4s4", "edges_main", "corners_main", "vn_edges_only", "moore_wide")]
+                         + [(n, 256) for n in ("clustered", "edges_main", "corners_main", "moore_wide")])
+def test_resident_class_kernel(eng, name, G):
+    """The resident kernel for rules with diagonal neighbour classes (ca_resident_class_kernel.inc): 512^3 (tiles of 16 words
+    x 32 rows x 32 planes) and 256^3 (8 x 32 x 8), K steps per launch, halo planes and corner rows from all eight neighbour
+    tiles; dense and sparse states (faces of zeros still carry their tags), odd and even batch lengths, against the oracle
+    and against the per-step kernels."""
     r = rules(name)
     eng.configure(G)
     set_rules(eng, r)

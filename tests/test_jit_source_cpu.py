@@ -63,8 +63,24 @@ namespace ca3d_jit
 }
 """
 
+RESIDENT_CLASS_PROGRAM = b"""
+#include "ca_device_types.h"
+namespace ca3d
+{
+namespace jit
+{
+#include "ca_bitops.inc"
+#include "ca_jit_rule.inc"
+#include "ca_bitslice.inc"
+#include "ca_packed_roll_kernel.inc"
+#include "ca_resident_kernel.inc"
+#include "ca_resident_class_kernel.inc"
+}
+}
+"""
+
 HEADERS = [b"ca_bitops.inc", b"ca_packed_vn_kernel.inc", b"ca_device_types.h", b"ca_bitslice.inc", b"ca_packed_class_kernel.inc",
-           b"ca_packed_roll_kernel.inc", b"ca_resident_kernel.inc"]
+           b"ca_packed_roll_kernel.inc", b"ca_resident_kernel.inc", b"ca_resident_class_kernel.inc"]
 
 
 #: the clustered rule as rule_synth.cpp writes it (the generated header the engine passes as "ca_jit_rule.inc")
@@ -146,3 +162,12 @@ def test_roll_kernel_source_compiles_with_hiprtc(cvl, main, e, c, tables):
 def test_resident_kernel_source_compiles_with_hiprtc():
     code = _compile(_hiprtc(), RESIDENT_PROGRAM, b"ca3d_jit_resident.hip", [b"-DCA3D_JIT_LS=%d" % 0x2A, b"-DCA3D_JIT_LB=%d" % 0x14])
     assert b"ca3d_jit_resident" in code
+
+
+def test_resident_class_kernel_source_compiles_with_hiprtc():
+    """Both tile geometries (512^3: 16 words x 32 planes, 256^3: 8 x 8) of the resident class kernel, for the clustered rule."""
+    main, e, c, tables = 2, "true", "true", (0x000000F0, 0x000000E0, 0x0038, 0x0010, 0x0014, 0x0008)
+    defines = [b"-DCA3D_JIT_MAIN=%d" % main, b"-DCA3D_JIT_E=" + e.encode(), b"-DCA3D_JIT_C=" + c.encode()]
+    defines += [b"-DCA3D_JIT_%s=%du" % (n, t) for n, t in zip([b"TS0", b"TB0", b"TS1", b"TB1", b"TS2", b"TB2"], tables)]
+    code = _compile(_hiprtc(), RESIDENT_CLASS_PROGRAM, b"ca3d_jit_resident_class.hip", defines, CLUSTERED_RULE_FN)
+    assert b"ca3d_jit_resident_class256" in code and b"ca3d_jit_resident_class" in code

@@ -18,7 +18,7 @@ TABLES = {"clustered": (2, "true", "true", (0x000000F0, 0x000000E0, 0x0038, 0x00
           "moore": (2, "false", "false", (0x000000F0, 0x000000E0, 0, 0, 0, 0))}
 
 ap = argparse.ArgumentParser()
-ap.add_argument("program", choices=["roll", "class"])
+ap.add_argument("program", choices=["roll", "class", "rclass"])
 ap.add_argument("--cvl", type=int, default=2)
 ap.add_argument("--rule", default="clustered")
 ap.add_argument("--dump", default="")
@@ -31,6 +31,8 @@ defines += [b"-DCA3D_JIT_%s=%du" % (n, t) for n, t in zip([b"TS0", b"TB0", b"TS1
 defines += [x.encode() for x in a.extra.split()]
 if a.program == "roll":
     code = T._compile(T._hiprtc(), T.ROLL_PROGRAM, b"ca3d_jit_roll.hip", defines + [b"-DCA3D_JIT_CVL=%d" % a.cvl], *([T.CLUSTERED_RULE_FN] if a.rule == "clustered" and a.synth else []))
+elif a.program == "rclass":
+    code = T._compile(T._hiprtc(), T.RESIDENT_CLASS_PROGRAM, b"ca3d_jit_resident_class.hip", defines, *([T.CLUSTERED_RULE_FN] if a.rule == "clustered" and a.synth else []))
 else:
     code = T._compile(T._hiprtc(), T.CLASS_PROGRAM, b"ca3d_jit_class.hip", defines + [b"-DCA3D_JIT_ZR=4"])
 out = a.dump or "/tmp/ca3d_jit_disasm"

@@ -37,6 +37,12 @@ hipError_t launch(const PackedLaunch &l, VnArgs a, hipStream_t stream)
 	a.runs1 = (l.pr.hi - l.pr.lo + ZR - 1u) / ZR;
 	constexpr u32 CV = 1u << CVL, TPP = 128u * CV * CV / 256u;
 	const u32 blocks = TPP * (a.runs1 + (l.pr.hi2 > l.pr.lo2 ? (l.pr.hi2 - l.pr.lo2 + ZR - 1u) / ZR : 0u));
+	// z-fastest block order (ca_packed_vn_kernel.inc; one output range, runs divisible by the XCDs), CA3D_VN_ORDER=1. Measured at
+	// 2048^3: the fabric reads of a step fall from 1.29 x to 1.01 x the state (FETCH_SIZE) and the step is no faster (419 vs 414 us,
+	// same box), so it stays off: what bounds that grid is not the re-read of neighbour planes.
+	static const int order_env = getenv("CA3D_VN_ORDER") ? atoi(getenv("CA3D_VN_ORDER")) : 0;
+	const bool one_range = !(l.pr.hi2 > l.pr.lo2) && (l.pr.hi - l.pr.lo) % ZR == 0;
+	a.zfast = one_range && a.runs1 % 8u == 0 && order_env == 1 ? a.runs1 / 8u : 0u;
 	const VnJit *jit = l.vn_jit;
 	if (a.lut_s == (u32)kDefaultS && a.lut_b == (u32)kDefaultB)
 		hipLaunchKernelGGL((ca_packed_vn<CVL, ZR, kDefaultS, kDefaultB>), dim3(blocks), dim3(256), 0, stream, l.in, l.out, a);

@@ -85,12 +85,14 @@ bool resident_class_applies(const CanonRules &r, uint32_t G, int variant)
 	return (G == 512u || G == 256u) && use_class_kernel(r, G, variant) && !vn_kernel_applies(r, G, variant) && roll_kernel_applies(r, G, variant);
 }
 
-// 256^3: two z groups per tile (512 threads, two waves per SIMD; CA3D_RC256_ZS=1 for the one-group form); 512^3: one
+// 256^3: two z groups per tile (512 threads, two waves per SIMD; CA3D_RC256_ZS=1 / 4 for the one- / four-group forms: 2.92 / 2.60 us per
+// step against 2.26); 512^3: one
 uint32_t resident_class_zsplit(uint32_t G)
 {
 	if (G != 256u) return 1u;
 	const char *e = getenv("CA3D_RC256_ZS");
-	return e && atoi(e) == 1 ? 1u : 2u;
+	const int v = e ? atoi(e) : 0;
+	return v == 1 ? 1u : v == 4 ? 4u : 2u;
 }
 
 size_t resident_mail_bytes(uint32_t G, uint32_t rows)
@@ -193,7 +195,7 @@ hipError_t launch_resident(const ResidentLaunch &l, hipStream_t stream)
 	a.timeout_ticks = l.timeout_ticks;
 	a.fault_tile = l.fault_tile;
 	const bool z2 = l.zsplit == 2u;
-	if (l.zsplit != 1u && l.zsplit != 2u) return hipErrorInvalidValue;
+	if (l.zsplit != 1u && l.zsplit != 2u && !(l.zsplit == 4u && l.G == 256u && l.jit_fn)) return hipErrorInvalidValue;
 	if (l.G == 256u)
 	{
 		// 8 x 32 tiles of 32 rows x 8 planes, 256 (x 2 with the z split) threads each (ca_resident_kernel.inc: CW = 8, PZ = 8)

@@ -110,9 +110,9 @@ __global__ __launch_bounds__(kBThreads) void ca_unpacked_ballot(const u32 *__res
 				for (int k = 0; k < 4; k++)
 				{
 					u32 n = (vals[k].x != 0u ? 1u : 0u) | (vals[k].y != 0u ? 2u : 0u) | (vals[k].z != 0u ? 4u : 0u) | (vals[k].w != 0u ? 8u : 0u);
-					n |= (u32)__shfl_down((int)n, 1) << 4;
-					n |= (u32)__shfl_down((int)n, 2) << 8;
-					n |= (u32)__shfl_down((int)n, 4) << 16;
+					n |= dpp_mov<0x101>(n) << 4;  // row_shl:1 = lane + 1 (the eight lanes of a word sit in one DPP row)
+					n |= dpp_mov<0x102>(n) << 8;
+					n |= dpp_mov<0x104>(n) << 16;
 					if ((lane & 7u) == 0 && x0 + (u32)k < X256) dst[(x0 + (u32)k) * 8u] = n;
 				}
 			}
@@ -147,9 +147,9 @@ __global__ __launch_bounds__(kBThreads) void ca_unpacked_ballot(const u32 *__res
 			{
 				const u32 row = base + NW * ((u32)q >> xshift), xc = (u32)q & (xper - 1u);
 				u32 n = (vals[q].x != 0u ? 1u : 0u) | (vals[q].y != 0u ? 2u : 0u) | (vals[q].z != 0u ? 4u : 0u) | (vals[q].w != 0u ? 8u : 0u);
-				n |= (u32)__shfl_down((int)n, 1) << 4;
-				n |= (u32)__shfl_down((int)n, 2) << 8;
-				n |= (u32)__shfl_down((int)n, 4) << 16;
+				n |= dpp_mov<0x101>(n) << 4;  // row_shl:1 = lane + 1 (the eight lanes of a word sit in one DPP row)
+				n |= dpp_mov<0x102>(n) << 8;
+				n |= dpp_mov<0x104>(n) << 16;
 				if ((lane & 7u) == 0 && row < nrows && (u32)q < rif * xper) in_bits[row * C + (lane >> 3) + xc * 8u] = n;
 			}
 		}
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(kBThreads) void ca_unpacked_pipe(const u32 *__restr
 		for (int k = 0; k < 4; k++)
 		{
 			u32 n = (v[k].x != 0u ? 1u : 0u) | (v[k].y != 0u ? 2u : 0u) | (v[k].z != 0u ? 4u : 0u) | (v[k].w != 0u ? 8u : 0u);
-			n |= (u32)__shfl_down((int)n, 1) << 4;
+			n |= (u32)__shfl_down((int)n, 1) << 4; // through the LDS crossbar: DPP moves here (as in ca_unpacked_ballot) measure 2 % slower at 512^3 — they sit on the VALU path the stores wait for
 			n |= (u32)__shfl_down((int)n, 2) << 8;
 			n |= (u32)__shfl_down((int)n, 4) << 16;
 			if ((lane & 7u) == 0 && (u32)k < X256) dst[(u32)k * 8u] = n;

@@ -122,6 +122,7 @@ struct ca3d_engine
 	uint32_t queue_max = 0;               // > 0: ca3d_step calls are encoded and submitted together (option "queue")
 	uint32_t queued = 0;                  // steps encoded, not yet submitted
 	uint64_t launches_total = 0;          // kernel launches the step calls issued since ca3d_create
+	bool res_pair = true;                 // 512^3 von Neumann form: the row-pair kernel (option "resident_pair"; 2.48 against 2.52 us per step)
 	uint32_t res_rows = 32;               // rows per tile of the von Neumann form (ca_resident_kernel.inc: 32 or 16)
 	uint32_t res_zsplit = 1;              // thread groups along z of the von Neumann form (option "resident_zsplit"; 2 = twice the threads, four waves per
 	                                      // SIMD: measured SLOWER with 32-row tiles — 2.61 vs 2.52 us per step at 512^3, 1.37 vs 1.26 at 256^3 — and faster
@@ -296,6 +297,9 @@ int enqueue_step(ca3d_engine *h, int src, uint32_t lo, uint32_t hi, hipStream_t 
 // (Re)select the kernels for the current rules and grid; compiles the rule's specialisation when one applies. Called
 // whenever rules, grid or the relevant options change — never from the step path (the WebGPU analogue is pipeline
 // creation). A failed compile leaves the ahead-of-time kernels in charge.
+// the 512^3 von Neumann form runs as the row-pair kernel (32-row tiles, one z group: its own geometry)
+bool vn_pair(const ca3d_engine *h) { return h->res_pair && h->G == 512u && h->res_rows == 32u && h->res_zsplit == 1u; } // another geometry asked for: the general form
+
 void select_kernels(ca3d_engine *h)
 {
 	h->vn_jit = VnJit{};
@@ -363,7 +367,7 @@ void select_kernels(ca3d_engine *h)
 		h->vn_jit = j;
 		h->kernel_name = "ca_packed_vn(jit)";
 	}
-	if (resident && jit_resident_kernel(h->device, ls, lb, h->G == 256u ? 256u : h->res_rows, h->res_zsplit, &h->res_jit_fn, &h->jit_log) == CA3D_OK) h->res_ready = true;
+	if (resident && jit_resident_kernel(h->device, ls, lb, h->G == 256u ? 256u : h->res_rows, h->res_zsplit, vn_pair(h), &h->res_jit_fn, &h->jit_log) == CA3D_OK) h->res_ready = true;
 }
 
 // A resident launch only completes when ALL its workgroups are on the chip at once (they wait for each other's faces). Ask the
@@ -379,8 +383,8 @@ void check_residency(ca3d_engine *h)
 	char buf[256];
 	if (h->res_ready)
 	{
-		const uint32_t rows = (h->res_class || h->G == 256u) ? 32u : h->res_rows;
-		if (resident_capacity(h->G, rows, h->res_class ? resident_class_zsplit(h->G) : h->res_zsplit, h->res_jit_fn, h->stream, &tiles, &cap) && cap < tiles)
+		const uint32_t rows = (h->res_class || h->G == 256u || vn_pair(h)) ? 32u : h->res_rows;
+		if (resident_capacity(h->G, rows, h->res_class ? resident_class_zsplit(h->G) : h->res_zsplit, !h->res_class && vn_pair(h), h->res_jit_fn, h->stream, &tiles, &cap) && cap < tiles)
 		{
 			h->res_ready = false;
 			h->res_class = false;
@@ -639,8 +643,9 @@ int resident_steps(ca3d_engine *h, uint32_t n)
 	l.lut_s = l.lut_b = 0;
 	if (!h->res_class) vn_tables(h->rules, &l.lut_s, &l.lut_b);
 	l.jit_fn = h->res_jit_fn;
-	l.rows = h->res_class ? 32u : h->res_rows;
+	l.rows = (h->res_class || vn_pair(h)) ? 32u : h->res_rows;
 	l.zsplit = h->res_class ? resident_class_zsplit(h->G) : h->res_zsplit;
+	l.pair = !h->res_class && vn_pair(h);
 	hipError_t e = launch_resident(l, h->stream);
 	if (e != hipSuccess) return fail(CA3D_ERR_DEVICE, "resident kernel launch failed: %s", hipGetErrorString(e));
 	h->res_pending.push_back({h->res_epoch, n, h->cur, h->step, in, other, h->spare});
@@ -1758,6 +1763,21 @@ int ca3d_set_option(ca3d_t *h, const char *name, int64_t value)
 			HIP_TRY(hipStreamSynchronize(h->stream));
 			free_resident(h);
 			h->res_rows = (uint32_t)value;
+			refresh_kernels(h);
+			note_jit_failure(h);
+		}
+		return CA3D_OK;
+	}
+	if (!strcmp(name, "resident_pair"))
+	{
+		if (value != 0 && value != 1) return fail(CA3D_ERR_INVALID_ARGUMENT, "resident_pair must be 0 or 1");
+		if ((value != 0) != h->res_pair)
+		{
+			int rc2 = bind_device(h);
+			if (rc2) return rc2;
+			HIP_TRY(hipStreamSynchronize(h->stream));
+			free_resident(h); // the tiling may change with it (32-row tiles): start from clean mailboxes
+			h->res_pair = value != 0;
 			refresh_kernels(h);
 			note_jit_failure(h);
 		}

@@ -133,8 +133,9 @@ uint32_t usable_cus(hipStream_t stream)
 }
 } // namespace
 
-bool resident_capacity(uint32_t G, uint32_t rows, uint32_t zsplit, void *jit_fn, hipStream_t stream, uint32_t *tiles, uint32_t *capacity)
+bool resident_capacity(uint32_t G, uint32_t rows, uint32_t zsplit, bool pair, void *jit_fn, hipStream_t stream, uint32_t *tiles, uint32_t *capacity)
 {
+	if (pair) { rows = 32u; zsplit = 1u; } // the row-pair form: the tiles and the 512 threads of the 32-row form
 	const uint32_t threads = (G == 256u ? 256u : 16u * rows) * zsplit;
 	const bool z2 = zsplit == 2u;
 	*tiles = G == 256u ? 256u : (G / rows) * (G / kResTileRows);
@@ -142,6 +143,7 @@ bool resident_capacity(uint32_t G, uint32_t rows, uint32_t zsplit, void *jit_fn,
 	int per_cu = 0;
 	hipError_t e;
 	if (jit_fn) e = hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (hipFunction_t)jit_fn, (int)threads, 0);
+	else if (pair) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)ca_resident_vn_pair<kDefaultS, kDefaultB>, (int)threads, 0);
 	else if (G == 256u) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, z2 ? (const void *)ca_resident_vn256<kDefaultS, kDefaultB, 2> : (const void *)ca_resident_vn256<kDefaultS, kDefaultB, 1>, (int)threads, 0);
 	else if (rows == 16u) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, z2 ? (const void *)ca_resident_vn<kDefaultS, kDefaultB, 16, 2> : (const void *)ca_resident_vn<kDefaultS, kDefaultB, 16, 1>, (int)threads, 0);
 	else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, z2 ? (const void *)ca_resident_vn<kDefaultS, kDefaultB, 32, 2> : (const void *)ca_resident_vn<kDefaultS, kDefaultB, 32, 1>, (int)threads, 0);
@@ -209,6 +211,20 @@ hipError_t launch_resident(const ResidentLaunch &l, hipStream_t stream)
 		return chained_launch(stream, [&]() {
 			if (z2) hipLaunchKernelGGL((ca_resident_vn256<kDefaultS, kDefaultB, 2>), dim3(256), dim3(threads), 0, stream, a);
 			else hipLaunchKernelGGL((ca_resident_vn256<kDefaultS, kDefaultB, 1>), dim3(256), dim3(threads), 0, stream, a);
+			return hipGetLastError();
+		});
+	}
+	if (l.pair)
+	{
+		if (l.G != 512u) return hipErrorInvalidValue;
+		if (l.jit_fn)
+		{
+			void *args[] = {(void *)&a};
+			return chained_launch(stream, [&]() { return hipModuleLaunchKernel((hipFunction_t)l.jit_fn, 256, 1, 1, 512, 1, 1, 0, stream, args, nullptr); });
+		}
+		if (l.lut_s != (u32)kDefaultS || l.lut_b != (u32)kDefaultB) return hipErrorInvalidValue;
+		return chained_launch(stream, [&]() {
+			hipLaunchKernelGGL((ca_resident_vn_pair<kDefaultS, kDefaultB>), dim3(256), dim3(512), 0, stream, a);
 			return hipGetLastError();
 		});
 	}

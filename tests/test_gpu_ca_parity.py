@@ -347,7 +347,8 @@ def test_rolling_window_kernel_launcher_choice(eng, name, G):
     assert np.array_equal(eng.read_state(), ol.packed_run(G, st, r, 2))
 
 
-@pytest.mark.parametrize("tables,rows,zsplit", [("default", 32, 2), ("vn_b24_s135", 32, 2), ("default", 16, 2), ("default", 32, 1), ("vn_b24_s135", 16, 1)])
+@pytest.mark.parametrize("tables,rows,zsplit", [("default", 32, 2), ("vn_b24_s135", 32, 2), ("default", 16, 2), ("default", 32, 1), ("vn_b24_s135", 16, 1),
+                                                ("default", "pair", 1), ("vn_b24_s135", "pair", 1)])
 def test_resident_multi_step_kernel(eng, tables, rows, zsplit):
     """The resident kernel (ca_resident_kernel.inc): K steps of a 512^3 von Neumann rule in one launch, the state in
     registers, tile faces handed over through tagged granules. Batches of several lengths back to back (the state tags
@@ -356,6 +357,9 @@ def test_resident_multi_step_kernel(eng, tables, rows, zsplit):
     G = 512
     r = rules(tables)
     eng.configure(G)
+    pair = rows == "pair"  # the row-pair form: 32-row tiles, a thread owns two adjacent rows x 16 planes (resident_pair_run)
+    eng.set_option("resident_pair", int(pair))
+    rows = 32 if pair else rows
     eng.set_option("resident_rows", rows)  # tiles of 32 rows (one workgroup per CU) or 16 rows (two per CU)
     eng.set_option("resident_zsplit", zsplit)  # 2: two threads per (row, word) column, half the planes each — four waves per SIMD
     set_rules(eng, r)
@@ -399,6 +403,7 @@ def test_resident_multi_step_kernel(eng, tables, rows, zsplit):
     if rows == 32 and zsplit == 1 and tables == "default":
         np.testing.assert_array_equal(got, ol.packed_run(G, st, r, 1000), err_msg="1000 resident steps vs the oracle")
     assert eng.recovered_launches() == 0
+    eng.set_option("resident_pair", 1)  # the defaults again
     eng.set_option("resident_rows", 32)
     eng.set_option("resident_zsplit", 1)
 

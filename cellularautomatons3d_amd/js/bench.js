@@ -90,8 +90,36 @@ const stepUs = dt * 1e6 / total;
 const out = {
 	metric: `Gcells/s CA step at ${G}^3 (Node.js host)`, value: +(G ** 3 * total / dt / 1e9).toFixed(3), unit: "Gcells/s", steps, reps, warmup,
 	ms_per_step: +(dt * 1e3 / total).toFixed(6), kernel: eng.info().kernelName, launch_us: +launchUs.toFixed(3),
-	steps_per_launch: Math.round(total / launches), roofline_frac: +((0.25 * G ** 3) / (stepUs * 1e-6) / 8e12).toFixed(4), node: process.version
+	steps_per_launch: Math.round(total / launches), node: process.version
 };
+// The roofline of the kernel that ran, as bench.py reports it: the per-step kernels move the state through HBM every step (fraction of
+// 8 TB/s of algorithmic bytes); a resident kernel keeps it on chip and is bound by vector-instruction issue — SQ_INSTS_VALU per step
+// from the committed rocprofv3 pass of bench.py's command (profiles/r*_pmc_sq_*.json) against 1024 SIMDs x 2.4 GHz / 2.
+const hbmEquivalent = (0.25 * G ** 3) / (stepUs * 1e-6) / 1e9;
+if (/^ca_resident/.test(out.kernel))
+{
+	const key = /class/.test(out.kernel) ? `clustered${G}` : `resident${G}`;
+	const dir = path.join(__dirname, "..", "..", "profiles");
+	let prof = null, src = null;
+	try
+	{
+		for (const f of fs.readdirSync(dir).filter((n) => /^r.*_pmc_sq_/.test(n) && n.endsWith(`_${key}.json`)).sort().reverse())
+		{
+			const d = JSON.parse(fs.readFileSync(path.join(dir, f), "utf8"));
+			if (d.steps_per_launch && d.SQ_INSTS_VALU) { prof = d; src = `profiles/${f}`; break; }
+		}
+	}
+	catch (e) { /* no profiles directory: the instruction count stays unknown */ }
+	const peak = 1228.8; // Gwaveinst/s
+	out.roofline = { bound: "valu_issue", peak, unit: "Gwaveinst/s", achieved: null, frac: null, counter_source: src, hbm_equivalent_gbs: +hbmEquivalent.toFixed(1) };
+	if (prof)
+	{
+		const achieved = prof.SQ_INSTS_VALU / prof.steps_per_launch / (stepUs * 1e-6) / 1e9;
+		out.roofline.achieved = +achieved.toFixed(2);
+		out.roofline.frac = +(achieved / peak).toFixed(4);
+	}
+}
+else out.roofline = { bound: "hbm", peak: 8000, unit: "GB/s", achieved: +hbmEquivalent.toFixed(1), frac: +(hbmEquivalent / 8000).toFixed(4) };
 if (frames > 0 && uniformsPath)
 {
 	// a sparser scene for the renderer, as bench.py: density 2^-5

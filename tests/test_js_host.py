@@ -110,3 +110,6 @@ def test_node_bench_reports_the_headline_metric(tmp_path):
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["kernel"].startswith("ca_resident_vn") and d["steps_per_launch"] == 256 and d["value"] > 100 and d["render"]["value"] > 10
+    # a resident kernel is priced against vector-instruction issue (a fraction <= 1), not against HBM bytes it does not move
+    rf = d["roofline"]
+    assert rf["bound"] == "valu_issue" and rf["counter_source"] and 0.0 < rf["frac"] <= 1.0, rf

@@ -299,7 +299,15 @@ __global__ __launch_bounds__(kBThreads) void ca_unpacked_pipe(const u32 *__restr
 			const u32 w = srcb[xc * 8u] >> sh;
 			uint4 v;
 			v.x = w & 1u; v.y = (w >> 1) & 1u; v.z = (w >> 2) & 1u; v.w = (w >> 3) & 1u;
-			drow[xc * 64u + lane] = v;
+			{
+				// non-temporal: the output is not read again before the next step, and 512 MiB and more of it would only push the
+				// halo rows the neighbour tiles are about to read out of L2 / the Infinity Cache (512^3: 233 -> 217 us per step, same
+				// box; non-temporal LOADS on top: 222 — the halo rows are read twice)
+				typedef u32 u32x4_t __attribute__((ext_vector_type(4)));
+				u32x4_t nv;
+				nv.x = v.x; nv.y = v.y; nv.z = v.z; nv.w = v.w;
+				__builtin_nontemporal_store(nv, reinterpret_cast<u32x4_t *>(drow) + xc * 64u + lane);
+			}
 		}
 	};
 

@@ -166,6 +166,8 @@ struct ca3d_engine
 	int render_skip = 1; // empty-space skipping on sparse volumes
 	int r_swap = 0;
 	hipEvent_t rev_start = nullptr, rev_stop = nullptr;
+	hipStream_t r_aux = nullptr;             // renderer: the plain kernel around the volume's screen rectangle runs here, beside the scheduled launch
+	hipEvent_t r_fork = nullptr, r_join = nullptr;
 	bool rev_valid = false;
 	ca3d_render_stats rstats{};
 
@@ -837,6 +839,9 @@ int ca3d_destroy(ca3d_t *h)
 	if (h->comm_stream) hipStreamDestroy(h->comm_stream);
 	if (h->r_counters) hipFree(h->r_counters);
 	if (h->r_occ) hipFree(h->r_occ);
+	if (h->r_aux) hipStreamDestroy(h->r_aux);
+	if (h->r_fork) hipEventDestroy(h->r_fork);
+	if (h->r_join) hipEventDestroy(h->r_join);
 	if (h->rev_start) hipEventDestroy(h->rev_start);
 	if (h->rev_stop) hipEventDestroy(h->rev_stop);
 	if (h->ev_start) hipEventDestroy(h->ev_start);
@@ -1600,6 +1605,19 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 	l.legacy = h->layout == CA3D_LAYOUT_UNPACKED; // legacy volume -> legacy shader (pathtraced_fragment.wgsl)
 	l.prev_light = h->r_light[h->r_swap ^ 1]; // group 1 of the render pass: last frame's targets (1519-1555, 1787)
 	l.prev_depth = h->r_depth[h->r_swap ^ 1];
+	static const bool aux_off = getenv("CA3D_RENDER_AUX") && atoi(getenv("CA3D_RENDER_AUX")) == 0; // tuning: everything on one stream
+	if (!aux_off && h->render_mode == 0 && h->render_sched && !trace_path)
+	{
+		if (!h->r_aux)
+		{
+			HIP_TRY(hipStreamCreateWithFlags(&h->r_aux, hipStreamNonBlocking));
+			HIP_TRY(hipEventCreateWithFlags(&h->r_fork, hipEventDisableTiming));
+			HIP_TRY(hipEventCreateWithFlags(&h->r_join, hipEventDisableTiming));
+		}
+		l.aux = h->r_aux;
+		l.ev_fork = h->r_fork;
+		l.ev_join = h->r_join;
+	}
 	HIP_TRY(hipEventRecord(h->rev_start, h->stream));
 	hipError_t e = launch_render(l, h->stream);
 	if (e != hipSuccess) return fail(CA3D_ERR_DEVICE, "render launch failed: %s", hipGetErrorString(e));

@@ -141,6 +141,10 @@ struct RenderLaunch
 	uint32_t row0 = 0, row1 = 0;  // mode 0: render image rows [row0, row1) only (row1 == 0: all); row0 % 16 == 0
 	bool indirect = false;        // mode 0, packed: add the one-bounce neighbour lighting term (wgsl :307-377)
 	bool trace = false;           // diagnostics: per-wave {start, end, HW_ID, visits} after the counters (the buffer must hold them)
+	// mode 0, scheduled kernel: a second stream (+ two events) for the plain kernel that renders the tiles AROUND the volume's screen
+	// rectangle — it then runs beside the persistent scheduled launch (whose tail leaves CUs idle) instead of after it. Null: one stream.
+	hipStream_t aux = nullptr;
+	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 // ca_diag.hip: float4 device-to-device copy (measurement only)

@@ -1581,6 +1581,20 @@ hipError_t launch_render(const RenderLaunch &l, hipStream_t stream)
 		volume_rect(P);
 		const bool one = l.spp == 1; // one sample per pixel: 256 pixels per wave tile (32 x 8), else 64 (16 x 4)
 		const u32 tiles = ((P.rx1 - P.rx0) / (one ? 32u : 16u)) * ((P.ry1 - P.ry0) / (one ? 8u : 4u));
+		const bool around = tiles == 0 || P.rx0 > 0 || P.rx1 < l.W || P.ry0 > P.row0 || P.ry1 < P.row1; // tiles outside the rectangle exist
+		// Everything but the dense-volume scheduled kernel — the plain kernel on the tiles around the rectangle (view rays that miss the
+		// volume), the sparse-volume variants (which return at once on a dense volume, as the dense ones do on a sparse one: each
+		// tests the occupancy count before it touches the tile queue) — goes to a second stream when there is one: it then runs
+		// BESIDE the scheduled launch, which is persistent and ends in a tail with most CUs idle, and joins this stream before the
+		// frame is done. The kernels write disjoint pixels. The fork sits behind the counters' memset and the occupancy pass.
+		const bool beside = tiles && l.aux && l.ev_fork && l.ev_join;
+		hipStream_t side = beside ? l.aux : stream;
+		if (beside)
+		{
+			hipError_t e = hipEventRecord(l.ev_fork, stream);
+			if (e == hipSuccess) e = hipStreamWaitEvent(l.aux, l.ev_fork, 0);
+			if (e != hipSuccess) return e;
+		}
 		if (tiles)
 		{
 			int dev = 0, cus = 256;
@@ -1589,17 +1603,16 @@ hipError_t launch_render(const RenderLaunch &l, hipStream_t stream)
 			if (one)
 			{
 				hipLaunchKernelGGL((ca_render_packed_sched<false, 256, 1, kSchedWaves>), dim3(wgs), dim3(256), 0, stream, P);
-				if (P.occ) hipLaunchKernelGGL((ca_render_packed_sched<true, 256, 1, kSchedWaves>), dim3(wgs), dim3(256), 0, stream, P);
+				if (P.occ) hipLaunchKernelGGL((ca_render_packed_sched<true, 256, 1, kSchedWaves>), dim3(wgs), dim3(256), 0, side, P);
 			}
 			else
 			{
 				hipLaunchKernelGGL((ca_render_packed_sched<false, 64, kSchedChunk, kSchedWaves>), dim3(wgs), dim3(256), 0, stream, P);
-				if (P.occ) hipLaunchKernelGGL((ca_render_packed_sched<true, 64, kSchedChunk, kSchedWaves>), dim3(wgs), dim3(256), 0, stream, P);
+				if (P.occ) hipLaunchKernelGGL((ca_render_packed_sched<true, 64, kSchedChunk, kSchedWaves>), dim3(wgs), dim3(256), 0, side, P);
 			}
 		}
 		P.outside_only = tiles ? 1u : 0u;
-		const bool around = tiles == 0 || P.rx0 > 0 || P.rx1 < l.W || P.ry0 > P.row0 || P.ry1 < P.row1; // tiles outside the rectangle exist
-		if (around) hipLaunchKernelGGL(ca_render_packed<false>, grid, dim3(256), 0, stream, P);
+		if (around) hipLaunchKernelGGL(ca_render_packed<false>, grid, dim3(256), 0, side, P);
 		if (P.occ && P.live_box)
 		{
 			// a sparse volume with a small live box: its frame belongs to the spread kernel (a persistent launch: it costs a dense frame
@@ -1607,9 +1620,15 @@ hipError_t launch_render(const RenderLaunch &l, hipStream_t stream)
 			int dev = 0, cus = 256;
 			if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
 			P.spread = 1u;
-			hipLaunchKernelGGL(ca_render_packed_spread<true>, dim3((u32)cus * 4u), dim3(256), 0, stream, P);
+			hipLaunchKernelGGL(ca_render_packed_spread<true>, dim3((u32)cus * 4u), dim3(256), 0, side, P);
 		}
-		if (P.occ && around) hipLaunchKernelGGL(ca_render_packed<true>, grid, dim3(256), 0, stream, P);
+		if (P.occ && around) hipLaunchKernelGGL(ca_render_packed<true>, grid, dim3(256), 0, side, P);
+		if (beside)
+		{
+			hipError_t e = hipEventRecord(l.ev_join, l.aux);
+			if (e == hipSuccess) e = hipStreamWaitEvent(stream, l.ev_join, 0);
+			if (e != hipSuccess) return e;
+		}
 	}
 	else
 	{

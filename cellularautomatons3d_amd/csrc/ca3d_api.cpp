@@ -122,6 +122,7 @@ struct ca3d_engine
 	uint32_t queue_max = 0;               // > 0: ca3d_step calls are encoded and submitted together (option "queue")
 	uint32_t queued = 0;                  // steps encoded, not yet submitted
 	uint64_t launches_total = 0;          // kernel launches the step calls issued since ca3d_create
+	bool res_deep = false;                // 256^3 von Neumann form: two steps per hand-off (option "resident_deep")
 	bool res_pair = true;                 // 512^3 von Neumann form: the row-pair kernel (option "resident_pair"; 2.48 against 2.52 us per step)
 	uint32_t res_rows = 32;               // rows per tile of the von Neumann form (ca_resident_kernel.inc: 32 or 16)
 	uint32_t res_zsplit = 1;              // thread groups along z of the von Neumann form (option "resident_zsplit"; 2 = twice the threads, four waves per
@@ -300,6 +301,7 @@ int enqueue_step(ca3d_engine *h, int src, uint32_t lo, uint32_t hi, hipStream_t 
 // whenever rules, grid or the relevant options change — never from the step path (the WebGPU analogue is pipeline
 // creation). A failed compile leaves the ahead-of-time kernels in charge.
 // the 512^3 von Neumann form runs as the row-pair kernel (32-row tiles, one z group: its own geometry)
+bool vn_deep(const ca3d_engine *h) { return h->res_deep && h->G == 256u; }
 bool vn_pair(const ca3d_engine *h) { return h->res_pair && h->G == 512u && h->res_rows == 32u && h->res_zsplit == 1u; } // another geometry asked for: the general form
 
 void select_kernels(ca3d_engine *h)
@@ -369,7 +371,7 @@ void select_kernels(ca3d_engine *h)
 		h->vn_jit = j;
 		h->kernel_name = "ca_packed_vn(jit)";
 	}
-	if (resident && jit_resident_kernel(h->device, ls, lb, h->G == 256u ? 256u : h->res_rows, h->res_zsplit, vn_pair(h), &h->res_jit_fn, &h->jit_log) == CA3D_OK) h->res_ready = true;
+	if (resident && jit_resident_kernel(h->device, ls, lb, h->G == 256u ? 256u : h->res_rows, h->res_zsplit, vn_pair(h), vn_deep(h), &h->res_jit_fn, &h->jit_log) == CA3D_OK) h->res_ready = true;
 }
 
 // A resident launch only completes when ALL its workgroups are on the chip at once (they wait for each other's faces). Ask the
@@ -386,7 +388,7 @@ void check_residency(ca3d_engine *h)
 	if (h->res_ready)
 	{
 		const uint32_t rows = (h->res_class || h->G == 256u || vn_pair(h)) ? 32u : h->res_rows;
-		if (resident_capacity(h->G, rows, h->res_class ? resident_class_zsplit(h->G) : h->res_zsplit, !h->res_class && vn_pair(h), h->res_jit_fn, h->stream, &tiles, &cap) && cap < tiles)
+		if (resident_capacity(h->G, rows, h->res_class ? resident_class_zsplit(h->G) : h->res_zsplit, !h->res_class && vn_pair(h), !h->res_class && vn_deep(h), h->res_jit_fn, h->stream, &tiles, &cap) && cap < tiles)
 		{
 			h->res_ready = false;
 			h->res_class = false;
@@ -648,6 +650,7 @@ int resident_steps(ca3d_engine *h, uint32_t n)
 	l.rows = (h->res_class || vn_pair(h)) ? 32u : h->res_rows;
 	l.zsplit = h->res_class ? resident_class_zsplit(h->G) : h->res_zsplit;
 	l.pair = !h->res_class && vn_pair(h);
+	l.deep = !h->res_class && vn_deep(h);
 	hipError_t e = launch_resident(l, h->stream);
 	if (e != hipSuccess) return fail(CA3D_ERR_DEVICE, "resident kernel launch failed: %s", hipGetErrorString(e));
 	h->res_pending.push_back({h->res_epoch, n, h->cur, h->step, in, other, h->spare});
@@ -1781,6 +1784,21 @@ int ca3d_set_option(ca3d_t *h, const char *name, int64_t value)
 			HIP_TRY(hipStreamSynchronize(h->stream));
 			free_resident(h);
 			h->res_rows = (uint32_t)value;
+			refresh_kernels(h);
+			note_jit_failure(h);
+		}
+		return CA3D_OK;
+	}
+	if (!strcmp(name, "resident_deep"))
+	{
+		if (value != 0 && value != 1) return fail(CA3D_ERR_INVALID_ARGUMENT, "resident_deep must be 0 or 1");
+		if ((value != 0) != h->res_deep)
+		{
+			int rc2 = bind_device(h);
+			if (rc2) return rc2;
+			HIP_TRY(hipStreamSynchronize(h->stream));
+			free_resident(h); // another mailbox layout: start from clean ones
+			h->res_deep = value != 0;
 			refresh_kernels(h);
 			note_jit_failure(h);
 		}

@@ -313,7 +313,7 @@ int ca3d_get_render_stats(ca3d_t *h, ca3d_render_stats *out);
  * "roll" 0/1 the rolling-window form of the run-time compiled class kernels (on by
  * default where it applies), "roll_tile" 0-3 which of its forms (0 every thread shifts its three rows, 1 workgroup tiles sharing the
  * shifted rows through LDS, 2 wave tiles, 3 two words per thread), "roll_z" 0/2/4/8/16/15/30 its planes per thread
- * (0: chosen per launch); "resident_zsplit" 1/2, "resident_rows" 32/16: tiling of the resident von Neumann kernels, "resident_pair" 1/0: at 512^3 with the
+ * (0: chosen per launch); "resident_zsplit" 1/2, "resident_rows" 32/16: tiling of the resident von Neumann kernels, "resident_deep" 0/1: at 256^3 two steps per hand-off with two-deep faces (measured slower: off); "resident_pair" 1/0: at 512^3 with the
  * default tiling a thread owns two adjacent rows x 16 planes instead of one row x 32 (less LDS traffic; default 1); "graph_min" n: batches shorter than n
  * steps are launched kernel by kernel instead of as a captured graph; "render_mode" 0/1; "render_row_begin" / "render_row_end":
  * ca3d_render then fills image rows [begin, end) only (begin a multiple of 16; 0 / 0 = the whole frame) — a rank's

@@ -691,7 +691,10 @@ def test_checkpoint_resume(eng, tmp_path):
     np.testing.assert_array_equal(eng.read_state(), want)
 
 
-@pytest.mark.parametrize("tables,zsplit", [("default", 2), ("vn_b24_s135", 2), ("default", 1)])
+RESIDENT_DEEP_DEFAULT = 0  # the engine's default for option "resident_deep"
+
+
+@pytest.mark.parametrize("tables,zsplit", [("default", 2), ("vn_b24_s135", 2), ("default", 1), ("default", "deep"), ("vn_b24_s135", "deep2")])
 def test_resident_kernel_at_256(eng, tables, zsplit):
     """BASELINE configs[1] (256^3, 1000 steps) through the resident kernel's 256^3 form: 256 tiles of 8 words x 32 rows x 8
     planes (rows of 8 words: two grid rows per DPP row), y faces smaller than a tile's thread count. Batches of several
@@ -699,6 +702,9 @@ def test_resident_kernel_at_256(eng, tables, zsplit):
     G = 256
     r = rules(tables)
     eng.configure(G)
+    deep = zsplit in ("deep", "deep2")  # two steps per hand-off: faces two cells deep, the step in between on the tile plus a one-cell ring (resident_deep_run)
+    eng.set_option("resident_deep", int(deep))
+    zsplit = {"deep": 1, "deep2": 2}.get(zsplit, zsplit)
     eng.set_option("resident_zsplit", zsplit)
     set_rules(eng, r)
     assert eng.info().kernel_name.startswith(b"ca_resident_vn")
@@ -707,7 +713,9 @@ def test_resident_kernel_at_256(eng, tables, zsplit):
     want = st
     total = 0
     from cellularautomatons3d_amd import slab
-    for n in (8, 9, 21):
+    for n in (8, 9, 21, 1, 2):
+        if n < 8:
+            eng.set_option("resident_min", 1)  # short batches through the resident path too (one round of one step / of two)
         eng.step(n)
         prev = ol.packed_run(G, want, r, n - 1)
         want = ol.packed_step(G, prev, r)
@@ -716,10 +724,22 @@ def test_resident_kernel_at_256(eng, tables, zsplit):
         assert eng.info().current_buffer == total % 2 and eng.info().step == total
         other = slab.device_tensor(*eng.device_buffer(1 - total % 2), 0).cpu().numpy().view(np.uint32)
         np.testing.assert_array_equal(other, prev, err_msg="the other buffer holds the state one step earlier")
+    eng.set_option("resident_min", 8)
     st2 = host.initial_state(G)
     eng.upload_state(st2)
     eng.step(100)
     np.testing.assert_array_equal(eng.read_state(), ol.packed_run(G, st2, r, 100))
+    # live cells hugging the dead -y / -z faces and the wrapping +y / +z faces, and both x ends (the deep form EVOLVES cells outside its tiles)
+    edge = np.zeros(host.words_per_buffer(G), dtype=np.uint32)
+    e3 = edge.reshape(G, G, G // 32)
+    e3[:3, :3, :] = host.random_fill(9 * (G // 32), seed=7).reshape(3, 3, G // 32)
+    e3[-3:, -3:, :] = host.random_fill(9 * (G // 32), seed=8).reshape(3, 3, G // 32)
+    e3[:3, -3:, :] = host.random_fill(9 * (G // 32), seed=9).reshape(3, 3, G // 32)
+    e3[-3:, :3, :] = host.random_fill(9 * (G // 32), seed=10).reshape(3, 3, G // 32)
+    eng.upload_state(edge)
+    for n in (9, 12):
+        eng.step(n)
+    np.testing.assert_array_equal(eng.read_state(), ol.packed_run(G, edge, r, 21), err_msg="boundary slabs, 21 steps")
     eng.upload_state(st)
     eng.step(1000)
     assert eng.info().kernel_name.startswith(b"ca_resident_vn")
@@ -734,6 +754,7 @@ def test_resident_kernel_at_256(eng, tables, zsplit):
     finally:
         eng.set_option("resident", 1)
         eng.set_option("resident_zsplit", 1)
+        eng.set_option("resident_deep", RESIDENT_DEEP_DEFAULT)
 
 
 def test_queued_submission(eng):

@@ -10,7 +10,8 @@
 int main(int argc, char **argv)
 {
 	const int rows = argc > 3 ? atoi(argv[3]) : 32; // 32 / 16: rows per tile at 512^3; 256: the 256^3 form
-	const u32 steps = argc > 1 ? atoi(argv[1]) : 4, G = rows == 256 ? 256 : 512;
+	const bool deep = rows == 257; // 257: the two-steps-per-hand-off form at 256^3
+	const u32 steps = argc > 1 ? atoi(argv[1]) : 4, G = rows == 256 || deep ? 256 : 512;
 	const size_t words = (size_t)G / 32 * G * G;
 	std::vector<u32> h(words);
 	u32 x = 12345;
@@ -34,7 +35,9 @@ int main(int argc, char **argv)
 	{
 		ResidentArgs a{buf[cur], buf[(cur + steps) & 1], buf[(cur + steps + 1) & 1], mail, status, hflag, steps, epoch, 5000000u};
 		CK(hipEventRecord(e0));
-		if (rows == 256 && zs == 2) hipLaunchKernelGGL((ca_resident_vn256<0xFF, 0x0A, 2>), dim3(256), dim3(512), 0, 0, a);
+		if (deep && zs == 2) hipLaunchKernelGGL((ca_resident_vn256_deep<0xFF, 0x0A, 2>), dim3(256), dim3(512), 0, 0, a);
+		else if (deep) hipLaunchKernelGGL((ca_resident_vn256_deep<0xFF, 0x0A, 1>), dim3(256), dim3(256), 0, 0, a);
+		else if (rows == 256 && zs == 2) hipLaunchKernelGGL((ca_resident_vn256<0xFF, 0x0A, 2>), dim3(256), dim3(512), 0, 0, a);
 		else if (rows == 256) hipLaunchKernelGGL((ca_resident_vn256<0xFF, 0x0A, 1>), dim3(256), dim3(256), 0, 0, a);
 		else if (rows == 16 && zs == 2) hipLaunchKernelGGL((ca_resident_vn<0xFF, 0x0A, 16, 2>), dim3(512), dim3(512), 0, 0, a);
 		else if (rows == 16) hipLaunchKernelGGL((ca_resident_vn<0xFF, 0x0A, 16, 1>), dim3(512), dim3(256), 0, 0, a);
@@ -51,7 +54,16 @@ int main(int argc, char **argv)
 		CK(hipMemcpy(st.data(), status, st.size() * 4, hipMemcpyDeviceToHost));
 		printf("launch %d steps %u: %.3f ms (%.3f us/step), status %u\n", l, steps, ms, ms * 1e3 / steps, st[0]);
 #ifdef CA3D_RES_STAMPS
+		if (deep)
 		{
+			std::vector<u32> tt(700);
+			CK(hipMemcpy(tt.data(), status, 700 * 4, hipMemcpyDeviceToHost));
+			static const char *nm[7] = {"poll", "halo+barrier", "ring rows", "column step A", "image1+barrier", "step B", "publish+image0"};
+			if (l == launches - 1) for (int w = 0; w < 4 * zs; w++) { printf("  wave %d cycles/round:", w); u32 tot = 0; for (int i = 0; i < 7; i++) { printf(" %s %u", nm[i], tt[600 + w * 8 + i]); tot += tt[600 + w * 8 + i]; } printf("  total %u\n", tot); }
+		}
+		else
+		{
+
 			std::vector<u32> tt(700);
 			CK(hipMemcpy(tt.data(), status, 616 * 4, hipMemcpyDeviceToHost));
 			static const char *nm[7] = {"poll", "halo+barrier", "face pass", "ym/yp reads", "z faces+prefetch", "main pass", "to_image"};

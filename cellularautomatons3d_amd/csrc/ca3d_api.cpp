@@ -165,6 +165,10 @@ struct ca3d_engine
 	unsigned long long *r_occ = nullptr; // block-occupancy bits of the current state + count, rebuilt per frame (render.hip)
 	size_t r_occ_words = 0;
 	int render_skip = 1; // empty-space skipping on sparse volumes
+	int render_stream = 1; // dense packed volumes: the ray-stream passes (render_stream.hip) instead of the in-wave scheduled kernel
+	int render_stream_check = 0; // diagnostics: count filter / slab-test contradictions (ca3d_get_render_stats is unchanged; see "render_stream_contradictions")
+	void *r_stream = nullptr;    // scratch of the stream passes
+	size_t r_stream_bytes = 0;
 	int r_swap = 0;
 	hipEvent_t rev_start = nullptr, rev_stop = nullptr;
 	hipStream_t r_aux = nullptr;             // renderer: the plain kernel around the volume's screen rectangle runs here, beside the scheduled launch
@@ -842,6 +846,7 @@ int ca3d_destroy(ca3d_t *h)
 	if (h->comm_stream) hipStreamDestroy(h->comm_stream);
 	if (h->r_counters) hipFree(h->r_counters);
 	if (h->r_occ) hipFree(h->r_occ);
+	if (h->r_stream) hipFree(h->r_stream);
 	if (h->r_aux) hipStreamDestroy(h->r_aux);
 	if (h->r_fork) hipEventDestroy(h->r_fork);
 	if (h->r_join) hipEventDestroy(h->r_join);
@@ -1621,6 +1626,22 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 		l.ev_fork = h->r_fork;
 		l.ev_join = h->r_join;
 	}
+	if (h->render_stream && h->render_mode == 0 && h->render_sched && !l.legacy && !l.indirect && !trace_path)
+	{
+		size_t o0, o1, o2;
+		const size_t need = stream_scratch_bytes(width, height, spp, &o0, &o1, &o2);
+		if (h->r_stream_bytes < need)
+		{
+			HIP_TRY(hipStreamSynchronize(h->stream));
+			if (h->r_stream) HIP_TRY(hipFree(h->r_stream));
+			h->r_stream = nullptr;
+			h->r_stream_bytes = 0;
+			HIP_TRY(hipMalloc(&h->r_stream, need));
+			h->r_stream_bytes = need;
+		}
+		l.stream_scratch = h->r_stream;
+		l.stream_check = h->render_stream_check != 0;
+	}
 	HIP_TRY(hipEventRecord(h->rev_start, h->stream));
 	hipError_t e = launch_render(l, h->stream);
 	if (e != hipSuccess) return fail(CA3D_ERR_DEVICE, "render launch failed: %s", hipGetErrorString(e));
@@ -1636,6 +1657,14 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 			fwrite(t.data(), sizeof(unsigned long long), counter_words, f);
 			fclose(f);
 		}
+	}
+	if (l.stream_scratch && l.stream_check)
+	{
+		// diagnostics: the stream passes counted where their interval filter and the reference's slab test disagreed (must be nowhere)
+		uint32_t bad = 0;
+		HIP_TRY(hipStreamSynchronize(h->stream));
+		HIP_TRY(hipMemcpy(&bad, static_cast<const uint32_t *>(l.stream_scratch) + 2, sizeof bad, hipMemcpyDeviceToHost));
+		if (bad) return fail(CA3D_ERR_DEVICE, "render_stream_check: the interval filter contradicted the slab test at %u live cells", bad);
 	}
 	h->rstats.primary_rays = (uint64_t)width * ((l.row1 ? l.row1 : height) - l.row0) * spp;
 	if (presentation_rgba8) HIP_TRY(hipMemcpyAsync(presentation_rgba8, h->r_present, px * 4, hipMemcpyDeviceToHost, h->stream));
@@ -1725,6 +1754,8 @@ int ca3d_set_option(ca3d_t *h, const char *name, int64_t value)
 	if (!strcmp(name, "render_indirect")) { h->render_indirect = value ? 1 : 0; return CA3D_OK; }
 	if (!strcmp(name, "render_sched")) { h->render_sched = value ? 1 : 0; return CA3D_OK; }
 	if (!strcmp(name, "render_skip")) { h->render_skip = value ? 1 : 0; return CA3D_OK; }
+	if (!strcmp(name, "render_stream")) { h->render_stream = value ? 1 : 0; return CA3D_OK; }
+	if (!strcmp(name, "render_stream_check")) { h->render_stream_check = value ? 1 : 0; return CA3D_OK; }
 	if (!strcmp(name, "render_row_begin") || !strcmp(name, "render_row_end"))
 	{
 		if (value < 0 || value > 16384) return fail(CA3D_ERR_INVALID_ARGUMENT, "row %lld is outside any target", (long long)value);

@@ -146,12 +146,20 @@ struct RenderLaunch
 	// rectangle — it then runs beside the persistent scheduled launch (whose tail leaves CUs idle) instead of after it. Null: one stream.
 	hipStream_t aux = nullptr;
 	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+	// mode 0, packed, scheduled: scratch of the ray-stream pipeline (render_stream.hip; stream_scratch_bytes(W, H, spp) bytes) — with it the
+	// dense-volume part of the frame is drawn by the stream passes instead of ca_render_packed_sched (same frame, bit for bit). Null: not used.
+	void *stream_scratch = nullptr;
+	bool stream_check = false; // diagnostics: every live-cell decision of the interval filter is checked against the slab test and contradictions counted
 };
 
 // ca_diag.hip: float4 device-to-device copy (measurement only)
 hipError_t launch_copy_f4(const void *in, void *out, size_t bytes, hipStream_t stream);
 // render.hip
 hipError_t launch_render(const RenderLaunch &l, hipStream_t stream);
+// render_stream.hip: bytes of scratch a frame of this size needs at most (and where its three arrays start); the passes themselves
+// (`params`: render.hip's launch parameters with the volume's screen rectangle filled in)
+size_t stream_scratch_bytes(uint32_t W, uint32_t H, uint32_t spp, size_t *hit_off, size_t *occl_off, size_t *rays_off);
+hipError_t launch_render_stream(const void *params, void *scratch, uint32_t W, uint32_t H, bool check, hipStream_t stream);
 
 // ca_packed.hip / ca_unpacked.hip
 hipError_t launch_packed_step(const PackedLaunch &l, hipStream_t stream, const char **kernel_name);

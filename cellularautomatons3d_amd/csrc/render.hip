@@ -15,495 +15,8 @@ namespace ca3d
 namespace
 {
 
-using u32 = uint32_t;
+#include "render_device.inc"
 
-struct v3
-{
-	float x, y, z;
-};
-__device__ __forceinline__ v3 V(float x, float y, float z) { return v3{x, y, z}; }
-__device__ __forceinline__ v3 operator+(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
-__device__ __forceinline__ v3 operator-(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
-__device__ __forceinline__ v3 operator*(v3 a, v3 b) { return V(a.x * b.x, a.y * b.y, a.z * b.z); }
-__device__ __forceinline__ v3 operator*(v3 a, float s) { return V(a.x * s, a.y * s, a.z * s); }
-__device__ __forceinline__ float dot3(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-__device__ __forceinline__ float len3(v3 a) { return sqrtf(dot3(a, a)); }
-__device__ __forceinline__ v3 norm3(v3 a) { const float l = len3(a); return V(a.x / l, a.y / l, a.z / l); }
-
-// float indices of the 128-float uniform block (MemoryManager allocation order, main_pathtraced.js:166,
-// 467-478 == struct CommonBufferLayout, pathtraced_fragment_clustered.wgsl:17-34)
-enum
-{
-	U_LIGHT = 0, U_VIEW = 4, U_PROJVIEWINV = 20, U_PREVVIEW = 36, U_PREVPROJVIEWINV = 52, U_WINDOW = 68, U_TIME = 70,
-	U_DEPTHSAMPLES = 71, U_SHADOWSAMPLES = 72, U_CELLSIZE = 73, U_SHOWDEPTH = 74, U_TEMPORALALPHA = 75,
-	U_REFLECTIVITY = 76, U_ROUGHNESS = 79, U_MATERIALCOLOR = 80, U_GAMMA = 83, U_LIVE = 84
-};
-
-struct RenderParams
-{
-	const u32 *cells;
-	u32 G, cols; // cols = G / 32
-	u32 W, H, spp;
-	float cot_half_fov;
-	float u[U_LIVE];
-	u32 *presentation;         // RGBA8
-	uint2 *light;              // RGBA16F
-	u32 *depth;                // RG16F
-	unsigned long long *counters; // [0] shadow rays, [1] primary cell visits, [2] shadow cell visits
-	u32 legacy; // 1: one-u32-per-cell volume + the shading of shaders/pathtraced_fragment.wgsl (R-legacy)
-	const unsigned long long *occ; // block occupancy (ca_occupancy) or null; the word after the bits counts the set bits
-	u32 occ_words;                 // 64-bit words of (fine) occupancy bits
-	u32 occ_coarse;                // != 0: coarse bits (blocks of 128 x 32 x 32 cells) follow the count word
-	u32 row0, row1; // only image rows [row0, row1) are rendered (a rank's band of a frame shared between GPUs); row0 is a multiple of 16
-	u32 indirect;   // add calculateIndirectLighting (:307-377), the term the reference leaves commented out at :424
-	u32 trace;      // diagnostics (CA3D_RENDER_TRACE): counters + 8 + 4 * tile receives {start, end (s_memrealtime), HW_ID, cell visits}
-	// The volume's screen rectangle, pixels [rx0, rx1) x [ry0, ry1) (x a multiple of 32, y of 16 from row0; clipped to the band): the
-	// scheduled kernel takes the wave tiles inside it from a queue (counters[3]); the plain kernel, launched with
-	// outside_only, renders the 16 x 16 tiles outside it (view rays that miss the volume: no walk to schedule).
-	u32 rx0, rx1, ry0, ry1, outside_only;
-	// Box around the occupied blocks (32 x 8 x 8 cells each), in cells (ca_occupancy): [0] x1, [1] ~x0, [2] y1, [3] ~y0, [4] z1, [5] ~z0, each the
-	// maximum over the occupied blocks (zero-initialised: an empty volume gives x0 > x1), or null. A view ray that misses it cannot
-	// meet a live cell: the sparse-volume kernels answer "no hit" without walking.
-	const u32 *live_box;
-	u32 spread; // the launch includes ca_render_packed_spread: a small live box is its frame, not the plain kernel's
-	u32 park;   // scheduled kernel: lanes that stand on a live cell park until this many wait for the hit test (0: test at once)
-};
-
-constexpr float kPi = 3.14159265359f;
-constexpr float kHalf = 0.5f;
-constexpr float kOcclusion = 0.0095f;
-
-// (v + 0.5) / cellSize, the shaders' `(p + 0.5) / cs` — for a power-of-two grid cs = 2^-k and the division is a multiplication by
-// G, bit for bit (scaling by a power of two is exact); other grids keep the division. Wave-uniform choice.
-__device__ __forceinline__ float to_cells(const RenderParams &P, float v)
-{
-	const float cs = 1.0f / (float)P.G;
-	return (P.G & (P.G - 1u)) == 0u ? (v + kHalf) * (float)P.G : (v + kHalf) / cs;
-}
-
-__device__ __forceinline__ u32 cell_state(const RenderParams &P, u32 x, u32 y, u32 z)
-{
-	// legacy: cellStates[x + y*G + z*G*G], no wrap (pathtraced_fragment.wgsl:157-168). A point on the volume's
-	// boundary can floor to G or -1: the reference then indexes outside its buffer, which WebGPU's robust buffer
-	// access turns into a harmless read; here such a cell is simply dead.
-	if (P.legacy)
-	{
-		if (x >= P.G || y >= P.G || z >= P.G) return 0u;
-		return P.cells[(size_t)x + (size_t)y * P.G + (size_t)z * P.G * P.G] == 1u ? 1u : 0u;
-	}
-	// :268-290 — every coordinate wraps modulo the grid
-	if ((P.G & (P.G - 1u)) == 0u) // power-of-two grid: the three modulo operations are masks (a u32 % by a run-time value is ~25 instructions)
-	{
-		const u32 idx = ((x >> 5) & (P.cols - 1u)) + (y & (P.G - 1u)) * P.cols + (z & (P.G - 1u)) * P.cols * P.G;
-		return (P.cells[idx] >> (x & 31u)) & 1u;
-	}
-	const u32 idx = ((x >> 5) % P.cols) + (y % P.G) * P.cols + (z % P.G) * P.cols * P.G;
-	return (P.cells[idx] >> (x & 31u)) & 1u;
-}
-
-__device__ __forceinline__ void ray_cube(v3 o, v3 d, v3 center, v3 half, float &tnear, float &tfar)
-{
-	// :212-225
-	const v3 inv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-	const v3 tmin = ((center - half) - o) * inv;
-	const v3 tmax = ((center + half) - o) * inv;
-	const v3 t1 = V(fminf(tmin.x, tmax.x), fminf(tmin.y, tmax.y), fminf(tmin.z, tmax.z));
-	const v3 t2 = V(fmaxf(tmin.x, tmax.x), fmaxf(tmin.y, tmax.y), fmaxf(tmin.z, tmax.z));
-	tnear = fmaxf(fmaxf(t1.x, t1.y), t1.z);
-	tfar = fminf(fminf(t2.x, t2.y), t2.z);
-}
-
-// The same test with 1 / d handed in (bit-identical: ray_cube forms exactly this `inv` first). A walk tests many cells along
-// one ray: three correctly rounded divisions (~10 instructions each) per live cell become three per ray.
-__device__ __forceinline__ void ray_cube_inv(v3 o, v3 inv, v3 center, v3 half, float &tnear, float &tfar)
-{
-	const v3 tmin = ((center - half) - o) * inv;
-	const v3 tmax = ((center + half) - o) * inv;
-	const v3 t1 = V(fminf(tmin.x, tmax.x), fminf(tmin.y, tmax.y), fminf(tmin.z, tmax.z));
-	const v3 t2 = V(fmaxf(tmin.x, tmax.x), fmaxf(tmin.y, tmax.y), fmaxf(tmin.z, tmax.z));
-	tnear = fmaxf(fmaxf(t1.x, t1.y), t1.z);
-	tfar = fminf(fminf(t2.x, t2.y), t2.z);
-}
-
-__device__ __forceinline__ float sd_box(v3 p, v3 b)
-{
-	// :182-186
-	const v3 q = V(fabsf(p.x) - b.x, fabsf(p.y) - b.y, fabsf(p.z) - b.z);
-	const v3 m = V(fmaxf(q.x, 0.0f), fmaxf(q.y, 0.0f), fmaxf(q.z, 0.0f));
-	return len3(m) + fminf(fmaxf(q.x, fmaxf(q.y, q.z)), 0.0f);
-}
-
-__device__ __forceinline__ v3 face_normal(v3 p, v3 origin)
-{
-	// :227-254
-	const v3 d = p - origin;
-	const v3 a = V(fabsf(d.x), fabsf(d.y), fabsf(d.z));
-	const float m = fmaxf(fmaxf(a.x, a.y), a.z);
-	v3 n;
-	if (a.x == m) n = V(d.x, 0.0f, 0.0f);
-	else if (a.y == m) n = V(0.0f, d.y, 0.0f);
-	else n = V(0.0f, 0.0f, d.z);
-	return norm3(n);
-}
-
-__device__ __forceinline__ v3 cell_origin(float cs, int x, int y, int z)
-{
-	return V((float)x * cs + cs * 0.5f - kHalf, (float)y * cs + cs * 0.5f - kHalf, (float)z * cs + cs * 0.5f - kHalf);
-}
-
-__device__ v3 surface_brdf(v3 L, v3 Vd, v3 N, float roughness, v3 albedo, v3 F0)
-{
-	// :537-592
-	const v3 Hh = norm3(L + Vd);
-	const v3 fL = V(albedo.x / kPi, albedo.y / kPi, albedo.z / kPi);
-	const float a2 = roughness * roughness;
-	const float NoH = dot3(N, Hh);
-	const float NoH2 = NoH * NoH;
-	const float f = NoH2 * (a2 - 1.0f) + 1.0f;
-	const float D = a2 / (kPi * f * f);
-	const float n = roughness + 1.0f;
-	const float k = (n * n) / 8.0f;
-	const float NoV = fmaxf(0.0f, dot3(N, Vd));
-	const float gv = NoV / (NoV * (1.0f - k) + k);
-	const float NoL = fmaxf(0.0f, dot3(N, L));
-	const float gl = NoL / (NoL * (1.0f - k) + k);
-	const float Gm = gv * gl;
-	const float p = powf(1.0f - dot3(Hh, Vd), 5.0f);
-	const v3 F = V(F0.x + (1.0f - F0.x) * p, F0.y + (1.0f - F0.y) * p, F0.z + (1.0f - F0.z) * p);
-	const float denom = 4.0f * dot3(Vd, N) * dot3(L, N);
-	return V(fL.x + (D * Gm * F.x) / denom, fL.y + (D * Gm * F.y) / denom, fL.z + (D * Gm * F.z) / denom);
-}
-
-// calculateLightingAt :594-633 with a vec3 incident light arriving from `light_pos` (the direct term passes the light
-// source's magnitude and position, the indirect term a neighbour cell's reflected light and the point it leaves from)
-__device__ v3 lighting_from(const RenderParams &P, v3 p, v3 origin, u32 cx, u32 cy, v3 eye, v3 incident, v3 light_pos)
-{
-	const float *u = P.u;
-	const v3 N = face_normal(p, origin);
-	const float Gf = (float)P.G;
-	const float cxn = (float)cx / Gf, cyn = (float)cy / Gf;
-	v3 albedo = V(cxn, cyn, 1.0f - cxn);
-	if (u[U_MATERIALCOLOR] != 0.0f || u[U_MATERIALCOLOR + 1] != 0.0f || u[U_MATERIALCOLOR + 2] != 0.0f)
-		albedo = V(u[U_MATERIALCOLOR], u[U_MATERIALCOLOR + 1], u[U_MATERIALCOLOR + 2]);
-	const v3 Vd = norm3(eye - p);
-	const v3 L = norm3(light_pos - p);
-	const v3 F0 = V(u[U_REFLECTIVITY], u[U_REFLECTIVITY + 1], u[U_REFLECTIVITY + 2]);
-	const v3 brdf = surface_brdf(L, Vd, N, u[U_ROUGHNESS], albedo, F0);
-	const float LoN = dot3(L, N);
-	return V(fmaxf(0.0f, brdf.x * incident.x * LoN), fmaxf(0.0f, brdf.y * incident.y * LoN), fmaxf(0.0f, brdf.z * incident.z * LoN));
-}
-
-// ---- empty-space skipping ------------------------------------------------------------------------------------
-// One occupancy bit per block of 32 x 8 x 8 cells (ca_occupancy below). When the walk enters an empty block it
-// jumps to the block's exit face and re-seeds its boundary times in closed form there. Used only on sparse volumes
-// (< 1/4 of the blocks occupied, decided per frame from the bit count): there it visits the same cells as the
-// cell-by-cell walk except where a ray grazes a cell corner within rounding (re-seeded times are not the accumulated
-// ones) — inside the renderer's stated tolerance, not bit-identical to the unskipped walk.
-__device__ __forceinline__ bool occ_skip_enabled(const RenderParams &P)
-{
-	if (!P.occ) return false;
-	const unsigned long long set = P.occ[P.occ_words];
-	return set * 4ull < (unsigned long long)P.cols * (P.G >> 3) * (P.G >> 3);
-}
-
-// true: the ray o + t d (t >= 0) stays outside the box of the occupied blocks, grown by one cell — it cannot enter a live cell, and
-// the walk along it would come back empty-handed. A NaN in the slab test (a zero direction component on a slab face) reads as
-// "may hit".
-__device__ __forceinline__ bool misses_live_box(const RenderParams &P, v3 o, v3 d)
-{
-	if (!P.live_box) return false;
-	const u32 x1 = P.live_box[0], x0 = ~P.live_box[1], y1 = P.live_box[2], y0 = ~P.live_box[3], z1 = P.live_box[4], z0 = ~P.live_box[5];
-	if (x0 >= x1) return true; // nothing alive
-	const float cs = 1.0f / (float)P.G;
-	const v3 lo = V((float)x0 * cs - kHalf - cs, (float)y0 * cs - kHalf - cs, (float)z0 * cs - kHalf - cs);
-	const v3 hi = V((float)x1 * cs - kHalf + cs, (float)y1 * cs - kHalf + cs, (float)z1 * cs - kHalf + cs);
-	float tn, tf;
-	ray_cube(o, d, V(0.5f * (lo.x + hi.x), 0.5f * (lo.y + hi.y), 0.5f * (lo.z + hi.z)), V(0.5f * (hi.x - lo.x), 0.5f * (hi.y - lo.y), 0.5f * (hi.z - lo.z)), tn, tf);
-	return tn > tf || tf < 0.0f;
-}
-
-// A sparse volume whose live cells sit in a small box (under an eighth of the grid: the reference's start-up seed) is rendered by
-// the plain kernel alone: nearly every ray is answered by misses_live_box, and the few tiles that walk are next to each other —
-// per-wave ray scheduling has nothing to schedule there and its 256-job tiles serialise the only work there is (measured on the
-// start-up scene, 1080p 4 spp: 2.2 ms scheduled, 0.76 ms plain; volumes with live cells everywhere: 5.0 vs 6.3 ms).
-__device__ __forceinline__ bool live_box_small(const RenderParams &P)
-{
-	if (!P.live_box) return false;
-	const u32 x1 = P.live_box[0], x0 = ~P.live_box[1], y1 = P.live_box[2], y0 = ~P.live_box[3], z1 = P.live_box[4], z0 = ~P.live_box[5];
-	if (x0 >= x1) return true;
-	return (unsigned long long)(x1 - x0) * (y1 - y0) * (z1 - z0) * 8ull < (unsigned long long)P.G * P.G * P.G;
-}
-
-__device__ __forceinline__ bool block_occupied(const RenderParams &P, int ix, int iy, int iz)
-{
-	const int bk = (ix >> 5) + ((iy >> 3) + (iz >> 3) * ((int)P.G >> 3)) * (int)P.cols;
-	return (P.occ[bk >> 6] >> (bk & 63)) & 1ull;
-}
-
-// second level: blocks of 128 x 32 x 32 cells (4 x 4 x 4 fine blocks), grids that are multiples of 128 only
-__device__ __forceinline__ bool coarse_occupied(const RenderParams &P, int ix, int iy, int iz)
-{
-	const int ck = (ix >> 7) + ((iy >> 5) + (iz >> 5) * ((int)P.G >> 5)) * ((int)P.cols >> 2);
-	return (P.occ[P.occ_words + 1u + (u32)(ck >> 6)] >> (ck & 63)) & 1ull;
-}
-
-// The ray is in cell (ix, iy, iz) of an empty block: move to the first cell past the block. false: the ray ends or
-// leaves the volume first.
-template <int LX, int LY, int LZ> // log2 of the block's extent in cells
-__device__ __forceinline__ bool block_jump(const RenderParams &P, v3 start, v3 dir, float tmax, int &ix, int &iy, int &iz, float &t,
-                                           float &tx, float &ty, float &tz)
-{
-	constexpr int BX = 1 << LX, BY = 1 << LY, BZ = 1 << LZ;
-	const int G = (int)P.G;
-	const float cs = 1.0f / (float)P.G, big = 3.0e38f;
-	const int sx = dir.x > 0.0f ? 1 : -1, sy = dir.y > 0.0f ? 1 : -1, sz = dir.z > 0.0f ? 1 : -1;
-	const int bx0 = ix & ~(BX - 1), by0 = iy & ~(BY - 1), bz0 = iz & ~(BZ - 1);
-	const float tex = dir.x != 0.0f ? (((float)(sx > 0 ? bx0 + BX : bx0) * cs - kHalf) - start.x) / dir.x : big;
-	const float tey = dir.y != 0.0f ? (((float)(sy > 0 ? by0 + BY : by0) * cs - kHalf) - start.y) / dir.y : big;
-	const float tez = dir.z != 0.0f ? (((float)(sz > 0 ? bz0 + BZ : bz0) * cs - kHalf) - start.z) / dir.z : big;
-	const bool mx = tex <= tey && tex <= tez, my = !mx && tey <= tez;
-	const float te = mx ? tex : (my ? tey : tez);
-	if (te >= tmax) return false;
-	const v3 p = start + dir * te;
-	int nx = min(max((int)floorf(to_cells(P, p.x)), bx0), bx0 + BX - 1);
-	int ny = min(max((int)floorf(to_cells(P, p.y)), by0), by0 + BY - 1);
-	int nz = min(max((int)floorf(to_cells(P, p.z)), bz0), bz0 + BZ - 1);
-	if (mx) nx = sx > 0 ? bx0 + BX : bx0 - 1;
-	else if (my) ny = sy > 0 ? by0 + BY : by0 - 1;
-	else nz = sz > 0 ? bz0 + BZ : bz0 - 1;
-	if ((u32)nx >= (u32)G || (u32)ny >= (u32)G || (u32)nz >= (u32)G) return false;
-	ix = nx; iy = ny; iz = nz;
-	t = te;
-	tx = dir.x != 0.0f ? (((float)(ix + (sx > 0 ? 1 : 0)) * cs - kHalf) - start.x) / dir.x : big;
-	ty = dir.y != 0.0f ? (((float)(iy + (sy > 0 ? 1 : 0)) * cs - kHalf) - start.y) / dir.y : big;
-	tz = dir.z != 0.0f ? (((float)(iz + (sz > 0 ? 1 : 0)) * cs - kHalf) - start.z) / dir.z : big;
-	return true;
-}
-
-// Exact cell walk (Amanatides-Woo) from `start` along unit `dir` over (t0, tmax). SHADOW selects the visit test.
-// Returns true on a hit; `tnear_out` is the slab entry of the hit cube (primary only).
-template <bool SHADOW, bool SKIP>
-__device__ bool walk(const RenderParams &P, v3 start, v3 dir, float t0, float tmax, v3 half, int sx0, int sy0, int sz0,
-                     float &tnear_out, u32 &visits)
-{
-	const int G = (int)P.G;
-	const float cs = 1.0f / (float)P.G;
-	const v3 p = start + dir * t0;
-	int ix = (int)floorf(to_cells(P, p.x)), iy = (int)floorf(to_cells(P, p.y)), iz = (int)floorf(to_cells(P, p.z));
-	ix = min(max(ix, 0), G - 1);
-	iy = min(max(iy, 0), G - 1);
-	iz = min(max(iz, 0), G - 1);
-	const int sx = dir.x > 0.0f ? 1 : -1, sy = dir.y > 0.0f ? 1 : -1, sz = dir.z > 0.0f ? 1 : -1;
-	const float big = 3.0e38f;
-	float tx = dir.x != 0.0f ? (((float)(ix + (sx > 0 ? 1 : 0)) * cs - kHalf) - start.x) / dir.x : big;
-	float ty = dir.y != 0.0f ? (((float)(iy + (sy > 0 ? 1 : 0)) * cs - kHalf) - start.y) / dir.y : big;
-	float tz = dir.z != 0.0f ? (((float)(iz + (sz > 0 ? 1 : 0)) * cs - kHalf) - start.z) / dir.z : big;
-	const float dx = dir.x != 0.0f ? cs / fabsf(dir.x) : big, dy = dir.y != 0.0f ? cs / fabsf(dir.y) : big,
-	            dz = dir.z != 0.0f ? cs / fabsf(dir.z) : big;
-	float t = t0;
-	const v3 inv = V(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z); // what ray_cube forms first: once per ray, not once per live cell
-	// one packed word covers 32 x-cells of a row: keep it in a register while the walk stays inside it
-	u32 word = 0;
-	int wkey = -1;
-	for (int guard = 0; guard < 3 * G + 3; guard++)
-	{
-		if (t >= tmax) return false;
-		visits++;
-		if (SKIP)
-		{
-			if (P.occ_coarse && !coarse_occupied(P, ix, iy, iz))
-			{
-				if (!block_jump<7, 5, 5>(P, start, dir, tmax, ix, iy, iz, t, tx, ty, tz)) return false;
-				continue;
-			}
-			if (!block_occupied(P, ix, iy, iz))
-			{
-				if (!block_jump<5, 3, 3>(P, start, dir, tmax, ix, iy, iz, t, tx, ty, tz)) return false;
-				continue;
-			}
-		}
-		bool alive;
-		if (P.legacy) alive = P.cells[(size_t)ix + ((size_t)iy + (size_t)iz * G) * G] == 1u; // `== 1` (pathtraced_fragment.wgsl:530)
-		else
-		{
-			const int key = (ix >> 5) + (iy + iz * G) * (int)P.cols;
-			if (key != wkey) { word = P.cells[key]; wkey = key; }
-			alive = (word >> (ix & 31)) & 1u;
-		}
-		if (alive)
-		{
-			if (!(SHADOW && ix == sx0 && iy == sy0 && iz == sz0)) // any(cell != startCell) :664
-			{
-				float tn, tf;
-				ray_cube_inv(start, inv, cell_origin(cs, ix, iy, iz), half, tn, tf);
-				if (SHADOW ? (tn <= tf && tn >= 0.0f) /* :668 */ : (tf >= 0.0f && tn <= tf) /* :722-729 */)
-				{
-					tnear_out = tn;
-					return true;
-				}
-			}
-		}
-		// advance along the axis whose boundary comes first — selects, not a three-way branch: the lanes of a wave
-		// step along different axes almost every time
-		const bool mx = tx <= ty && tx <= tz, my = !mx && ty <= tz, mz = !mx && !my;
-		t = mx ? tx : (my ? ty : tz);
-		tx += mx ? dx : 0.0f;
-		ty += my ? dy : 0.0f;
-		tz += mz ? dz : 0.0f;
-		ix += mx ? sx : 0;
-		iy += my ? sy : 0;
-		iz += mz ? sz : 0;
-		if ((u32)ix >= (u32)G || (u32)iy >= (u32)G || (u32)iz >= (u32)G) return false;
-	}
-	return false;
-}
-
-struct Sample
-{
-	float r, g, b, a, depth;
-	u32 shadow_ray;
-};
-
-template <bool SKIP>
-__device__ Sample shade_sample(const RenderParams &P, float vu, float vv, u32 &pvis, u32 &svis)
-{
-	const float *u = P.u;
-	const float *view = u + U_VIEW;
-	Sample s{0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0u};
-	const v3 cam = V(view[12], view[13], view[14]);
-	// getRay :188-197, then viewMat * vec4(ray, 0)
-	const float r = u[U_WINDOW] / u[U_WINDOW + 1];
-	const v3 rl = norm3(V((vu - 0.5f) * r, vv - 0.5f, -(0.5f * P.cot_half_fov)));
-	const v3 ray = V(view[0] * rl.x + view[4] * rl.y + view[8] * rl.z, view[1] * rl.x + view[5] * rl.y + view[9] * rl.z,
-	                 view[2] * rl.x + view[6] * rl.y + view[10] * rl.z);
-	const v3 half = V(kHalf, kHalf, kHalf);
-	float tn, tf;
-	ray_cube(cam, ray, V(0.0f, 0.0f, 0.0f), half, tn, tf);
-	const float cam_dist = sd_box(cam, half);
-	if (tn <= tf && tf >= 0.0f) // :822
-	{
-		v3 enter = cam;
-		const v3 exitp = cam + ray * tf;
-		if (cam_dist >= 0.0f) enter = cam + ray * tn;
-		const v3 seg = exitp - enter;
-		const v3 dir = norm3(seg);
-		const float depth_len = len3(seg);
-		const float cs = 1.0f / (float)P.G;
-		const float vis = cs * u[U_CELLSIZE] * 0.5f;
-		const v3 vhalf = V(vis, vis, vis);
-		float tnear = 0.0f;
-		const bool hit = (SKIP && misses_live_box(P, cam, ray)) ? false : walk<false, SKIP>(P, enter, dir, 0.0f, depth_len, vhalf, 0, 0, 0, tnear, pvis);
-		const v3 final_point = hit ? enter + dir * tnear : exitp;
-		s.depth = len3(final_point - cam);  // :762, 774
-		const v3 p = cam + ray * s.depth;   // moreAccurateSamplePoint :840
-		// calculateLightingAndOcclusionAt :379-427
-		const v3 f = V(floorf(to_cells(P, p.x)), floorf(to_cells(P, p.y)), floorf(to_cells(P, p.z)));
-		const v3 origin = V(f.x * cs + cs * 0.5f - kHalf, f.y * cs + cs * 0.5f - kHalf, f.z * cs + cs * 0.5f - kHalf);
-		const int cx = (int)f.x, cy = (int)f.y, cz = (int)f.z;
-		const u32 st = cell_state(P, (u32)cx, (u32)cy, (u32)cz);
-		const float dist = sd_box(p - origin, vhalf);
-		if (st == 1u && !(dist > 0.001f))
-		{
-			const v3 light_pos = V(u[U_LIGHT], u[U_LIGHT + 1], u[U_LIGHT + 2]);
-			const v3 ldir = norm3(light_pos - p);
-			float vn, vf;
-			ray_cube(p, ldir, V(0.0f, 0.0f, 0.0f), half, vn, vf);
-			const v3 vexit = p + ldir * vf;
-			const v3 sseg = vexit - p;
-			const v3 sdir = norm3(sseg);
-			const float slen = len3(sseg);
-			float dummy = 0.0f;
-			const bool occluded = walk<true, SKIP>(P, p, sdir, 0.0025f, slen, vhalf, cx, cy, cz, dummy, svis);
-			const float occ = occluded ? (P.legacy ? 0.095f : kOcclusion) : 1.0f; // pathtraced_fragment.wgsl:67 / clustered :72
-			if (P.legacy)
-			{
-				// calculateLigtingAt (pathtraced_fragment.wgsl:338-365): mirror-reflection term + flat term, 1/d^2 to light and eye
-				const v3 N = face_normal(p, origin);
-				const float Gf = (float)P.G;
-				const v3 colr = V(f.x / Gf, f.y / Gf, 1.0f - f.x / Gf);
-				const v3 view_dir = norm3(p - cam);
-				const float dl = len3(light_pos - p), dc = len3(cam - p);
-				const float fl = fmaxf(1.0f, powf(dl, 2.0f)), fc = fmaxf(1.0f, powf(dc, 2.0f));
-				const float incident = u[U_LIGHT + 3] / fl;
-				const v3 inc_dir = norm3(p - light_pos);
-				const float ndi = dot3(N, inc_dir);
-				const v3 refl = V(inc_dir.x - 2.0f * ndi * N.x, inc_dir.y - 2.0f * ndi * N.y, inc_dir.z - 2.0f * ndi * N.z);
-				const float reflected = incident * dot3(refl, V(-view_dir.x, -view_dir.y, -view_dir.z));
-				s.r = occ * ((colr.x * reflected + incident * colr.x) / fc);
-				s.g = occ * ((colr.y * reflected + incident * colr.y) / fc);
-				s.b = occ * ((colr.z * reflected + incident * colr.z) / fc);
-				s.a = occ; // the vec4 colour (alpha 1) is scaled as a whole (:226)
-				s.shadow_ray = 1u;
-			}
-			else
-			{
-			// calculateLightingAt :594-633
-			const v3 N = face_normal(p, origin);
-			const float Gf = (float)P.G;
-			const float cxn = (float)(u32)cx / Gf, cyn = (float)(u32)cy / Gf;
-			v3 albedo = V(cxn, cyn, 1.0f - cxn);
-			if (u[U_MATERIALCOLOR] != 0.0f || u[U_MATERIALCOLOR + 1] != 0.0f || u[U_MATERIALCOLOR + 2] != 0.0f)
-				albedo = V(u[U_MATERIALCOLOR], u[U_MATERIALCOLOR + 1], u[U_MATERIALCOLOR + 2]);
-			const v3 Vd = norm3(cam - p);
-			const v3 L = norm3(light_pos - p);
-			const v3 F0 = V(u[U_REFLECTIVITY], u[U_REFLECTIVITY + 1], u[U_REFLECTIVITY + 2]);
-			const v3 brdf = surface_brdf(L, Vd, N, u[U_ROUGHNESS], albedo, F0);
-			const float mag = u[U_LIGHT + 3];
-			const float LoN = dot3(L, N);
-			s.r = occ * fmaxf(0.0f, brdf.x * mag * LoN);
-			s.g = occ * fmaxf(0.0f, brdf.y * mag * LoN);
-			s.b = occ * fmaxf(0.0f, brdf.z * mag * LoN);
-			s.shadow_ray = 1u;
-			if (P.indirect)
-			{
-				// calculateIndirectLighting :307-377 — one bounce off the four neighbour cells of the layer the face looks
-				// into (tables :117-169): each live neighbour is hit along the integer offset direction, lit from the light
-				// source (own shadow walk), and what it reflects towards p is p's incident light from that point
-				int ox[4], oy[4], oz[4];
-				if (N.x != 0.0f) { const int sx = N.x < 0.0f ? -1 : 1; ox[0] = ox[1] = ox[2] = ox[3] = sx; oy[0] = 1; oy[1] = -1; oy[2] = oy[3] = 0; oz[0] = oz[1] = 0; oz[2] = 1; oz[3] = -1; }
-				else if (N.y != 0.0f) { const int sy = N.y < 0.0f ? -1 : 1; oy[0] = oy[1] = oy[2] = oy[3] = sy; ox[0] = -1; ox[1] = 1; ox[2] = ox[3] = 0; oz[0] = oz[1] = 0; oz[2] = 1; oz[3] = -1; }
-				else { const int sz = N.z < 0.0f ? -1 : 1; oz[0] = oz[1] = oz[2] = oz[3] = sz; ox[0] = ox[1] = 0; ox[2] = -1; ox[3] = 1; oy[0] = 1; oy[1] = -1; oy[2] = oy[3] = 0; }
-				for (int i = 0; i < 4; i++)
-				{
-					const u32 nx = (u32)(cx + ox[i]), ny = (u32)(cy + oy[i]), nz = (u32)(cz + oz[i]); // vec3u(vec3i) :345
-					if (!cell_state(P, nx, ny, nz)) continue;
-					const v3 norigin = V((float)nx * cs + cs * 0.5f - kHalf, (float)ny * cs + cs * 0.5f - kHalf, (float)nz * cs + cs * 0.5f - kHalf);
-					const v3 ndir = V((float)ox[i], (float)oy[i], (float)oz[i]);
-					float qn, qf;
-					ray_cube(p, ndir, norigin, vhalf, qn, qf);
-					if (!(qn <= qf && qf >= 0.0f)) continue;
-					const v3 np = p + ndir * qn;
-					const v3 nl = norm3(light_pos - np);
-					float wn, wf;
-					ray_cube(np, nl, V(0.0f, 0.0f, 0.0f), half, wn, wf);
-					const v3 nseg = (np + nl * wf) - np;
-					float dummy2 = 0.0f;
-					const bool nocc = walk<true, SKIP>(P, np, norm3(nseg), 0.0025f, len3(nseg), vhalf, (int)nx, (int)ny, (int)nz, dummy2, svis);
-					const v3 refl = lighting_from(P, np, norigin, nx, ny, p, V(mag, mag, mag), light_pos) * (nocc ? kOcclusion : 1.0f);
-					const v3 ind = lighting_from(P, p, origin, (u32)cx, (u32)cy, cam, refl, np);
-					s.r += ind.x; s.g += ind.y; s.b += ind.z;
-				}
-			}
-			}
-		}
-		// fixed point of clamp(mix(prev, cur, alpha), 0, 1) under a static camera :468
-		s.r = fminf(fmaxf(s.r, 0.0f), 1.0f);
-		s.g = fminf(fmaxf(s.g, 0.0f), 1.0f);
-		s.b = fminf(fmaxf(s.b, 0.0f), 1.0f);
-		s.a = fminf(fmaxf(s.a, 0.0f), 1.0f);
-	}
-	{
-		// light gizmo :866-874
-		const v3 light_pos = V(u[U_LIGHT], u[U_LIGHT + 1], u[U_LIGHT + 2]);
-		float ln, lf;
-		ray_cube(cam, ray, light_pos, V(0.005f, 0.005f, 0.005f), ln, lf);
-		if (ln <= lf && lf >= 0.0f && s.r == 0.0f && s.g == 0.0f && s.b == 0.0f) { s.r = s.g = s.b = 1.0f; s.a = 1.0f; }
-	}
-	if (u[U_SHOWDEPTH] == 1.0f && vu < 0.5f) { s.r = s.depth; s.g = 0.0f; s.b = 0.0f; s.a = 1.0f; } // :880-883
-	return s;
-}
-
-__device__ __forceinline__ u32 unorm8(float x) { return (u32)__float2int_rn(fminf(fmaxf(x, 0.0f), 1.0f) * 255.0f); }
 
 // SKIP: the variant with empty-space skipping. Both variants are launched for every frame and the one that does not
 // match the frame's occupancy (occ_skip_enabled) returns at once: the choice is made on the device, without a host
@@ -1600,14 +1113,22 @@ hipError_t launch_render(const RenderLaunch &l, hipStream_t stream)
 			int dev = 0, cus = 256;
 			if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
 			const u32 wgs = min((tiles + 3u) / 4u, (u32)cus * (u32)kSchedWaves);
+			// the dense-volume kernel: the ray-stream passes (render_stream.hip) when the engine has given them scratch, else the
+			// in-wave scheduled kernel (legacy volumes, traces, option render_stream 0)
+			const bool streamed = l.stream_scratch && !P.legacy && !P.trace;
+			if (streamed)
+			{
+				hipError_t e = launch_render_stream(&P, l.stream_scratch, l.W, l.H, l.stream_check, stream);
+				if (e != hipSuccess) return e;
+			}
 			if (one)
 			{
-				hipLaunchKernelGGL((ca_render_packed_sched<false, 256, 1, kSchedWaves>), dim3(wgs), dim3(256), 0, stream, P);
+				if (!streamed) hipLaunchKernelGGL((ca_render_packed_sched<false, 256, 1, kSchedWaves>), dim3(wgs), dim3(256), 0, stream, P);
 				if (P.occ) hipLaunchKernelGGL((ca_render_packed_sched<true, 256, 1, kSchedWaves>), dim3(wgs), dim3(256), 0, side, P);
 			}
 			else
 			{
-				hipLaunchKernelGGL((ca_render_packed_sched<false, 64, kSchedChunk, kSchedWaves>), dim3(wgs), dim3(256), 0, stream, P);
+				if (!streamed) hipLaunchKernelGGL((ca_render_packed_sched<false, 64, kSchedChunk, kSchedWaves>), dim3(wgs), dim3(256), 0, stream, P);
 				if (P.occ) hipLaunchKernelGGL((ca_render_packed_sched<true, 64, kSchedChunk, kSchedWaves>), dim3(wgs), dim3(256), 0, side, P);
 			}
 		}

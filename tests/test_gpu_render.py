@@ -27,17 +27,21 @@ def _compare(eng, cells, G, u, W, H, spp, rows=None, min_ok=0.999):
     eng.configure(G)
     set_rules(eng, rules("default"))
     eng.upload_state(cells)
-    # the plain kernel (one pixel per lane, samples in order) and the scheduled one must agree bit for bit
+    # the plain kernel (one pixel per lane, samples in order), the in-wave scheduled one and the ray-stream passes (the default; also with
+    # every decision of their interval filter checked against the slab test: a contradiction fails the call) must agree bit for bit
     eng.set_option("render_sched", 0)
     pres0, light0, depth0 = eng.render(u, W, H, spp)
     st0 = eng.render_stats()
     eng.set_option("render_sched", 1)
-    pres, light, depth = eng.render(u, W, H, spp)
-    st1 = eng.render_stats()
-    np.testing.assert_array_equal(pres, pres0)
-    np.testing.assert_array_equal(light.view(np.uint16), light0.view(np.uint16))
-    np.testing.assert_array_equal(depth.view(np.uint16), depth0.view(np.uint16))
-    assert (st0.shadow_rays, st0.primary_cell_visits, st0.shadow_cell_visits) == (st1.shadow_rays, st1.primary_cell_visits, st1.shadow_cell_visits)
+    for stream, check in ((0, 0), (1, 1), (1, 0)):
+        eng.set_option("render_stream", stream)
+        eng.set_option("render_stream_check", check)
+        pres, light, depth = eng.render(u, W, H, spp)
+        st1 = eng.render_stats()
+        np.testing.assert_array_equal(pres, pres0)
+        np.testing.assert_array_equal(light.view(np.uint16), light0.view(np.uint16))
+        np.testing.assert_array_equal(depth.view(np.uint16), depth0.view(np.uint16))
+        assert (st0.shadow_rays, st0.primary_cell_visits, st0.shadow_cell_visits) == (st1.shadow_rays, st1.primary_cell_visits, st1.shadow_cell_visits)
     olight, odepth, opres, oshadow = ol.render(cells, G, u, W, H, spp, rows)
     y0, y1 = rows if rows else (0, H)
     sl = slice(y0, y1)
@@ -142,12 +146,15 @@ def test_volume_rectangle_cases(eng, position, axis, angle):
         pres0, light0, depth0 = eng.render(u, W, H, spp)
         st0 = eng.render_stats()
         eng.set_option("render_sched", 1)
-        pres, light, depth = eng.render(u, W, H, spp)
-        st1 = eng.render_stats()
-        np.testing.assert_array_equal(pres, pres0)
-        np.testing.assert_array_equal(light.view(np.uint16), light0.view(np.uint16))
-        np.testing.assert_array_equal(depth.view(np.uint16), depth0.view(np.uint16))
-        assert (st0.shadow_rays, st0.primary_cell_visits, st0.shadow_cell_visits) == (st1.shadow_rays, st1.primary_cell_visits, st1.shadow_cell_visits)
+        for stream, check in ((0, 0), (1, 1), (1, 0)):
+            eng.set_option("render_stream", stream)
+            eng.set_option("render_stream_check", check)
+            pres, light, depth = eng.render(u, W, H, spp)
+            st1 = eng.render_stats()
+            np.testing.assert_array_equal(pres, pres0)
+            np.testing.assert_array_equal(light.view(np.uint16), light0.view(np.uint16))
+            np.testing.assert_array_equal(depth.view(np.uint16), depth0.view(np.uint16))
+            assert (st0.shadow_rays, st0.primary_cell_visits, st0.shadow_cell_visits) == (st1.shadow_rays, st1.primary_cell_visits, st1.shadow_cell_visits)
     olight, odepth, opres, _ = ol.render(cells, G, u, W, H, 4)
     ok = np.abs(light.astype(np.float32)[..., :3] - olight[..., :3]).max(-1) <= 2e-3
     assert ok.mean() >= 0.995, ok.mean()

@@ -17,6 +17,7 @@ ap.add_argument("--grid", type=int, default=512)
 ap.add_argument("--sched", type=int, default=1)
 ap.add_argument("--density-rounds", type=int, default=4)
 ap.add_argument("--option", action="append", default=[], help="name=value engine options")
+ap.add_argument("--literal", type=int, default=0, help="1: the reference's own frame (render_mode 1), one sample per pixel, elapsedTime advancing")
 a = ap.parse_args()
 W, H = (int(v) for v in a.size.lower().split("x"))
 eng = Engine(0)
@@ -27,12 +28,18 @@ eng.set_option("render_sched", a.sched)
 for o in a.option:
     k, v = o.split("=")
     eng.set_option(k, int(v))
-u = host.uniform_block(W, H, host.orbit_camera())
-eng.render(u, W, H, a.spp, readback=False)
+vm = host.orbit_camera()
+if a.literal:
+    a.spp = 1
+    eng.set_render_mode(True)
+    eng.reset_render_history()
+frame_u = lambda i: host.uniform_block(W, H, vm, elapsed_time=0.5 + 0.01 * i, prev_view_mat=vm) if a.literal else host.uniform_block(W, H, vm)
+for i in range(3 if a.literal else 1):
+    eng.render(frame_u(i), W, H, a.spp, readback=False)
 eng.synchronize()
 t0 = time.perf_counter()
-for _ in range(a.frames):
-    eng.render(u, W, H, a.spp, readback=False)
+for i in range(a.frames):
+    eng.render(frame_u(10 + i), W, H, a.spp, readback=False)
 eng.synchronize()
 dt = time.perf_counter() - t0
 st = eng.render_stats()

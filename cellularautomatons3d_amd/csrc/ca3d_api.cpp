@@ -1661,10 +1661,11 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 	if (l.stream_scratch && l.stream_check)
 	{
 		// diagnostics: the stream passes counted where their interval filter and the reference's slab test disagreed (must be nowhere)
-		uint32_t bad = 0;
+		uint32_t bad[4] = {0, 0, 0, 0};
 		HIP_TRY(hipStreamSynchronize(h->stream));
-		HIP_TRY(hipMemcpy(&bad, static_cast<const uint32_t *>(l.stream_scratch) + 2, sizeof bad, hipMemcpyDeviceToHost));
-		if (bad) return fail(CA3D_ERR_DEVICE, "render_stream_check: the interval filter contradicted the slab test at %u live cells", bad);
+		HIP_TRY(hipMemcpy(bad, static_cast<const uint32_t *>(l.stream_scratch) + 2, sizeof bad, hipMemcpyDeviceToHost));
+		if (bad[0]) return fail(CA3D_ERR_DEVICE, "render_stream_check: the interval filter contradicted the slab test at %u live cells", bad[0]);
+		if (bad[1]) return fail(CA3D_ERR_DEVICE, "render_stream_check: %u looked-up answers had not been given in this frame (jobs lost by the queues; jobs %u .. %u)", bad[1], ~bad[2], bad[3]);
 	}
 	h->rstats.primary_rays = (uint64_t)width * ((l.row1 ? l.row1 : height) - l.row0) * spp;
 	if (presentation_rgba8) HIP_TRY(hipMemcpyAsync(presentation_rgba8, h->r_present, px * 4, hipMemcpyDeviceToHost, h->stream));

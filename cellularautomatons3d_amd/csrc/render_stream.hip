@@ -1,7 +1,7 @@
 // The converged frame of a dense packed volume as a RAY STREAM (gfx950): the same frame as render.hip's plain kernel, bit for
 // bit, drawn by four lean passes instead of one kernel that carries a sample from its view ray to its colour.
 //
-//   ca_stream_walk<primary>   persistent; lanes take sample jobs of the volume's screen rectangle from a queue of 8 x 8-pixel tiles,
+//   ca_stream_walk<primary>   persistent; lanes take sample jobs of the volume's screen rectangle from queues of 64-job chunks,
 //                             form the view ray (shade_sample up to its walk) and walk it; answer per job: hit distance | none
 //   ca_stream_shadow_rays     one lane per job: shade_sample with the answer looked up, up to the shadow ray; lit jobs leave the
 //                             point the shadow ray starts from
@@ -21,6 +21,9 @@
 // accumulated by the same float operations as render_device.inc's walk().
 #include <hip/hip_fp16.h>
 
+#include <cstdio>
+#include <vector>
+
 #include "ca3d_internal.h"
 
 namespace ca3d
@@ -31,16 +34,13 @@ namespace
 #include "render_device.inc"
 
 constexpr u32 kNoHit = 0xFFFFFFFFu; // a hit distance is never NaN (the slab test rejects NaN)
+constexpr u32 kUnanswered = 0x5A5A5A5Au; // check build: what the answer arrays are filled with before the passes (a distance of 1.5e16)
 enum : unsigned char { kOcclNone = 0, kOcclHit = 1, kOcclPending = 2 };
 
 #ifndef CA3D_STREAM_WAVES
 #define CA3D_STREAM_WAVES 8
 #endif
-#ifndef CA3D_STREAM_REFILL
-#define CA3D_STREAM_REFILL 24
-#endif
 constexpr int kStreamWaves = CA3D_STREAM_WAVES; // waves per SIMD the walk kernel is compiled for
-constexpr int kRefillAt = CA3D_STREAM_REFILL;   // lanes without a ray at which a wave leaves the stepping loop to take new jobs
 constexpr int kStatSlots = 64;
 
 struct StreamParams
@@ -49,13 +49,31 @@ struct StreamParams
 	u32 *hit;            // per job: the view ray's answer (float bits of the hit cube's slab entry, kNoHit)
 	unsigned char *occl; // per job: kOcclPending (lit, shadow ray waiting) -> kOcclHit / kOcclNone
 	float4 *rays;        // per lit job: the point the shadow ray starts from
-	u32 *ctl;            // [0] primary tile queue, [1] shadow tile queue, [2] filter / slab-test contradictions (check build),
-	                     // [16 + 4 * slot + {0 shadow rays, 1 primary visits, 2 shadow visits}] statistics, kStatSlots slots
-	u32 tiles, tiles_x;  // 8 x 8-pixel tiles of the rectangle; jobs of tile i: [i * 64 * spp, (i + 1) * 64 * spp), pixel-major
+	u32 *ctl;            // [2] filter / slab-test contradictions (check build); [16 + 4 * slot + {0 shadow rays, 1 primary visits, 2 shadow
+	                     // visits}] statistics, kStatSlots slots; [kQueueWords + 32 * (8 * pass + q)] head of queue q of walk pass `pass`
+	u32 chunks, chunks_x; // chunks of 64 jobs = pixel blocks (4 x 4 pixels at 4 samples, 8 x 8 at one) of the rectangle, row-major;
+	                      // jobs of chunk c: [64 c, 64 c + 64), pixel-major, a pixel's samples next to each other
 	u32 lg, lc;          // log2 G, log2 cols (power-of-two grids)
+	int refill;          // lanes without a ray at which a wave leaves the stepping loop to take new jobs (tuning: CA3D_STREAM_REFILL)
+	u32 lb;              // log2 of a chunk's pixel-block edge; jobs per chunk = spp << (2 lb)
+	u32 qmap;            // 0: queue q owns a contiguous eighth of the chunks (a band of the image); 1: every eighth chunk
+	u32 check;           // diagnostics build: answers were pre-set to kUnanswered and whoever looks one up counts those still unset in ctl[3]
+	unsigned long long *trace; // diagnostics (CA3D_STREAM_TRACE=<file>): 8 words per wave and walk pass — start, end (s_memrealtime, 100 MHz),
+	                           // refill rounds, stepping iterations, chunks taken, ticks spent refilling, jobs started, 0
 };
+constexpr u32 kQueueWords = 512, kNoChunk = 0xFFFFFFFFu;
 
 __device__ __forceinline__ u32 job_shift(const RenderParams &P) { return P.spp == 4u ? 2u : 0u; }
+
+// pixel of job r of chunk c
+__device__ __forceinline__ void job_pixel(const StreamParams &S, u32 c, u32 r, u32 &px, u32 &py, u32 &k)
+{
+	const RenderParams &P = S.R;
+	const u32 sh = job_shift(P), q = r >> sh, lb = S.lb;
+	k = r & ((1u << sh) - 1u);
+	px = P.rx0 + ((c % S.chunks_x) << lb) + (q & ((1u << lb) - 1u));
+	py = P.ry0 + ((c / S.chunks_x) << lb) + (q >> lb);
+}
 
 __device__ __forceinline__ void sample_uv(const RenderParams &P, u32 px, u32 py, u32 k, float &vu, float &vv)
 {
@@ -85,10 +103,11 @@ struct LookupPrimaryRecordShadow // second pass
 {
 	static constexpr bool kSkipBox = false, kStopAfterPrimary = false, kStopAfterShadow = true;
 	u32 answer;
-	bool lit = false;
+	bool lit = false, unanswered = false;
 	v3 p;
 	__device__ __forceinline__ bool primary(const RenderParams &, v3, v3, v3, v3, float, v3, float &tnear)
 	{
+		unanswered = answer == kUnanswered;
 		if (answer == kNoHit) return false;
 		tnear = __uint_as_float(answer);
 		return true;
@@ -105,13 +124,18 @@ struct LookupBoth // last pass
 	static constexpr bool kSkipBox = false, kStopAfterPrimary = false, kStopAfterShadow = false;
 	u32 answer;
 	const unsigned char *occl;
+	bool unanswered = false;
 	__device__ __forceinline__ bool primary(const RenderParams &, v3, v3, v3, v3, float, v3, float &tnear)
 	{
 		if (answer == kNoHit) return false;
 		tnear = __uint_as_float(answer);
 		return true;
 	}
-	__device__ __forceinline__ bool shadow(const RenderParams &, v3, v3, float, v3, int, int, int) { return *occl == kOcclHit; }
+	__device__ __forceinline__ bool shadow(const RenderParams &, v3, v3, float, v3, int, int, int)
+	{
+		unanswered = *occl != kOcclHit && *occl != kOcclNone;
+		return *occl == kOcclHit;
+	}
 };
 
 // ---- the stepping loop ------------------------------------------------------------------------------------------------------
@@ -229,29 +253,75 @@ __device__ __forceinline__ int walk_cell(const StreamParams &S, Walker &w, bool 
 	return (outside || t >= w.tmax) ? 2 : 0;
 }
 
+// Job source of the walk passes. The rectangle's jobs come in chunks (a pixel block x its samples, a power of two of jobs). Chunks
+// are handed to WORKGROUPS — eight queues, one per XCD (workgroups go to the XCDs round-robin), a load before the atomic so that an
+// empty queue costs none, the first chunk of a workgroup its own (thousands of pullers asking at once queue for tens of
+// microseconds behind a word: ~88 dequeues per us) — and inside a workgroup the jobs are handed to LANES through a ticket counter in
+// LDS: a wave whose idle lanes reach the refill threshold draws that many tickets; ticket t is job t % per of the workgroup's
+// (t / per)-th chunk. The wave that draws the first ticket of chunk k fetches chunk k + 1's id from the global queue and posts it in a
+// ring of slots, so the id is there long before chunk k runs out; a lane whose ticket lands in a chunk not yet posted waits for it.
+// When the queues run dry the id posted is "none", and so is every id after it.
+// Per-wave chunk ownership (the first form of this kernel) left waves with one or with two heavy chunks of 256 jobs: the launch
+// lasted twice the average wave's life. Chunks of 64 jobs handed to waves through the global queues cost more in atomics than they
+// balanced (1.55 ms against 0.90).
+constexpr int kWalkThreads = 512, kWalkWaves = kWalkThreads / 64, kSlots = 8;
+
 template <bool SHADOW, bool P2, bool CHECK>
-__global__ __launch_bounds__(256, kStreamWaves) void ca_stream_walk(StreamParams S)
+__global__ __launch_bounds__(kWalkThreads, kStreamWaves) void ca_stream_walk(StreamParams S)
 {
 	const RenderParams &P = S.R;
 	if (occ_skip_enabled(P)) return; // a sparse volume: the skipping kernels of render.hip draw the frame
-	__shared__ float ctx_lds[6][256];
+	__shared__ float ctx_lds[6][kWalkThreads];
+	__shared__ u32 q_ticket, q_id[kSlots], q_seq[kSlots], q_read[kSlots];
 	const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	float *ctx = &ctx_lds[0][tid];
-	constexpr int stride = 256;
+	constexpr int stride = kWalkThreads;
 	const float cs = 1.0f / (float)P.G;
 	const float vis = cs * P.u[U_CELLSIZE] * 0.5f;
 	const v3 vhalf = V(vis, vis, vis);
 	const float k0 = 0.5f - 0.5f * fabsf(P.u[U_CELLSIZE]), k1 = 1.0f - k0;
 	const float eps_a = 4.76837158203125e-7f * (float)P.G;
-	const u32 sh = job_shift(P), per = 64u << sh; // jobs of a tile
-	const u32 nwaves = gridDim.x * 4u;
-	u32 tile = blockIdx.x * 4u + (u32)wave; // the first tile is the wave's own; the queue hands out the rest
-	bool more = tile < S.tiles;
-	u32 jn = 0;                             // next job of the tile nobody has taken
+	const u32 qown = blockIdx.x & 7u;
+	u32 qcur = qown, qtried = 0;
+	const u32 lper = 2u * S.lb + job_shift(P), per = 1u << lper; // jobs of a chunk
+	auto q_lo = [&](u32 q) { return S.qmap ? q : (u32)(((unsigned long long)S.chunks * q) >> 3); };
+	auto q_len = [&](u32 q) { return S.qmap ? (S.chunks + 7u - q) >> 3 : q_lo(q + 1u) - q_lo(q); };
+	auto q_chunk = [&](u32 q, u32 pos) { return S.qmap ? pos * 8u + q : q_lo(q) + pos; };
+	auto q_static = [&](u32 q) { return (gridDim.x + 7u - q) >> 3; }; // workgroups whose own chunk comes out of queue q
+	auto next_chunk = [&]() -> u32 { // wave-uniform
+		while (qtried < 8u)
+		{
+			u32 *head = S.ctl + kQueueWords + 32u * ((SHADOW ? 8u : 0u) + qcur);
+			const u32 len = q_len(qcur), st = q_static(qcur);
+			u32 pos = kNoChunk;
+			if (lane == 0)
+			{
+				if (st + __hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < len) pos = st + atomicAdd(head, 1u);
+			}
+			pos = (u32)__builtin_amdgcn_readfirstlane((int)pos);
+			if (pos < len) return q_chunk(qcur, pos);
+			qcur = (qcur + 1u) & 7u;
+			qtried++;
+		}
+		return kNoChunk;
+	};
+	if (wave == 0)
+	{
+		const u32 idx = blockIdx.x >> 3;
+		const u32 c0 = idx < q_len(qown) ? q_chunk(qown, idx) : next_chunk();
+		if (lane == 0) { q_ticket = 0; q_id[0] = c0; q_seq[0] = 1u; }
+		if (lane > 0 && lane < kSlots) q_seq[lane] = 0u;
+		if (lane < kSlots) q_read[lane] = 0u;
+	}
+	__syncthreads();
+	bool more = true;
 	int job = -1, term = 0;
 	bool exempt = false;
 	Walker w;
 	u32 visits = 0; // wave-uniform
+	const unsigned long long tr_t0 = S.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
+	unsigned long long tr_refill = 0;
+	u32 tr_rounds = 0, tr_iters = 0, tr_chunks = 0, tr_jobs = 0;
 	for (;;)
 	{
 		// retire the lanes whose walk is over
@@ -273,83 +343,133 @@ __global__ __launch_bounds__(256, kStreamWaves) void ca_stream_walk(StreamParams
 			term = 0;
 		}
 		// refill
+		const unsigned long long tr_r0 = S.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
 		for (;;)
 		{
 			const unsigned long long idle = __ballot(job < 0);
 			const int nidle = __popcll(idle);
-			if (!more || nidle < kRefillAt) break;
-			const u32 cand = jn + (u32)__popcll(idle & ((1ull << lane) - 1ull));
-			if (job < 0 && cand < per)
+			if (!more || nidle < S.refill) break;
+			tr_rounds++;
+			u32 base = 0;
+			if (lane == 0) base = atomicAdd(&q_ticket, (u32)nidle);
+			base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+			// the first ticket of a chunk is among these: post the next chunk's id (at most one chunk starts in a draw: nidle <= 64 <= per)
+			const u32 kfirst = (base + per - 1u) >> lper;
+			if ((kfirst << lper) < base + (u32)nidle)
 			{
-				const u32 j = tile * per + cand;
-				const u32 q = cand >> sh, k = cand & ((1u << sh) - 1u);
-				const u32 px = P.rx0 + (tile % S.tiles_x) * 8u + (q & 7u), py = P.ry0 + (tile / S.tiles_x) * 8u + (q >> 3);
-				if (!SHADOW)
+				// ... unless chunk kfirst itself is "none": the queues ran dry, and everything after the first "none" must be "none" too —
+				// a wave that meets one stops drawing, so a real chunk posted behind it would never be drawn (two posters racing for the
+				// last chunks of the queues did exactly that: the one for chunk k got nothing, the one for k + 1 the last chunk). Chunk
+				// kfirst was asked for a whole chunk ago: it is there.
+				u32 prev = 0;
+				if (lane == 0)
 				{
-					if (px < P.W && py < P.row1)
+					while (__hip_atomic_load(&q_seq[kfirst % kSlots], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != kfirst + 1u) __builtin_amdgcn_s_sleep(1);
+					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+					prev = q_id[kfirst % kSlots];
+				}
+				prev = (u32)__builtin_amdgcn_readfirstlane((int)prev);
+				const u32 c = prev == kNoChunk ? kNoChunk : next_chunk();
+				tr_chunks++;
+				if (lane == 0)
+				{
+					// the slot's last tenant (chunk kfirst + 1 - kSlots) must have been read by every lane that drew one of its tickets:
+					// q_read counts the tickets read per slot, all of its tenants together (they were all drawn before this draw, and a
+					// drawer reads at once: the wait is over before it begins, but it is what makes the ring safe)
+					const u32 m = kfirst + 1u;
+					while (__hip_atomic_load(&q_read[m % kSlots], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != (m / kSlots) << lper) __builtin_amdgcn_s_sleep(1);
+					q_id[(kfirst + 1u) % kSlots] = c;
+					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+					__hip_atomic_store(&q_seq[(kfirst + 1u) % kSlots], kfirst + 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				}
+			}
+			bool dry = false;
+			if (job < 0)
+			{
+				const u32 t = base + (u32)__popcll(idle & ((1ull << lane) - 1ull));
+				const u32 k = t >> lper, cand = t & (per - 1u);
+				while (__hip_atomic_load(&q_seq[k % kSlots], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != k + 1u) __builtin_amdgcn_s_sleep(2);
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+				const u32 chunk = q_id[k % kSlots];
+				if (chunk == kNoChunk) dry = true;
+				else
+				{
+					const u32 j = chunk * per + cand;
+					u32 px, py, ks;
+					job_pixel(S, chunk, cand, px, py, ks);
+					if (!SHADOW)
 					{
-						float vu, vv;
-						sample_uv(P, px, py, k, vu, vv);
-						CapturePrimary tr;
-						shade_sample_with(P, vu, vv, tr);
-						if (tr.wanted)
+						if (px < P.W && py < P.row1)
 						{
-							if (0.0f >= tr.len) S.hit[j] = kNoHit; // walk(): `if (t >= tmax) return false` before the first cell
-							else
+							float vu, vv;
+							sample_uv(P, px, py, ks, vu, vv);
+							CapturePrimary tr;
+							shade_sample_with(P, vu, vv, tr);
+							if (tr.wanted)
 							{
-								walker_begin(P, w, tr.enter, tr.dir, 0.0f, tr.len, ctx, stride);
-								job = (int)j;
+								if (0.0f >= tr.len) S.hit[j] = kNoHit; // walk(): `if (t >= tmax) return false` before the first cell
+								else
+								{
+									walker_begin(P, w, tr.enter, tr.dir, 0.0f, tr.len, ctx, stride);
+									job = (int)j;
+								}
 							}
 						}
 					}
-				}
-				else if (S.occl[j] == kOcclPending)
-				{
-					// shade_sample_with between the shading gate and the shadow walk
-					const float4 r = S.rays[j];
-					const v3 p = V(r.x, r.y, r.z);
-					const v3 light_pos = V(P.u[U_LIGHT], P.u[U_LIGHT + 1], P.u[U_LIGHT + 2]);
-					const v3 ldir = norm3(light_pos - p);
-					float vn, vf;
-					ray_cube(p, ldir, V(0.0f, 0.0f, 0.0f), V(kHalf, kHalf, kHalf), vn, vf);
-					const v3 vexit = p + ldir * vf;
-					const v3 sseg = vexit - p;
-					const float slen = len3(sseg);
-					if (0.0025f >= slen) S.occl[j] = kOcclNone;
-					else
+					else if (S.occl[j] == kOcclPending)
 					{
-						walker_begin(P, w, p, norm3(sseg), 0.0025f, slen, ctx, stride);
-						const int cx = (int)floorf(to_cells(P, p.x)), cy = (int)floorf(to_cells(P, p.y)), cz = (int)floorf(to_cells(P, p.z));
-						exempt = w.ix == cx && w.iy == cy && w.iz == cz; // any(cell != startCell) :664
-						job = (int)j;
+						// shade_sample_with between the shading gate and the shadow walk
+						const float4 r = S.rays[j];
+						const v3 p = V(r.x, r.y, r.z);
+						const v3 light_pos = V(P.u[U_LIGHT], P.u[U_LIGHT + 1], P.u[U_LIGHT + 2]);
+						const v3 ldir = norm3(light_pos - p);
+						float vn, vf;
+						ray_cube(p, ldir, V(0.0f, 0.0f, 0.0f), V(kHalf, kHalf, kHalf), vn, vf);
+						const v3 vexit = p + ldir * vf;
+						const v3 sseg = vexit - p;
+						const float slen = len3(sseg);
+						if (0.0025f >= slen) S.occl[j] = kOcclNone;
+						else
+						{
+							walker_begin(P, w, p, norm3(sseg), 0.0025f, slen, ctx, stride);
+							const int cx = (int)floorf(to_cells(P, p.x)), cy = (int)floorf(to_cells(P, p.y)), cz = (int)floorf(to_cells(P, p.z));
+							exempt = w.ix == cx && w.iy == cy && w.iz == cz; // any(cell != startCell) :664
+							job = (int)j;
+						}
 					}
 				}
 			}
-			jn += (u32)nidle;
-			if (jn >= per)
+			if (__ballot(dry) != 0ull) more = false; // the queues are empty (every later chunk is posted as "none" too)
+			if (lane == 0)
 			{
-				u32 nt = 0;
-				if (lane == 0) nt = nwaves + atomicAdd(&S.ctl[SHADOW ? 1 : 0], 1u);
-				tile = (u32)__builtin_amdgcn_readfirstlane((int)nt);
-				more = tile < S.tiles;
-				jn = 0;
+				// tickets read, per chunk (a draw spans at most two)
+				const u32 klo = base >> lper, nlo = min((u32)nidle, ((klo + 1u) << lper) - base);
+				atomicAdd(&q_read[klo % kSlots], nlo);
+				if ((u32)nidle > nlo) atomicAdd(&q_read[(klo + 1u) % kSlots], (u32)nidle - nlo);
 			}
 		}
 		int walking = __popcll(__ballot(job >= 0));
+		if (S.trace) { tr_refill += __builtin_amdgcn_s_memrealtime() - tr_r0; tr_jobs += (u32)walking; }
 		if (walking == 0)
 		{
 			if (!more) break;
 			continue;
 		}
-		const int leave_at = more ? 64 - kRefillAt : 0;
+		const int leave_at = more ? 64 - S.refill : 0;
 		do
 		{
 			visits += (u32)walking;
+			tr_iters++;
 			if (job >= 0 && term == 0) term = walk_cell<SHADOW, P2, CHECK>(S, w, exempt, vhalf, k0, k1, eps_a, ctx, stride);
 			walking = __popcll(__ballot(job >= 0 && term == 0));
 		} while (walking > leave_at);
 	}
-	if (lane == 0 && visits) atomicAdd(&S.ctl[16 + 4 * ((blockIdx.x * 4u + (u32)wave) % kStatSlots) + (SHADOW ? 2 : 1)], visits);
+	if (S.trace && lane == 0)
+	{
+		unsigned long long *t = S.trace + 8ull * ((SHADOW ? gridDim.x * (u32)kWalkWaves : 0u) + blockIdx.x * (u32)kWalkWaves + (u32)wave);
+		t[0] = tr_t0; t[1] = __builtin_amdgcn_s_memrealtime(); t[2] = tr_rounds; t[3] = tr_iters; t[4] = tr_chunks; t[5] = tr_refill; t[6] = tr_jobs; t[7] = 0;
+	}
+	if (lane == 0 && visits) atomicAdd(&S.ctl[16 + 4 * ((blockIdx.x * (u32)kWalkWaves + (u32)wave) % kStatSlots) + (SHADOW ? 2 : 1)], visits);
 }
 
 // Second pass: every job of the rectangle, one lane each.
@@ -357,14 +477,14 @@ __global__ __launch_bounds__(256) void ca_stream_shadow_rays(StreamParams S)
 {
 	const RenderParams &P = S.R;
 	if (occ_skip_enabled(P)) return;
-	const u32 sh = job_shift(P), per = 64u << sh;
 	const u32 j = blockIdx.x * 256u + threadIdx.x;
-	const u32 tile = j / per, cand = j % per;
+	const u32 lj = 2u * S.lb + job_shift(P); // log2 jobs per chunk
+	const u32 c = j >> lj;
 	bool lit = false;
-	if (tile < S.tiles)
+	if (c < S.chunks)
 	{
-		const u32 q = cand >> sh, k = cand & ((1u << sh) - 1u);
-		const u32 px = P.rx0 + (tile % S.tiles_x) * 8u + (q & 7u), py = P.ry0 + (tile / S.tiles_x) * 8u + (q >> 3);
+		u32 px, py, k;
+		job_pixel(S, c, j & ((1u << lj) - 1u), px, py, k);
 		unsigned char flag = kOcclNone;
 		if (px < P.W && py < P.row1)
 		{
@@ -373,6 +493,7 @@ __global__ __launch_bounds__(256) void ca_stream_shadow_rays(StreamParams S)
 			LookupPrimaryRecordShadow tr;
 			tr.answer = S.hit[j]; // (only read by primary(): a view ray that misses the volume never asks)
 			shade_sample_with(P, vu, vv, tr);
+			if (S.check && tr.unanswered) { atomicAdd(&S.ctl[3], 1u); atomicMax(&S.ctl[4], ~j); atomicMax(&S.ctl[5], j); }
 			if (tr.lit)
 			{
 				S.rays[j] = make_float4(tr.p.x, tr.p.y, tr.p.z, 0.0f);
@@ -386,7 +507,7 @@ __global__ __launch_bounds__(256) void ca_stream_shadow_rays(StreamParams S)
 	if ((threadIdx.x & 63u) == 0u && n) atomicAdd(&S.ctl[16 + 4 * (blockIdx.x % kStatSlots) + 0], n);
 }
 
-// Last pass: one lane per pixel of the rectangle, tile by tile (a wave = one 8 x 8 tile); the plain kernel's sums and outputs.
+// Last pass: one lane per pixel of the rectangle, chunk by chunk; the plain kernel's sums and outputs.
 __global__ __launch_bounds__(256) void ca_stream_resolve(StreamParams S)
 {
 	const RenderParams &P = S.R;
@@ -399,10 +520,12 @@ __global__ __launch_bounds__(256) void ca_stream_resolve(StreamParams S)
 		if (sum) atomicAdd(&P.counters[threadIdx.x], sum);
 	}
 	const u32 sh = job_shift(P);
-	const u32 n = blockIdx.x * 256u + threadIdx.x; // pixel slot: tile * 64 + q
-	const u32 tile = n >> 6, q = n & 63u;
-	if (tile >= S.tiles) return;
-	const u32 px = P.rx0 + (tile % S.tiles_x) * 8u + (q & 7u), py = P.ry0 + (tile / S.tiles_x) * 8u + (q >> 3);
+	const u32 n = blockIdx.x * 256u + threadIdx.x; // pixel slot: its first job is n << sh
+	const u32 lj = 2u * S.lb + sh;
+	const u32 c = (n << sh) >> lj;
+	if (c >= S.chunks) return;
+	u32 px, py, k0;
+	job_pixel(S, c, (n << sh) & ((1u << lj) - 1u), px, py, k0);
 	if (px >= P.W || py >= P.row1) return;
 	float r = 0.0f, g = 0.0f, b = 0.0f, a = 0.0f, d0 = 0.0f;
 	for (u32 k = 0; k < P.spp; k++)
@@ -414,6 +537,7 @@ __global__ __launch_bounds__(256) void ca_stream_resolve(StreamParams S)
 		tr.answer = S.hit[j];
 		tr.occl = S.occl + j;
 		const Sample s = shade_sample_with(P, vu, vv, tr);
+		if (S.check && tr.unanswered) atomicAdd(&S.ctl[3], 1u);
 		r += s.r; g += s.g; b += s.b; a += s.a;
 		if (k == 0) d0 = s.depth;
 	}
@@ -443,9 +567,9 @@ __global__ __launch_bounds__(256) void ca_stream_resolve(StreamParams S)
 template <bool P2, bool CHECK>
 void launch_walks(const StreamParams &S, u32 wgs, u32 job_blocks, hipStream_t stream)
 {
-	hipLaunchKernelGGL((ca_stream_walk<false, P2, CHECK>), dim3(wgs), dim3(256), 0, stream, S);
+	hipLaunchKernelGGL((ca_stream_walk<false, P2, CHECK>), dim3(wgs), dim3(kWalkThreads), 0, stream, S);
 	hipLaunchKernelGGL(ca_stream_shadow_rays, dim3(job_blocks), dim3(256), 0, stream, S);
-	hipLaunchKernelGGL((ca_stream_walk<true, P2, CHECK>), dim3(wgs), dim3(256), 0, stream, S);
+	hipLaunchKernelGGL((ca_stream_walk<true, P2, CHECK>), dim3(wgs), dim3(kWalkThreads), 0, stream, S);
 }
 
 } // namespace
@@ -475,8 +599,14 @@ hipError_t launch_render_stream(const void *params, void *scratch, uint32_t W, u
 	S.hit = reinterpret_cast<u32 *>(base + hit_off);
 	S.occl = reinterpret_cast<unsigned char *>(base + occl_off);
 	S.rays = reinterpret_cast<float4 *>(base + rays_off);
-	S.tiles_x = (P.rx1 - P.rx0) / 8u;
-	S.tiles = S.tiles_x * ((P.ry1 - P.ry0) / 8u);
+	static const int lb_env = getenv("CA3D_STREAM_LB") ? atoi(getenv("CA3D_STREAM_LB")) : 0;
+	static const int qmap_env = getenv("CA3D_STREAM_QMAP") ? atoi(getenv("CA3D_STREAM_QMAP")) : 0;
+	S.lb = lb_env >= 1 && lb_env <= 4 ? (u32)lb_env : (P.spp == 4u ? 3u : 4u); // pixel block of a chunk (the rectangle is aligned to 32 x 16)
+	S.qmap = qmap_env == 1 || !getenv("CA3D_STREAM_QMAP") ? 1u : 0u;
+	const u32 edge = 1u << S.lb;
+	S.chunks_x = (P.rx1 - P.rx0) / edge;
+	S.chunks = S.chunks_x * ((P.ry1 - P.ry0) / edge);
+	const u32 per = P.spp << (2u * S.lb);
 	const bool p2 = (P.G & (P.G - 1u)) == 0u;
 	S.lg = S.lc = 0;
 	if (p2)
@@ -484,16 +614,43 @@ hipError_t launch_render_stream(const void *params, void *scratch, uint32_t W, u
 		while ((1u << S.lg) < P.G) S.lg++;
 		S.lc = S.lg - 5u;
 	}
+	static const int refill_env = getenv("CA3D_STREAM_REFILL") ? atoi(getenv("CA3D_STREAM_REFILL")) : 0;
+	S.refill = refill_env >= 1 && refill_env <= 64 ? refill_env : 24;
+	static const char *trace_path = getenv("CA3D_STREAM_TRACE");
+	static unsigned long long *trace_buf = nullptr;
+	const size_t trace_words = 8u * 2u * 4u * 256u * 8u * 2u; // two walk passes, up to 16 384 waves each
+	if (trace_path && !trace_buf && hipMalloc((void **)&trace_buf, trace_words * 8u) != hipSuccess) trace_buf = nullptr;
+	S.trace = trace_path ? trace_buf : nullptr;
+	if (S.trace) hipMemsetAsync(S.trace, 0, trace_words * 8u, stream);
+	S.check = check ? 1u : 0u;
+	if (check)
+	{
+		// every answer a pass looks up must have been given in THIS frame: a job the queues lost would otherwise show last frame's
+		hipMemsetAsync(S.hit, 0x5A, (size_t)S.chunks * per * 4u, stream);
+		hipMemsetAsync(S.occl, 0x5A, (size_t)S.chunks * per, stream);
+	}
 	hipError_t e = hipMemsetAsync(S.ctl, 0, 4096, stream);
 	if (e != hipSuccess) return e;
 	int dev = 0, cus = 256;
 	if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-	const u32 wgs = min((S.tiles + 3u) / 4u, (u32)cus * (u32)kStreamWaves);
-	const u32 jobs = S.tiles * 64u * P.spp;
-	const u32 job_blocks = (jobs + 255u) / 256u;
+	const u32 wgs = min(S.chunks, (u32)cus * (u32)kStreamWaves * 4u / (u32)kWalkWaves); // persistent: what the chip holds at kStreamWaves per SIMD
+	const u32 job_blocks = (S.chunks * per + 255u) / 256u;
 	if (p2) { if (check) launch_walks<true, true>(S, wgs, job_blocks, stream); else launch_walks<true, false>(S, wgs, job_blocks, stream); }
 	else { if (check) launch_walks<false, true>(S, wgs, job_blocks, stream); else launch_walks<false, false>(S, wgs, job_blocks, stream); }
-	hipLaunchKernelGGL(ca_stream_resolve, dim3((S.tiles * 64u + 255u) / 256u), dim3(256), 0, stream, S);
+	hipLaunchKernelGGL(ca_stream_resolve, dim3((S.chunks * (per / P.spp) + 255u) / 256u), dim3(256), 0, stream, S);
+	if (S.trace)
+	{
+		// the last frame wins; [0] = waves per pass
+		std::vector<unsigned long long> t(trace_words);
+		if (hipStreamSynchronize(stream) == hipSuccess && hipMemcpy(t.data(), S.trace, trace_words * 8u, hipMemcpyDeviceToHost) == hipSuccess)
+			if (FILE *f = fopen(trace_path, "wb"))
+			{
+				const unsigned long long n = (unsigned long long)wgs * (unsigned)kWalkWaves;
+				fwrite(&n, 8, 1, f);
+				fwrite(t.data(), 8, (size_t)n * 16u, f);
+				fclose(f);
+			}
+	}
 	return hipGetLastError();
 }
 

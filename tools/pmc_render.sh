@@ -12,7 +12,7 @@ pmc a "GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VAL
 pmc b "SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY"
 pmc c "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum"
 pmc d "TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCP_LATENCY_sum"
-pmc e "TCP_PENDING_STALL_CYCLES_sum TCP_TA_TCP_STATE_READ_sum TCP_GATE_EN1_sum TCP_GATE_EN2_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum" || true
+
 python - "$out" "$tag" <<'PY'
 import csv, collections, sys, json
 out, tag = sys.argv[1], sys.argv[2]
@@ -24,8 +24,8 @@ for p in "abcde":
     acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(set)
     for r in rows:
         k = r["Kernel_Name"]
-        if "render" not in k: continue
-        k = k.replace("void ca3d::(anonymous namespace)::", "").split("(ca3d")[0]
+        if "render" not in k and "stream" not in k: continue
+        k = k.replace("void ", "").replace("ca3d::(anonymous namespace)::", "").split("(ca3d")[0].split("(StreamParams")[0].split("(RenderParams")[0].split("(FrameParams")[0]
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[k].add(r["Dispatch_Id"])
     for k, v in acc.items():
         res.setdefault(k, {}).update({c: x / len(n[k]) for c, x in v.items()})

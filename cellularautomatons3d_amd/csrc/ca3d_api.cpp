@@ -167,6 +167,9 @@ struct ca3d_engine
 	int render_skip = 1; // empty-space skipping on sparse volumes
 	int render_stream = 1; // dense packed volumes: the ray-stream passes (render_stream.hip) instead of the in-wave scheduled kernel
 	int render_stream_check = 0; // diagnostics: count filter / slab-test contradictions (ca3d_get_render_stats is unchanged; see "render_stream_contradictions")
+	int render_frame_bricks = 1; // literal frame mode: the batched march over a bricked copy of the volume (render_frame.hip); 0: ca_render_frame_packed
+	uint32_t *r_bricks = nullptr;
+	size_t r_bricks_bytes = 0;
 	void *r_stream = nullptr;    // scratch of the stream passes
 	size_t r_stream_bytes = 0;
 	int r_swap = 0;
@@ -847,6 +850,7 @@ int ca3d_destroy(ca3d_t *h)
 	if (h->r_counters) hipFree(h->r_counters);
 	if (h->r_occ) hipFree(h->r_occ);
 	if (h->r_stream) hipFree(h->r_stream);
+	if (h->r_bricks) hipFree(h->r_bricks);
 	if (h->r_aux) hipStreamDestroy(h->r_aux);
 	if (h->r_fork) hipEventDestroy(h->r_fork);
 	if (h->r_join) hipEventDestroy(h->r_join);
@@ -1642,6 +1646,20 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 		l.stream_scratch = h->r_stream;
 		l.stream_check = h->render_stream_check != 0;
 	}
+	if (h->render_mode == 1 && h->render_frame_bricks && frame_bricks_applies(h->G))
+	{
+		const size_t need = frame_bricks_bytes(h->G);
+		if (h->r_bricks_bytes != need)
+		{
+			HIP_TRY(hipStreamSynchronize(h->stream));
+			if (h->r_bricks) HIP_TRY(hipFree(h->r_bricks));
+			h->r_bricks = nullptr;
+			h->r_bricks_bytes = 0;
+			HIP_TRY(hipMalloc((void **)&h->r_bricks, need));
+			h->r_bricks_bytes = need;
+		}
+		l.bricks = h->r_bricks;
+	}
 	HIP_TRY(hipEventRecord(h->rev_start, h->stream));
 	hipError_t e = launch_render(l, h->stream);
 	if (e != hipSuccess) return fail(CA3D_ERR_DEVICE, "render launch failed: %s", hipGetErrorString(e));
@@ -1755,6 +1773,7 @@ int ca3d_set_option(ca3d_t *h, const char *name, int64_t value)
 	if (!strcmp(name, "render_indirect")) { h->render_indirect = value ? 1 : 0; return CA3D_OK; }
 	if (!strcmp(name, "render_sched")) { h->render_sched = value ? 1 : 0; return CA3D_OK; }
 	if (!strcmp(name, "render_skip")) { h->render_skip = value ? 1 : 0; return CA3D_OK; }
+	if (!strcmp(name, "render_frame_bricks")) { h->render_frame_bricks = value ? 1 : 0; return CA3D_OK; }
 	if (!strcmp(name, "render_stream")) { h->render_stream = value ? 1 : 0; return CA3D_OK; }
 	if (!strcmp(name, "render_stream_check")) { h->render_stream_check = value ? 1 : 0; return CA3D_OK; }
 	if (!strcmp(name, "render_row_begin") || !strcmp(name, "render_row_end"))

@@ -148,6 +148,8 @@ struct RenderLaunch
 	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 	// mode 0, packed, scheduled: scratch of the ray-stream pipeline (render_stream.hip; stream_scratch_bytes(W, H, spp) bytes) — with it the
 	// dense-volume part of the frame is drawn by the stream passes instead of ca_render_packed_sched (same frame, bit for bit). Null: not used.
+	uint32_t *bricks = nullptr; // mode 1: room for the bricked copy of the volume (frame_bricks_bytes(G)); with it — and a power-of-two grid — the
+	                            // frame is drawn by render_frame.hip's batched march instead of ca_render_frame_packed (same frame, bit for bit)
 	void *stream_scratch = nullptr;
 	bool stream_check = false; // diagnostics: every live-cell decision of the interval filter is checked against the slab test and contradictions counted
 };
@@ -159,6 +161,10 @@ hipError_t launch_render(const RenderLaunch &l, hipStream_t stream);
 // render_stream.hip: bytes of scratch a frame of this size needs at most (and where its three arrays start); the passes themselves
 // (`params`: render.hip's launch parameters with the volume's screen rectangle filled in)
 size_t stream_scratch_bytes(uint32_t W, uint32_t H, uint32_t spp, size_t *hit_off, size_t *occl_off, size_t *rays_off);
+// render_frame.hip: the literal frame over a bricked copy of the volume (`frame_params`: render.hip's FrameParams)
+size_t frame_bricks_bytes(uint32_t G);
+bool frame_bricks_applies(uint32_t G);
+hipError_t launch_render_frame_bricks(const void *frame_params, uint32_t *bricks, hipStream_t stream);
 hipError_t launch_render_stream(const void *params, void *scratch, uint32_t W, uint32_t H, bool check, hipStream_t stream);
 
 // ca_packed.hip / ca_unpacked.hip

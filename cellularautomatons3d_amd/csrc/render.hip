@@ -734,67 +734,7 @@ __global__ __launch_bounds__(256) void ca_occupancy_coarse(unsigned long long *_
 }
 
 // ================================================================================================ literal frame
-// One frame exactly as fragment_main (800-890) produces it — jittered fixed-step marches, history look-ups,
-// depth repair, temporal blend — for hosts that want the reference's own accumulation behaviour
-// (ca3d_set_option("render_mode", 1)). sin() of the jitter hash is evaluated in double precision and rounded to
-// f32 (WGSL leaves it implementation-defined); history fetches outside the target or at NaN coordinates read 0.
-struct FrameParams
-{
-	RenderParams base;
-	const uint2 *prev_light; // RGBA16F written by the previous frame
-	const u32 *prev_depth;   // RG16F
-};
-
-__device__ __forceinline__ float fract1(float x) { return x - floorf(x); }
-
-__device__ float n1rand(const RenderParams &P, float u, float v)
-{
-	const float t = 0.07f * fract1(P.u[U_TIME]);
-	const float d = (t + u) * 12.9898f + (t + v) * 78.233f;
-	const float s = (float)sin((double)d);
-	return fract1(s * 43758.5453f);
-}
-
-__device__ __forceinline__ u32 f2u(float f) { return !(f >= 0.0f) ? 0u : (f >= 4294967296.0f ? 0xFFFFFFFFu : (u32)f); }
-
-__device__ void reprojected_uv(const RenderParams &P, v3 p, float &ux, float &uy)
-{
-	const float *m = P.u + U_PREVPROJVIEWINV;
-	const float q0 = m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12];
-	const float q1 = m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13];
-	const float q3 = m[3] * p.x + m[7] * p.y + m[11] * p.z + m[15];
-	const float cx = q0 / q3, cy = q1 / q3;
-	ux = cx * 0.5f + 0.5f;
-	uy = -cy * 0.5f + 0.5f;
-}
-
-__device__ bool texel_xy(const RenderParams &P, float fx, float fy, size_t &idx)
-{
-	if (!(fx == fx) || !(fy == fy)) return false;
-	if (fx <= -1.0f || fy <= -1.0f || fx >= (float)P.W || fy >= (float)P.H) return false;
-	const int x = (int)fx, y = (int)fy;
-	if (x < 0 || y < 0 || x >= (int)P.W || y >= (int)P.H) return false;
-	idx = (size_t)y * P.W + (size_t)x;
-	return true;
-}
-
-struct CellU
-{
-	v3 origin;
-	u32 x, y, z, idx;
-};
-
-__device__ CellU cell_u(const RenderParams &P, v3 p)
-{
-	const float cs = 1.0f / (float)P.G;
-	const v3 f = V(floorf(to_cells(P, p.x)), floorf(to_cells(P, p.y)), floorf(to_cells(P, p.z)));
-	CellU r;
-	r.origin = V(f.x * cs + cs * 0.5f - kHalf, f.y * cs + cs * 0.5f - kHalf, f.z * cs + cs * 0.5f - kHalf);
-	r.x = f2u(f.x); r.y = f2u(f.y); r.z = f2u(f.z);
-	r.idx = r.x + r.y * P.G + r.z * (u32)((float)P.G * (float)P.G);
-	return r;
-}
-
+// (FrameParams, the jitter hash, the history look-ups: render_device.inc)
 __global__ __launch_bounds__(256) void ca_render_frame_packed(FrameParams F)
 {
 	const RenderParams &P = F.base;
@@ -1085,7 +1025,12 @@ hipError_t launch_render(const RenderLaunch &l, hipStream_t stream)
 		F.base = P;
 		F.prev_light = reinterpret_cast<const uint2 *>(l.prev_light);
 		F.prev_depth = l.prev_depth;
-		hipLaunchKernelGGL(ca_render_frame_packed, grid, dim3(256), 0, stream, F);
+		if (l.bricks && frame_bricks_applies(l.G))
+		{
+			hipError_t e = launch_render_frame_bricks(&F, l.bricks, stream);
+			if (e != hipSuccess) return e;
+		}
+		else hipLaunchKernelGGL(ca_render_frame_packed, grid, dim3(256), 0, stream, F);
 	}
 	else if (l.sched && !P.indirect && l.counters)
 	{

@@ -339,6 +339,49 @@ def test_literal_frame_mode_tracks_the_oracle(eng):
         eng.set_render_mode(False)
 
 
+def test_literal_frame_batched_march_at_256(eng):
+    """The literal frame's two forms — ca_render_frame_packed (fragment_main statement by statement) and the batched march over the
+    bricked volume (render_frame.hip, the default) — produce the same frames bit for bit, each feeding on its own history, and at
+    256^3 / 640 x 360 they track the oracle's lock-step frames like the small case above."""
+    G, W, H = 256, 640, 360
+    cells = host.random_fill(host.words_per_buffer(G), seed=0xCA3D0001, and_rounds=4)
+    vm = host.orbit_camera()
+    eng.configure(G)
+    set_rules(eng, rules("default"))
+    eng.upload_state(cells)
+    eng.set_render_mode(True)
+    try:
+        frames = {}
+        for bricks in (0, 1):
+            eng.set_option("render_frame_bricks", bricks)
+            eng.render(host.uniform_block(W, H, vm), W, H, 1)
+            eng.reset_render_history()
+            seq = []
+            for f in range(5):
+                u = host.uniform_block(W, H, vm, elapsed_time=0.2 + 0.093 * f, prev_view_mat=vm if f else None)
+                out = eng.render(u, W, H, 1)
+                st = eng.render_stats()
+                seq.append((out, (st.shadow_rays, st.primary_cell_visits, st.shadow_cell_visits)))
+            frames[bricks] = seq
+        for (a, sa), (b, sb) in zip(frames[0], frames[1]):
+            for x, y in zip(a, b):
+                np.testing.assert_array_equal(x.view(np.uint8), y.view(np.uint8))
+            assert sa == sb
+        pl = pd = None
+        for f in range(5):
+            u = host.uniform_block(W, H, vm, elapsed_time=0.2 + 0.093 * f, prev_view_mat=vm if f else None)
+            ol_light, ol_depth, ol_pres = ol.render_frame(cells, G, u, W, H, pl, pd)
+            pl, pd = ol_light.astype(np.float16).astype(np.float32), ol_depth.astype(np.float16).astype(np.float32)
+            (pres, light, depth), _ = frames[1][f]
+            ok = (np.abs(light.astype(np.float32)[..., :3] - pl[..., :3]).max(-1) <= 4e-3) & \
+                 (np.abs(depth.astype(np.float32)[..., 0] - pd[..., 0]) <= 2e-3)
+            assert ok.mean() >= 0.99, (f, ok.mean())
+        assert pl[..., :3].max() > 0.05
+    finally:
+        eng.set_option("render_frame_bricks", 1)
+        eng.set_render_mode(False)
+
+
 def test_legacy_renderer_over_the_unpacked_volume(eng):
     """R-legacy: shaders/pathtraced_fragment.wgsl — one u32 per cell, reflect-based shading with 1/d^2 attenuation,
     OCCLUSION_FACTOR 0.095, gamma 2.2 — same converged-frame definition and tolerance."""

@@ -74,6 +74,7 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-render", action="store_true", help="skip the renderer legs (N=1)")
+    ap.add_argument("--no-interactive", action="store_true", help="N=1, config 3: skip the step(1) + literal-frame-per-submission leg")
     ap.add_argument("--no-scaling-base", action="store_true", help="N=1, config 3: skip the 1024^3 single-GPU leg")
     ap.add_argument("--no-per-step-leg", action="store_true", help="N=1: skip the per-step-kernel leg printed beside a resident-kernel headline")
     ap.add_argument("--no-per-call-leg", action="store_true", help="N=1: skip the per-call-submission leg printed beside a queued-submission headline")
@@ -103,8 +104,9 @@ def parse(argv=None):
     ap.add_argument("--queue", type=int, default=2048, help="steps per submission with --submit queued")
     ap.add_argument("--check", action="store_true", help="verify the final state against the oracle (small grids)")
     ap.add_argument("--verify-steps", type=int, default=-1,
-                    help="N>1: before the timed region run this many steps from the bench state and compare every rank's slab with the CPU oracle "
-                         "(default: ghost + 8 steps — past one halo exchange — on grids up to 1024^3, 0 = off beyond); the state is uploaded again afterwards")
+                    help="before the timed region run this many steps from the bench state through the headline path and compare the state (N>1: every "
+                         "rank's slab) with the CPU oracle; a mismatch fails the run. Default: N=1 warm-up + 40 steps on grids up to 512^3; N>1 ghost + 8 steps — "
+                         "past one halo exchange — on grids up to 1024^3; 0 = off. The state is uploaded again afterwards")
     a = ap.parse_args(argv)
     a.config = a.config or (3 if a.gpus == 1 else 4)
     cfg = CONFIGS[a.config]
@@ -115,7 +117,9 @@ def parse(argv=None):
     if a.config == 5 and a.gpus > 1:
         a.multi_render = True
     if a.verify_steps < 0:
-        a.verify_steps = a.ghost + 8 if (a.gpus > 1 and a.grid <= 1024) else 0
+        # N = 1: warm-up + 40 steps through the headline path (one queued submission: the resident kernel where there is one) on grids
+        # the oracle steps in about a second; N > 1: past one halo exchange
+        a.verify_steps = (a.ghost + 8 if a.grid <= 1024 else 0) if a.gpus > 1 else (a.warmup + 40 if a.grid <= 512 else 0)
     return a
 
 
@@ -189,33 +193,63 @@ def time_frames(eng, u, W, H, spp, frames):
 
 
 def render_pmc_record(kernel_ms):
-    """What bounds the dense frame's kernel, from the committed PMC passes over the same scene (tools/pmc_render.sh ->
-    profiles/r*_pmc_render.json, newest): vector-issue fraction, live lanes, L2 hit rate, bytes served by the L2 per second.
-    SURVEY 8(d): "report Mray/s and achieved GB/s from rocprof, no roofline claim beyond that"."""
+    """What bounds the dense frame's kernels, from the committed PMC passes over the same scene (tools/pmc_render.sh ->
+    profiles/r*_pmc_render.json, newest): vector-issue fraction, live lanes, L2 hit rate, bytes served by the L2 per second — for the
+    passes of the ray-stream pipeline together (counters summed over ca_stream_walk<primary>, ca_stream_shadow_rays, ca_stream_walk<shadow>,
+    ca_stream_resolve) and per pass. SURVEY 8(d): "report Mray/s and achieved GB/s from rocprof, no roofline claim beyond that"."""
     import glob
+
+    def rates(v, cycles):
+        return {"valu_issue_frac": round(v["SQ_INSTS_VALU"] * 2.0 / (1024.0 * cycles), 4),  # wave-instructions x 2 cycles / (SIMDs x kernel cycles)
+                "lanes_active_frac": round(v["SQ_THREAD_CYCLES_VALU"] / (v["SQ_ACTIVE_INST_VALU"] * 64.0), 4) if v.get("SQ_ACTIVE_INST_VALU") else None,
+                "wave_cycles_issuing_valu_frac": round(v["SQ_ACTIVE_INST_VALU"] / v["SQ_WAVE_CYCLES"], 4),
+                "wave_cycles_waiting_frac": round(v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"], 4) if v.get("SQ_WAIT_ANY") else None,
+                "l2_hit_rate": round(v["TCC_HIT_sum"] / (v["TCC_HIT_sum"] + v["TCC_MISS_sum"]), 4) if v.get("TCC_HIT_sum") else None}
 
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_render.json")), reverse=True):
         try:
             d = json.load(open(f))
         except Exception:
             continue
-        ks = [k for k, v in d.items() if "sched<false" in k and v.get("SQ_INSTS_VALU")]
+        ks = [k for k, v in d.items() if "ca_stream_" in k and v.get("SQ_INSTS_VALU")] or [k for k, v in d.items() if "sched<false" in k and v.get("SQ_INSTS_VALU")]
+        if not ks:
+            continue
+        tot = {}
+        for k in ks:
+            for c, x in d[k].items():
+                tot[c] = tot.get(c, 0.0) + x
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs: cycles of a kernel = / 8 (MI355X_MICROARCH.md, DVFS give-back); the passes run one after the other
+        cycles = tot["GRBM_GUI_ACTIVE"] / 8.0
+        rec = {"bound": "valu_issue at partial lane occupancy (divergent walks)", "kernels": ks, "counter_source": os.path.relpath(f, ROOT)}
+        rec.update(rates(tot, cycles))
+        if len(ks) > 1:
+            rec["per_kernel"] = {k: dict(rates(d[k], d[k]["GRBM_GUI_ACTIVE"] / 8.0), us_at_2400MHz=round(d[k]["GRBM_GUI_ACTIVE"] / 8.0 / 2400.0, 1)) for k in ks}
+        if tot.get("TCC_REQ_sum") and kernel_ms:
+            rec["l2_request_gbs"] = round(tot["TCC_REQ_sum"] * 128.0 / (kernel_ms * 1e-3) / 1e9, 1)   # 128-B lines requested of the L2 per second (this run's kernel time)
+        if tot.get("TCC_EA0_RDREQ_sum") and kernel_ms:
+            rec["fabric_read_gbs"] = round(tot["TCC_EA0_RDREQ_sum"] * 64.0 * 2.0 / (kernel_ms * 1e-3) / 1e9, 1)  # = FETCH_SIZE, doubled as the guide prescribes
+        return rec
+    return None
+
+
+def literal_pmc_record():
+    """The same for the literal frame's kernel (tools/pmc_render.sh <tag> --literal 1 -> profiles/r*_pmc_render_literal.json)."""
+    import glob
+
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_render_literal.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        ks = [k for k, v in d.items() if "ca_render_frame" in k and v.get("SQ_INSTS_VALU")]
         if not ks:
             continue
         v = d[ks[0]]
-        # GRBM_GUI_ACTIVE is summed over the 8 XCDs: cycles of the kernel = / 8 (MI355X_MICROARCH.md, DVFS give-back)
         cycles = v["GRBM_GUI_ACTIVE"] / 8.0
-        rec = {"bound": "valu_issue at partial lane occupancy (divergent walks)", "kernel": ks[0], "counter_source": os.path.relpath(f, ROOT),
-               "valu_issue_frac": round(v["SQ_INSTS_VALU"] * 2.0 / (1024.0 * cycles), 4),  # wave-instructions x 2 cycles / (SIMDs x kernel cycles)
-               "lanes_active_frac": round(v["SQ_THREAD_CYCLES_VALU"] / (v["SQ_ACTIVE_INST_VALU"] * 64.0), 4) if v.get("SQ_ACTIVE_INST_VALU") else None,
-               "wave_cycles_issuing_valu_frac": round(v["SQ_ACTIVE_INST_VALU"] / v["SQ_WAVE_CYCLES"], 4),
-               "wave_cycles_waiting_frac": round(v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"], 4) if v.get("SQ_WAIT_ANY") else None,
-               "l2_hit_rate": round(v["TCC_HIT_sum"] / (v["TCC_HIT_sum"] + v["TCC_MISS_sum"]), 4) if v.get("TCC_HIT_sum") else None}
-        if v.get("TCC_REQ_sum") and kernel_ms:
-            rec["l2_request_gbs"] = round(v["TCC_REQ_sum"] * 128.0 / (kernel_ms * 1e-3) / 1e9, 1)   # 128-B lines requested of the L2 per second (this run's kernel time)
-        if v.get("TCC_EA0_RDREQ_sum") and kernel_ms:
-            rec["fabric_read_gbs"] = round(v["TCC_EA0_RDREQ_sum"] * 64.0 * 2.0 / (kernel_ms * 1e-3) / 1e9, 1)  # = FETCH_SIZE, doubled as the guide prescribes
-        return rec
+        return {"kernel": ks[0], "counter_source": os.path.relpath(f, ROOT), "valu_issue_frac": round(v["SQ_INSTS_VALU"] * 2.0 / (1024.0 * cycles), 4),
+                "lanes_active_frac": round(v["SQ_THREAD_CYCLES_VALU"] / (v["SQ_ACTIVE_INST_VALU"] * 64.0), 4),
+                "wave_cycles_waiting_frac": round(v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"], 4),
+                "l2_hit_rate": round(v["TCC_HIT_sum"] / (v["TCC_HIT_sum"] + v["TCC_MISS_sum"]), 4) if v.get("TCC_HIT_sum") else None}
     return None
 
 
@@ -238,7 +272,7 @@ def render_leg(eng, G, a, size=None, sparse=True, literal=True):
              "cell_visits_per_primary_ray": round(st.primary_cell_visits / max(1, st.primary_rays), 2),
              "cell_visits_per_shadow_ray": round(st.shadow_cell_visits / max(1, st.shadow_rays), 2),
              "config": {"workload": f"{G}^3 packed volume, hashed fill density 2^-5, {W}x{H} @ {a.render_spp} spp, oblique pose "
-                                    "(0.6 rad about (1,1,0), distance 1.4), exact DDA walk + shadow ray + Cook-Torrance"}}
+                                    "(0.6 rad about (1,1,0), distance 1.4), exact DDA walk + shadow ray + Cook-Torrance; ray-stream passes (render_stream.hip)"}}
     if H == 1080 and a.render_spp == 4:
         pmc = render_pmc_record(st.gpu_ms)
         if pmc:
@@ -262,6 +296,9 @@ def render_leg(eng, G, a, size=None, sparse=True, literal=True):
                                       "value": round(W * H * a.render_frames / dtl / 1e6, 2), "unit": "Mpixel/s",
                                       "workload": f"the reference's own frame: one jittered fixed-step sample per pixel (<= 35 primary + <= 30 shadow march samples), history "
                                                   f"look-ups, depth repair, temporal blend; same scene and pose, {W}x{H}, static camera (prev matrices = current)"}
+            lp = literal_pmc_record()
+            if lp and H == 1080:
+                dense["literal_frame"]["pmc"] = lp
         finally:
             eng.set_render_mode(False)
     if sparse:
@@ -275,6 +312,52 @@ def render_leg(eng, G, a, size=None, sparse=True, literal=True):
                                  "workload": f"{G}^3, single seed after 30 default-rule steps, default pose, {W}x{H} @ {a.render_spp} spp, "
                                              "empty-space skipping over two levels of occupancy blocks"}
     return dense
+
+
+def interactive_leg(eng, G, a, frames=200):
+    """What a drop-in behind the reference's own loop gets (main_pathtraced.js:1821-1854): per animation frame ONE compute pass and ONE
+    render pass in one submission — here ca3d_step(1) (a per-step kernel: a one-step submission never reaches the resident kernel) and
+    ca3d_render in the literal frame mode (one jittered sample per pixel, history, EMA), 1920x1080, nothing read back, `frames` frames
+    back to back; two scenes: the UI's start-up seed (evolving from step 30) and the dense bench volume (evolving from the hashed fill)."""
+    import torch
+
+    from cellularautomatons3d_amd import host
+
+    W, H = 1920, 1080
+    vm = host.orbit_camera()
+    eng.set_option("queue", 0)
+    eng.set_render_mode(True)
+    out = {"frames": frames, "size": f"{W}x{H}", "per_frame": "ca3d_step(1) + ca3d_render(render_mode 1, 1 sample per pixel), one submission per frame, no read-back",
+           "reference_loop": "main_pathtraced.js:1821-1854 (_computePass + _renderPass per requestAnimationFrame)"}
+    try:
+        for name, start in (("startup_scene", None), ("dense_scene", host.random_fill(host.words_per_buffer(G), seed=0xCA3D0001, and_rounds=4))):
+            if start is None:
+                eng.upload_state(host.initial_state(G))
+                eng.step(30)
+            else:
+                eng.upload_state(start)
+            eng.reset_render_history()
+            for i in range(5):
+                eng.step(1)
+                eng.render(host.uniform_block(W, H, vm, elapsed_time=0.3 + 0.016 * i, prev_view_mat=vm), W, H, 1, readback=False)
+            torch.cuda.synchronize()
+            us = [host.uniform_block(W, H, vm, elapsed_time=0.5 + 0.016 * i, prev_view_mat=vm) for i in range(frames)]  # the host's uniform upload, prepared
+            t0 = time.perf_counter()
+            for i in range(frames):
+                eng.step(1)
+                eng.render(us[i], W, H, 1, readback=False)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            gpu_ms = eng.render_stats().gpu_ms
+            eng.set_option("resident", 0)  # (ca3d_get_info names the kernel the rules select for LONG batches; a one-step submission is below
+            step_kernel = eng.info().kernel_name.decode()  # resident_min = 8 and takes the per-step kernel: the name with the resident form off)
+            eng.set_option("resident", a.resident)
+            out[name] = {"ms_per_frame": round(dt * 1e3 / frames, 4), "frames_per_second": round(frames / dt, 1), "last_render_kernel_ms": round(gpu_ms, 4),
+                         "step_kernel": step_kernel,
+                         "render_kernels": "ca_brick_volume + ca_render_frame_bricks (render_frame.hip)"}
+    finally:
+        eng.set_render_mode(False)
+    return out
 
 
 def render_leg_multi(se, G, a, world, rank, barrier):
@@ -332,9 +415,11 @@ def copy_ceiling_gbs(eng):
     return eng.measure_copy(1 << 30, 8)
 
 
-def sq_profile(kernel, G):
-    """The committed rocprofv3 SQ pass of this command for a resident kernel (tools/profile_round3.sh -> tools/pmc_sq_reduce.py):
-    newest profiles/r*_pmc_sq_<key>.json that says how many steps its launches held. None when there is none."""
+def sq_profile(kernel, G, variant=None):
+    """The committed rocprofv3 SQ pass of this command for a resident kernel (tools/profile_round4.sh -> tools/pmc_sq_reduce.py):
+    newest profiles/r*_pmc_sq_<key>.json that says how many steps its launches held AND was taken on the same instruction stream —
+    its `variant` (ca3d_get_kernel_variant at profile time: kernel, grid, rule hash, form options, device-source hash) must equal
+    the running engine's. None when there is none: the count of another rule, form or source revision prices nothing."""
     import glob
 
     base = kernel.split("(")[0]
@@ -346,7 +431,7 @@ def sq_profile(kernel, G):
             d = json.load(open(f))
         except Exception:
             continue
-        if d.get("steps_per_launch") and d.get("SQ_INSTS_VALU") and d.get("SQ_WAVES"):
+        if d.get("steps_per_launch") and d.get("SQ_INSTS_VALU") and d.get("SQ_WAVES") and variant and d.get("variant") == variant:
             return d, os.path.relpath(f, ROOT)
     return None, None
 
@@ -424,9 +509,31 @@ def timed_region(run, stream, steps, warmup, min_seconds, barrier, world, backen
     return dt, reps, e0.elapsed_time(e1), group, (launch_count() - n0 if launch_count else None)
 
 
-def single_gpu_leg(device, G, rule, steps, warmup, min_seconds, density_rounds=0, resident=1, queue=0):
+def oracle_verify(eng, G, full, rule, nsteps, queued):
+    """`nsteps` from the bench state through the engine exactly as the timed region drives it (queued: one submission — the resident
+    kernel where one exists), compared bit for bit with the CPU oracle; the bench state is uploaded again afterwards."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_lib as ol
+
+    if queued:
+        eng.set_option("queue", max(nsteps, 8))
+    eng.step(nsteps)
+    eng.flush()
+    got = eng.read_state()
+    kernel = eng.info().kernel_name.decode()
+    t0 = time.perf_counter()
+    want = ol.packed_run(G, full, ol.Rules.from_strings(**RULES[rule]), nsteps, min(os.cpu_count() or 1, 64))
+    rec = {"oracle_match": bool(np.array_equal(got, want)), "steps": nsteps, "kernel": kernel, "oracle_seconds": round(time.perf_counter() - t0, 2),
+           "how": "the bench state stepped through the headline path (same engine, same submission mode) and read back, against the CPU oracle, before the timed region"}
+    eng.upload_state(full)
+    return rec
+
+
+def single_gpu_leg(device, G, rule, steps, warmup, min_seconds, density_rounds=0, resident=1, queue=0, verify_steps=0):
     """One GPU, whole grid: returns the numbers of the timed region plus the engine (state = the bench state advanced).
-    queue > 0: the K-step calls are encoded and submitted `queue` steps at a time."""
+    queue > 0: the K-step calls are encoded and submitted `queue` steps at a time. verify_steps > 0: the path is checked against
+    the oracle first (eng.verified)."""
     import torch
 
     from cellularautomatons3d_amd import Engine, host
@@ -449,6 +556,7 @@ def single_gpu_leg(device, G, rule, steps, warmup, min_seconds, density_rounds=0
     def barrier():
         torch.cuda.synchronize()
 
+    eng.verified = oracle_verify(eng, G, full, rule, verify_steps, queue > 0) if verify_steps > 0 else None
     group = 1
     if queue > 0:
         group = max(1, -(-queue // steps))
@@ -458,7 +566,7 @@ def single_gpu_leg(device, G, rule, steps, warmup, min_seconds, density_rounds=0
     return eng, full, dt, reps, ev_ms, cal, launches
 
 
-def roofline_block(kernel, G, bytes_per_step, total_steps, ev_ms, state_bytes, launches=None):
+def roofline_block(kernel, G, bytes_per_step, total_steps, ev_ms, state_bytes, launches=None, variant=None):
     """`launches`: kernel launches in the timed region (the engine's counter); None = one per step. The resident kernel runs a
     whole submission in ONE launch: per launch = per submission (rocprof's kernel duration is a submission)."""
     launches = launches or total_steps
@@ -479,9 +587,9 @@ def roofline_block(kernel, G, bytes_per_step, total_steps, ev_ms, state_bytes, l
         # State in registers + LDS for the whole launch; per step only the tile faces cross the fabric (2 MiB of payload at
         # 512^3). The HBM model does not describe this kernel (its algorithmic-byte rate exceeds the HBM peak): what bounds it is
         # vector-instruction issue. Instructions per launch come from the SQ pass of this command, the time from this run.
-        prof, src = sq_profile(kernel, G)
+        prof, src = sq_profile(kernel, G, variant)
         out = {"bound": "valu_issue", "achieved": None, "peak": VALU_PEAK_GWIPS, "unit": "Gwaveinst/s", "frac": None,
-               "traffic": traffic, "traffic_source": traffic_source}
+               "traffic": traffic, "traffic_source": traffic_source, "variant": variant}
         if prof:
             valu_per_step = prof["SQ_INSTS_VALU"] / prof["steps_per_launch"]
             achieved = valu_per_step * steps_per_launch / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
@@ -491,7 +599,7 @@ def roofline_block(kernel, G, bytes_per_step, total_steps, ev_ms, state_bytes, l
                         "peak_definition": "1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (SIMD-32; needs >= 2 waves per SIMD); "
                                            "half-rate instructions (v_alignbit, DPP moves) count once, so full issue sits below frac 1"})
         else:
-            out["note"] = "no profiles/r*_pmc_sq_* pass with steps_per_launch for this kernel: instruction count unknown"
+            out["note"] = "no committed profiles/r*_pmc_sq_* pass of this kernel VARIANT (same rule, form options and device sources): instruction count unknown, no fraction"
         out.update(common)
         out["hbm_equivalent"] = {"achieved": round(hbm_rate, 2), "unit": "GB/s", "hbm_peak": HBM_PEAK_GBS,
                                  "note": "algorithmic bytes (0.25 B per cell-step) per second — a rate, not a fraction of anything: the state does not move; "
@@ -549,10 +657,12 @@ def main():
 
     se = None
     verified = None
+    single_verified = None
     if world == 1:
         queue = a.queue if a.submit == "queued" else 0
-        eng, full, dt, reps, ev_ms, cal, launches = single_gpu_leg(local_rank, G, a.rule, a.steps, a.warmup, a.min_seconds, a.density_rounds, a.resident, queue)
+        eng, full, dt, reps, ev_ms, cal, launches = single_gpu_leg(local_rank, G, a.rule, a.steps, a.warmup, a.min_seconds, a.density_rounds, a.resident, queue, a.verify_steps)
         core = eng
+        single_verified = eng.verified
     else:
         offs, s, b = rule_payload(rule_kw)
         full = host.random_fill(host.words_per_buffer(G), seed=0xCA3D0001, and_rounds=a.density_rounds)
@@ -629,7 +739,7 @@ def main():
                        "parallelism": "1 GPU" if world == 1 else f"z-slab x{world}, ghost {a.ghost} planes, RCCL send/recv every {a.ghost} steps"
                                       + (" overlapped with the interior phase" if se.overlap else "")
                                       + (", exchange issued by the engine (ca3d_slab_run)" if getattr(se, "native", False) else ", exchange through torch.distributed")},
-            "roofline": roofline_block(kernel, G, 0.25 * own_cells, total_steps, ev_ms, state_bytes, launches),
+            "roofline": roofline_block(kernel, G, 0.25 * own_cells, total_steps, ev_ms, state_bytes, launches, core.kernel_variant()),
         }
         if world == 1:
             out["config"]["submission"] = (f"queued: ca3d_step({a.steps}) encodes, ca3d_flush submits every {cal * a.steps} steps (the reference's commandEncoder + "
@@ -640,6 +750,10 @@ def main():
                                    "how": "1 GiB float4-per-lane device-to-device copy, non-temporal stores (ca3d_measure_copy), bytes read + bytes written per second, measured in this run"}
         if ok is not None:
             out["oracle_match"] = ok
+        if world == 1 and single_verified is not None:
+            out["verified"] = single_verified
+            if not single_verified["oracle_match"]:
+                ok = False
         if verified is not None:
             out["verified"] = {"oracle_match": verified, "steps": a.verify_steps,
                                "how": "every rank's slab after this many steps (past one halo exchange) against the CPU oracle's full grid, before the timed region"}
@@ -655,7 +769,7 @@ def main():
             dt3, reps3, ev3, _, _ = timed_region(e.step, e.bench_stream, 256, 64, a.min_seconds, barrier, 1, "nccl")
             k3 = e.info().kernel_name.decode()
             leg = {"value": round(float(Gx) ** 3 * 256 * reps3 / dt3 / 1e9, 3), "unit": "Gcells/s", "ms_per_step": round(dt3 * 1e3 / (256 * reps3), 6),
-                   "steps": 256, "reps": reps3, "roofline": roofline_block(k3, Gx, 0.25 * float(Gx) ** 3, 256 * reps3, ev3, state_b)}
+                   "steps": 256, "reps": reps3, "roofline": roofline_block(k3, Gx, 0.25 * float(Gx) ** 3, 256 * reps3, ev3, state_b, None, e.kernel_variant())}
             leg["roofline"]["frac_of_copy_ceiling"] = round(leg["roofline"]["achieved"] / ceiling, 4)
             e.set_option("resident", a.resident)
             return leg
@@ -667,7 +781,7 @@ def main():
                                                   lambda: e.info().launches_total)
             return {"submission": f"per call: every ca3d_step({K}) is its own submission", "value": round(float(Gx) ** 3 * K * reps2 / dt2 / 1e9, 3), "unit": "Gcells/s",
                     "ms_per_step": round(dt2 * 1e3 / (K * reps2), 6), "steps": K, "reps": reps2,
-                    "roofline": roofline_block(e.info().kernel_name.decode(), Gx, 0.25 * float(Gx) ** 3, K * reps2, ev2, state_b, l2)}
+                    "roofline": roofline_block(e.info().kernel_name.decode(), Gx, 0.25 * float(Gx) ** 3, K * reps2, ev2, state_b, l2, e.kernel_variant())}
 
         resident_headline = world == 1 and kernel.startswith("ca_resident")
         if world == 1 and resident_headline and (a.compare_submission or (queue and not a.no_per_call_leg)):
@@ -682,7 +796,7 @@ def main():
                                                       lambda: eng.info().launches_total)
                 out["other_submission"] = {"submission": "queued" if q2 else "per call", "value": round(cells * a.steps * reps2 / dt2 / 1e9, 3), "unit": "Gcells/s",
                                            "ms_per_step": round(dt2 * 1e3 / (a.steps * reps2), 6), "reps": reps2,
-                                           "roofline": roofline_block(kernel, G, 0.25 * cells, a.steps * reps2, ev2, state_bytes, l2)}
+                                           "roofline": roofline_block(kernel, G, 0.25 * cells, a.steps * reps2, ev2, state_bytes, l2, eng.kernel_variant())}
         if world == 1 and resident_headline and not a.no_per_step_leg:
             out["per_step_kernels"] = per_step_leg(eng, G, state_bytes)
         if world == 1 and not resident_headline:
@@ -691,14 +805,21 @@ def main():
             out["render"] = render_leg(eng, G, a)
             if a.config == 3 and a.render_size == "1920x1080":
                 out["render_4k"] = render_leg(eng, G, a, size="3840x2160", sparse=False, literal=False)  # BASELINE configs[4]'s frame size
+            if a.config == 3 and not a.no_interactive:
+                out["interactive_frame"] = interactive_leg(eng, G, a)
         if world == 1 and a.config == 3 and G == 512 and not a.no_grid_256:
             # BASELINE configs[1]'s grid (256^3): the resident kernel's 256^3 form under queued submission, and the per-step kernels
             eng.close()
-            e1, _, dt1, reps1, ev1, cal1, l1 = single_gpu_leg(local_rank, 256, "default", a.steps, a.warmup, a.min_seconds, 0, a.resident, a.queue if a.submit == "queued" else 0)
+            e1, _, dt1, reps1, ev1, cal1, l1 = single_gpu_leg(local_rank, 256, "default", a.steps, a.warmup, a.min_seconds, 0, a.resident, a.queue if a.submit == "queued" else 0,
+                                                              a.verify_steps)
             k1 = e1.info().kernel_name.decode()
             out["grid_256"] = {"grid": 256, "rule": "default", "value": round(256.0 ** 3 * a.steps * reps1 / dt1 / 1e9, 3), "unit": "Gcells/s",
                                "ms_per_step": round(dt1 * 1e3 / (a.steps * reps1), 6), "steps": a.steps, "reps": reps1,
-                               "roofline": roofline_block(k1, 256, 0.25 * 256.0 ** 3, a.steps * reps1, ev1, 2 << 20, l1)}
+                               "roofline": roofline_block(k1, 256, 0.25 * 256.0 ** 3, a.steps * reps1, ev1, 2 << 20, l1, e1.kernel_variant())}
+            if e1.verified is not None:
+                out["grid_256"]["verified"] = e1.verified
+                if not e1.verified["oracle_match"]:
+                    ok = False
             if k1.startswith("ca_resident") and not a.no_per_step_leg:
                 out["grid_256"]["per_step_kernels"] = per_step_leg(e1, 256, 2 << 20)
             eng = e1
@@ -709,7 +830,7 @@ def main():
             k2 = e2.info().kernel_name.decode()
             out["scaling_base"] = {"grid": 1024, "rule": "default", "n_gpus": 1, "value": round(1024.0 ** 3 * 256 * reps2 / dt2 / 1e9, 3), "unit": "Gcells/s",
                                    "ms_per_step": round(dt2 * 1e3 / (256 * reps2), 6), "steps": 256, "reps": reps2,
-                                   "roofline": roofline_block(k2, 1024, 0.25 * 1024.0 ** 3, 256 * reps2, ev2, 128 << 20),
+                                   "roofline": roofline_block(k2, 1024, 0.25 * 1024.0 ** 3, 256 * reps2, ev2, 128 << 20, None, e2.kernel_variant()),
                                    "note": "divide the N > 1 values (config 4: 1024^3) by this, not by the 512^3 headline; "
                                            "`python bench.py --gpus 1 --config 5` gives the base of the 2048^3 clustered curve"}
             out["scaling_base"]["roofline"]["frac_of_copy_ceiling"] = round(out["scaling_base"]["roofline"]["achieved"] / ceiling, 4)

@@ -93,6 +93,7 @@ SYMBOLS = [
     ("ca3d_device_buffer", C.c_int, [_H, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     ("ca3d_get_info", C.c_int, [_H, C.POINTER(Info)]),
     ("ca3d_get_jit_log", C.c_int, [_H, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    ("ca3d_get_kernel_variant", C.c_int, [_H, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("ca3d_get_stats", C.c_int, [_H, C.POINTER(Stats)]),
     ("ca3d_set_option", C.c_int, [_H, C.c_char_p, C.c_int64]),
     ("ca3d_render", C.c_int, [_H, C.POINTER(C.c_float), C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),

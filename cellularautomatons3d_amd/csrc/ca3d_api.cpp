@@ -1518,6 +1518,40 @@ int ca3d_get_jit_log(ca3d_t *h, char *buf, size_t n_bytes, size_t *needed)
 	return CA3D_OK;
 }
 
+int ca3d_get_kernel_variant(ca3d_t *h, char *buf, size_t n_bytes, size_t *needed)
+{
+	if (!h) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL engine handle");
+	ca3d_info info;
+	int rc = ca3d_get_info(h, &info);
+	if (rc) return rc;
+	uint64_t rh = 1469598103934665603ull;
+	auto mix = [&](const void *p, size_t n) { for (size_t i = 0; i < n; i++) { rh ^= static_cast<const unsigned char *>(p)[i]; rh *= 1099511628211ull; } };
+	if (h->rules.valid)
+	{
+		mix(&h->rules.lists, sizeof h->rules.lists);
+		mix(h->rules.survive_raw, sizeof h->rules.survive_raw);
+		mix(h->rules.born_raw, sizeof h->rules.born_raw);
+	}
+	const char *zs = getenv("CA3D_RC256_ZS");
+	char text[320];
+	const bool res = !strncmp(info.kernel_name, "ca_resident", 11);
+	if (res)
+		snprintf(text, sizeof text, "%s;G=%u;rule=%016llx;rows=%u;zsplit=%u;pair=%d;deep=%d;rc256zs=%s;src=%016llx", info.kernel_name, h->G, (unsigned long long)rh,
+		         (h->res_class || vn_pair(h)) ? 32u : h->res_rows, h->res_class ? resident_class_zsplit(h->G) : h->res_zsplit, !h->res_class && vn_pair(h) ? 1 : 0,
+		         !h->res_class && vn_deep(h) ? 1 : 0, zs ? zs : "-", (unsigned long long)jit_sources_hash());
+	else
+		snprintf(text, sizeof text, "%s;G=%u;rule=%016llx;variant=%d;src=%016llx", info.kernel_name, h->G, (unsigned long long)rh, h->variant, (unsigned long long)jit_sources_hash());
+	const size_t len = strlen(text);
+	if (needed) *needed = len + 1;
+	if (buf && n_bytes)
+	{
+		const size_t n = len < n_bytes - 1 ? len : n_bytes - 1;
+		memcpy(buf, text, n);
+		buf[n] = '\0';
+	}
+	return CA3D_OK;
+}
+
 int ca3d_get_stats(ca3d_t *h, ca3d_stats *out)
 {
 	if (!h || !out) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL argument");

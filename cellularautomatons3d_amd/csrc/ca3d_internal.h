@@ -179,6 +179,7 @@ void vn_tables(const CanonRules &r, uint32_t *lut_s, uint32_t *lut_b);
 bool vn_tables_prebuilt(uint32_t lut_s, uint32_t lut_b);
 int vn_grid_log2(uint32_t G); // log2(G / 128)
 // ca_jit.cpp: compile (or fetch from the cache) the kernels specialised for (grid 128 << cvl, tables)
+uint64_t jit_sources_hash(); // of every device source the run-time compiler is given
 int jit_vn_kernels(int device, int cvl, uint32_t lut_s, uint32_t lut_b, VnJit *out, std::string *log);
 // Truth tables of the three rule-sets over their count planes, unreachable counts filled (class kernels, JIT)
 void class_tables(const CanonRules &r, uint32_t tables[6]);

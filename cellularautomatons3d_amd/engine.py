@@ -243,6 +243,15 @@ class Engine:
         _capi.check(self._lib.ca3d_get_jit_log(self._h, buf, len(buf), None))
         return buf.value.decode("utf-8", "replace")
 
+    def kernel_variant(self) -> str:
+        """Everything that decides which instruction stream the next step batch runs (kernel, grid, rule hash, resident-kernel form
+        options, device-source hash): a committed profile is comparable with this run only if its string is the same."""
+        need = C.c_size_t()
+        _capi.check(self._lib.ca3d_get_kernel_variant(self._h, None, 0, C.byref(need)))
+        buf = C.create_string_buffer(max(1, need.value))
+        _capi.check(self._lib.ca3d_get_kernel_variant(self._h, buf, len(buf), None))
+        return buf.value.decode("utf-8", "replace")
+
     def stats(self) -> Stats:
         s = Stats()
         _capi.check(self._lib.ca3d_get_stats(self._h, C.byref(s)))

@@ -310,6 +310,12 @@ static napi_value js_info(napi_env env, napi_callback_info info)
 	set_num(env, o, "launchesTotal", (double)i.launches_total);
 	napi_create_string_utf8(env, i.kernel_name, NAPI_AUTO_LENGTH, &s);
 	napi_set_named_property(env, o, "kernelName", s);
+	char variant[384];
+	if (ca3d_get_kernel_variant(h, variant, sizeof variant, NULL) == CA3D_OK)
+	{
+		napi_create_string_utf8(env, variant, NAPI_AUTO_LENGTH, &s);
+		napi_set_named_property(env, o, "kernelVariant", s);
+	}
 	return o;
 }
 

@@ -106,12 +106,15 @@ if (/^ca_resident/.test(out.kernel))
 		for (const f of fs.readdirSync(dir).filter((n) => /^r.*_pmc_sq_/.test(n) && n.endsWith(`_${key}.json`)).sort().reverse())
 		{
 			const d = JSON.parse(fs.readFileSync(path.join(dir, f), "utf8"));
-			if (d.steps_per_launch && d.SQ_INSTS_VALU) { prof = d; src = `profiles/${f}`; break; }
+			// only a profile of THIS instruction stream counts: same kernel, grid, rule, form options and device sources
+			if (d.steps_per_launch && d.SQ_INSTS_VALU && d.variant && d.variant === eng.info().kernelVariant) { prof = d; src = `profiles/${f}`; break; }
 		}
 	}
 	catch (e) { /* no profiles directory: the instruction count stays unknown */ }
 	const peak = 1228.8; // Gwaveinst/s
-	out.roofline = { bound: "valu_issue", peak, unit: "Gwaveinst/s", achieved: null, frac: null, counter_source: src, hbm_equivalent_gbs: +hbmEquivalent.toFixed(1) };
+	out.roofline = { bound: "valu_issue", peak, unit: "Gwaveinst/s", achieved: null, frac: null, counter_source: src, hbm_equivalent_gbs: +hbmEquivalent.toFixed(1),
+		variant: eng.info().kernelVariant };
+	if (!prof) out.roofline.note = "no committed profiles/r*_pmc_sq_* pass of this kernel variant: instruction count unknown, no fraction";
 	if (prof)
 	{
 		const achieved = prof.SQ_INSTS_VALU / prof.steps_per_launch / (stepUs * 1e-6) / 1e9;

@@ -250,6 +250,15 @@ int ca3d_get_info(ca3d_t *h, ca3d_info *out);
  */
 int ca3d_get_jit_log(ca3d_t *h, char *buf, size_t n_bytes, size_t *needed);
 
+/*
+ * Diagnostics (no reference counterpart): everything that decides WHICH instruction stream the next step batch runs, as one
+ * string — kernel name, grid, a hash of the rule payload, the resident-kernel form options, a hash of the device sources the
+ * run-time compiler is given. A profile (instruction counts per step, tools/pmc_sq_reduce.py) is only comparable with a run
+ * whose string is the same: bench.py / js/bench.js price a resident kernel's time against a committed profile only then.
+ * `needed` (nullable) receives the size including the terminator; the text is truncated to n_bytes.
+ */
+int ca3d_get_kernel_variant(ca3d_t *h, char *buf, size_t n_bytes, size_t *needed);
+
 typedef struct ca3d_stats
 {
 	uint64_t steps;          /* steps in the last ca3d_step / ca3d_slab_step batch */

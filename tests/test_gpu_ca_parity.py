@@ -830,3 +830,34 @@ def test_bench_line_single_gpu_queued_and_per_call():
     ps = d["per_step_kernels"]["roofline"]
     assert ps["bound"] == "hbm" and ps["kernel"].startswith("ca_packed_vn") and 0 < ps["frac"] <= 1 and abs(ps["achieved"] / ps["peak"] - ps["frac"]) < 1e-3
     assert d["copy_ceiling"]["value"] > 1000
+    # the line verifies itself: warm-up + 40 steps through the headline path (one queued submission: the resident kernel) against the
+    # oracle before anything is timed
+    v = d["verified"]
+    assert v["oracle_match"] is True and v["steps"] == 45 and v["kernel"].startswith("ca_resident_vn")
+    # a resident kernel's fraction is only given against a profile of the SAME instruction stream (kernel, grid, rule, form options,
+    # device sources); the variant the run had is on the line either way
+    assert rf["variant"].startswith(rf["kernel"]) and ";rule=" in rf["variant"] and ";src=" in rf["variant"]
+    if rf["frac"] is not None:
+        assert json.load(open(os.path.join(root, rf["counter_source"])))["variant"] == rf["variant"]
+
+
+def test_bench_interactive_frame_leg():
+    """bench.py's `interactive_frame`: the reference's own loop — ca3d_step(1) + one literal frame per submission (main_pathtraced.js:1821-1854)
+    — at the driver's grid, with the kernels that ran; and the literal frame leg beside the converged one."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "20", "--warmup", "5", "--min-seconds", "0.0001", "--no-cpu-baseline", "--no-scaling-base",
+           "--no-per-step-leg", "--no-per-call-leg", "--no-grid-256", "--render-frames", "3"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
+    assert d["verified"]["oracle_match"] is True and d["verified"]["kernel"].startswith("ca_resident_vn")
+    it = d["interactive_frame"]
+    for scene in ("startup_scene", "dense_scene"):
+        assert 0 < it[scene]["ms_per_frame"] < 50 and it[scene]["step_kernel"].startswith("ca_packed_vn")
+    assert it["frames"] == 200
+    assert 0 < d["render"]["literal_frame"]["ms_per_frame"] < d["render"]["ms_per_frame"] * 2

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Per-kernel means of a `rocprofv3 --pmc SQ_...` pass: tools/pmc_sq_reduce.py DIR KERNEL_SUBSTR [STEPS_PER_LAUNCH]  -> JSON on stdout.
+"""Per-kernel means of a `rocprofv3 --pmc SQ_...` pass: tools/pmc_sq_reduce.py DIR KERNEL_SUBSTR [STEPS_PER_LAUNCH [BENCH_JSON]]  -> JSON on stdout.
+BENCH_JSON: the bench line the profiled command printed; its roofline.variant (ca3d_get_kernel_variant: kernel, grid, rule hash, form
+options, device-source hash) and the repo's HEAD are recorded, and bench.py uses the instruction count only for a run of the same variant.
 STEPS_PER_LAUNCH (resident multi-step kernels): how many CA steps each profiled launch held; only launches of the most
 common duration class are averaged when given (the run also holds a shorter warm-up launch).
 SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md); ratios between them are unit-free."""
@@ -18,6 +20,18 @@ for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=T
                     if k in row and row[k] not in ("", None):
                         acc["_" + k].append(float(row[k]))
 out = {"kernel": kernel, "dispatches": max((len(v) for v in acc.values()), default=0)}
+if len(sys.argv) > 4:
+    import subprocess
+    try:
+        line = [l for l in open(sys.argv[4]).read().splitlines() if l.startswith("{")][-1]
+        bench = json.loads(line)
+        out["variant"] = (bench.get("roofline") or {}).get("variant")
+    except Exception as e:  # no variant: bench.py will not use this profile
+        out["variant_error"] = str(e)
+    try:
+        out["git_head"] = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL, text=True).strip()
+    except Exception:
+        pass
 if steps_per_launch:
     out["steps_per_launch"] = steps_per_launch
     # keep the launches of full length: SQ_INSTS_VALU within 10 % of the largest value seen (warm-up / calibration launches are shorter)

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_abi_version():
-    assert _capi.load().ca3d_abi_version() == 4
+    assert _capi.load().ca3d_abi_version() == 5
 
 
 def test_no_cpu_fallback_when_no_gpu():

@@ -103,6 +103,8 @@ struct ca3d_engine
 	int use_jit = 1;      // specialise kernels for the rule at run time (hiprtc) where a specialisation exists
 	VnJit vn_jit;         // valid when vn_jit.cvl >= 0
 	ClassJit class_jit;   // valid when class_jit.main >= 0
+	RowsJit rows_jit;     // valid when rows_jit.main >= 0: the rows kernel for this grid and these rules
+	int use_rows = 1;     // option "rows"
 	RollJit roll_jit;     // valid when roll_jit.cvl >= 0
 	std::string jit_log;  // why the last specialisation attempt failed (empty: none failed)
 
@@ -285,7 +287,7 @@ int enqueue_step(ca3d_engine *h, int src, uint32_t lo, uint32_t hi, hipStream_t 
 	{
 		pr.lo2 = lo2;
 		pr.hi2 = hi2;
-		PackedLaunch l{h->buf[src], h->buf[src ^ 1], pr, &h->rules, h->variant, h->vn_jit.cvl >= 0 ? &h->vn_jit : nullptr, h->class_jit.main >= 0 ? &h->class_jit : nullptr, h->roll_jit.cvl >= 0 ? &h->roll_jit : nullptr, h->roll_z, h->roll_tile};
+		PackedLaunch l{h->buf[src], h->buf[src ^ 1], pr, &h->rules, h->variant, h->vn_jit.cvl >= 0 ? &h->vn_jit : nullptr, h->class_jit.main >= 0 ? &h->class_jit : nullptr, h->roll_jit.cvl >= 0 ? &h->roll_jit : nullptr, h->roll_z, h->roll_tile, h->rows_jit.main >= 0 ? &h->rows_jit : nullptr};
 		e = fused ? launch_packed_fused(l, s, &h->kernel_name) : launch_packed_step(l, s, &h->kernel_name);
 	}
 	else
@@ -315,6 +317,7 @@ void select_kernels(ca3d_engine *h)
 {
 	h->vn_jit = VnJit{};
 	h->class_jit = ClassJit{};
+	h->rows_jit = RowsJit{};
 	h->roll_jit = RollJit{};
 	h->res_ready = false;
 	h->res_class = false;
@@ -345,15 +348,24 @@ void select_kernels(ca3d_engine *h)
 		}
 	}
 	if (!h->use_jit) return;
+	if (h->use_rows && rows_kernel_applies(h->rules, h->G, h->variant))
+	{
+		// grids without a uint4 kernel that has the rule compiled in (not a power of two, or rows that are not whole uint4)
+		if (hipSetDevice(h->device) != hipSuccess) return;
+		RowsJit rj;
+		if (jit_rows_kernels(h->device, h->rules, h->G, &rj, &h->jit_log) == CA3D_OK) { h->rows_jit = rj; h->kernel_name = "ca_packed_rows(jit)"; }
+		return;
+	}
 	if (!vn_kernel_applies(h->rules, h->G, h->variant))
 	{
 		// class kernels on power-of-two grids: the rule's truth tables become compile-time constants
 		const uint32_t cv = h->G / 128u;
-		if (!use_class_kernel(h->rules, h->G, h->variant) || h->G % 128u || (cv & (cv - 1u)) || cv > 64u) return;
+		if (!use_class_kernel(h->rules, h->G, h->variant) || h->G % 128u || cv > 64u) return;
 		if (hipSetDevice(h->device) != hipSuccess) return;
 		ClassJit cj;
 		if (jit_class_kernels(h->device, h->rules, &cj, &h->jit_log) == CA3D_OK) h->class_jit = cj;
 		else return;
+		if (cv & (cv - 1u)) return; // not a power of two: the class kernel's np2 entry points, nothing else
 		if (h->use_roll && roll_kernel_applies(h->rules, h->G, h->variant))
 		{
 			RollJit rj;
@@ -1494,6 +1506,7 @@ int ca3d_get_info(ca3d_t *h, ca3d_info *out)
 		else if (h->res_ready && h->use_resident && !h->res_failed && h->res_class) name = "ca_resident_class(jit)";
 		else if (h->res_ready && h->use_resident && !h->res_failed) name = h->res_jit_fn ? "ca_resident_vn(jit)" : "ca_resident_vn";
 		else if (h->slab && h->res_slab_fn && h->use_resident && !h->res_failed) name = "ca_resident_slab_vn(jit)";
+		else if (h->rows_jit.main >= 0) name = "ca_packed_rows(jit)";
 		else name = h->vn_jit.cvl >= 0 ? "ca_packed_vn(jit)" : packed_kernel_name(h->rules, h->G, h->variant);
 	}
 	const bool class_jit = h->configured && h->rules.valid && h->layout == CA3D_LAYOUT_PACKED32 && h->class_jit.main >= 0 && strncmp(name, "ca_resident", 11) != 0 &&
@@ -1807,6 +1820,13 @@ int ca3d_set_option(ca3d_t *h, const char *name, int64_t value)
 	if (!strcmp(name, "render_indirect")) { h->render_indirect = value ? 1 : 0; return CA3D_OK; }
 	if (!strcmp(name, "render_sched")) { h->render_sched = value ? 1 : 0; return CA3D_OK; }
 	if (!strcmp(name, "render_skip")) { h->render_skip = value ? 1 : 0; return CA3D_OK; }
+	if (!strcmp(name, "rows"))
+	{
+		h->use_rows = value ? 1 : 0;
+		refresh_kernels(h);
+		note_jit_failure(h);
+		return CA3D_OK;
+	}
 	if (!strcmp(name, "render_frame_bricks")) { h->render_frame_bricks = value ? 1 : 0; return CA3D_OK; }
 	if (!strcmp(name, "render_stream")) { h->render_stream = value ? 1 : 0; return CA3D_OK; }
 	if (!strcmp(name, "render_stream_check")) { h->render_stream_check = value ? 1 : 0; return CA3D_OK; }

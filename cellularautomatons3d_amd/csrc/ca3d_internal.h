@@ -55,11 +55,22 @@ struct VnJit
 	uint32_t lut_s = 0, lut_b = 0;
 };
 
+// Run-time compiled rows kernel (ca_packed_rows_kernel.inc) for one (grid, main table, live rule-sets, rule): any multiple of 32
+struct RowsJit
+{
+	void *deep = nullptr, *flat = nullptr; // zrun planes per thread / 1 plane per thread
+	uint32_t G = 0;
+	int zrun = 0, main = -1;
+	bool e = false, c = false;
+	uint32_t tables[6]{};
+};
+
 // Run-time compiled class kernels (rule as compile-time truth tables) for one (main table, live rule-sets, rule)
 struct ClassJit
 {
 	void *deep = nullptr, *deep_za = nullptr, *flat = nullptr; // hipFunction_t: ZRUN planes per thread (general /
 	                                                           // z-aligned ranges) / 1 plane per thread
+	void *deep_np2 = nullptr, *flat_np2 = nullptr;             // the same for rows of whole uint4 that are not a power of two of them
 	int main = -1;
 	bool e = false, c = false;
 	uint32_t tables[6] = {0, 0, 0, 0, 0, 0}; // survive / born of main, edges, corners (bit k = value at count k)
@@ -93,6 +104,7 @@ struct PackedLaunch
 	int roll_z = 0; // 0: the launcher picks the planes per thread of the rolling-window kernel; 2 / 4 / 8 (tile form: 16 too): forced (tests, tuning)
 	int roll_tile = 1; // 1: the tile form of the rolling-window kernel (ca_packed_roll_kernel.inc, tile_step); 0: every thread shifts its three rows itself;
 	                   // 2: wave tiles (the tile form with one wave per workgroup: no barrier); 3: two words per thread, no LDS (roll_step_w2)
+	const RowsJit *rows_jit = nullptr; // the rows kernel compiled for exactly this grid and these rules, or null
 };
 
 // One launch of the resident multi-step kernel (ca_resident.hip): `steps` steps from `in`, state on chip in between
@@ -186,6 +198,9 @@ void class_tables(const CanonRules &r, uint32_t tables[6]);
 int class_zrun(const CanonRules &r); // planes per thread of the deep variant for these rules
 bool use_class_kernel(const CanonRules &r, uint32_t G, int variant);
 int jit_class_kernels(int device, const CanonRules &r, ClassJit *out, std::string *log);
+int jit_rows_kernels(int device, const CanonRules &r, uint32_t G, RowsJit *out, std::string *log);
+// Whether the rows kernel is the one to use for these rules on this grid: named classes, and no uint4 kernel with the rule compiled in
+bool rows_kernel_applies(const CanonRules &r, uint32_t G, int variant);
 int jit_roll_kernels(int device, const CanonRules &r, int cvl, RollJit *out, std::string *log);
 // Whether the rolling-window kernel is the one to use for these rules on this grid (diagonal neighbour classes in
 // play, power-of-two grid of 256 and up)

@@ -346,7 +346,10 @@ hipError_t launch_class(const PackedLaunch &l, hipStream_t stream)
 	const bool deep = (size_t)g.tiles_per_plane * ((planes + ZRUN - 1u) / ZRUN) >= 1024u && shortest >= (u32)ZRUN;
 	const bool fast = rules_fit_fast(*l.rules);
 	const bool p2 = (g.use_shfl & 1u) != 0;
-	const u32 zr_used = (deep && p2) ? (u32)ZRUN : 1u;
+	const ClassJit *jit = l.class_jit;
+	const bool jit_ok = jit && jit->main == MAIN && jit->e == E && jit->c == C_ && jit->deep && jit->deep_za && jit->flat;
+	const bool np2_jit = !p2 && jit_ok && jit->deep_np2 && jit->flat_np2; // rows of whole uint4, not a power of two of them: the run-time compiled form
+	const u32 zr_used = (deep && (p2 || np2_jit)) ? (u32)ZRUN : 1u;
 	g.runs1 = (planes1 + zr_used - 1u) / zr_used;
 	const u32 runs = g.runs1 + (planes2 + zr_used - 1u) / zr_used;
 	const dim3 grid_deep(g.tiles_per_plane * runs), grid_flat(g.tiles_per_plane * runs);
@@ -428,8 +431,16 @@ hipError_t launch_class(const PackedLaunch &l, hipStream_t stream)
 			return hipModuleLaunchKernel((hipFunction_t)fn, g.tiles_per_plane * nruns, 1, 1, 256, 1, 1, tile_form ? 0u : lds_pad, stream, args, nullptr);
 		}
 	}
-	const ClassJit *jit = l.class_jit;
-	if (p2 && jit && jit->main == MAIN && jit->e == E && jit->c == C_ && jit->deep && jit->deep_za && jit->flat)
+	if (np2_jit)
+	{
+		const u32 *in = l.in;
+		u32 *out = l.out;
+		PlaneRange pr = l.pr;
+		PackedRuleArgs prog = l.rules->prog;
+		void *args[] = {(void *)&in, (void *)&out, (void *)&pr, (void *)&g, (void *)&prog};
+		return hipModuleLaunchKernel((hipFunction_t)(deep ? jit->deep_np2 : jit->flat_np2), grid_deep.x, 1, 1, 256, 1, 1, 0, stream, args, nullptr);
+	}
+	if (p2 && jit_ok)
 	{
 		// the run-time compiled kernel for exactly these rules (truth tables baked in: ca_jit.cpp). z-aligned: every
 		// z-run starts on a global plane that is a multiple of ZRUN, so plane 0 is never in the middle of a run.
@@ -475,6 +486,11 @@ hipError_t launch_class_ec(const PackedLaunch &l, hipStream_t stream)
 
 } // namespace
 
+struct RowsArgs // ca_packed_rows_kernel.inc
+{
+	u32 runs1, nt;
+};
+
 bool roll_kernel_applies(const CanonRules &r, uint32_t G, int variant)
 {
 	if (!use_class_kernel(r, G, variant) || vn_kernel_applies(r, G, variant)) return false;
@@ -489,6 +505,26 @@ int class_zrun(const CanonRules &r)
 {
 	const bool diagonals = r.need[1] || r.need[2] || r.main == MAIN_MOORE || r.main == MAIN_EDGES || r.main == MAIN_CORNERS;
 	return diagonals ? 4 : 2; // must match ZRUN of launch_class
+}
+
+// Grids the uint4 kernels serve without their compile-time-rule forms (G % 128 == 0 but not a power of two: cube programs, extra
+// edge loads) or not at all (rows that are not whole uint4: ca_packed_generic): the rows kernel (ca_packed_rows_kernel.inc, run-time
+// compiled for the grid and the rule) takes them.
+bool rows_kernel_applies(const CanonRules &r, uint32_t G, int variant)
+{
+	if (variant == 1 || !r.fast || G % 32u || G < 32u || G > 2048u) return false;
+	const uint32_t cv = G / 128u;
+	const bool p2_uint4 = G % 128u == 0 && (cv & (cv - 1u)) == 0; // vn / class (jit) / rolling kernels
+	if (p2_uint4) return false;
+	// Rows of whole uint4 that are not a power of two of them (384, 640, 768, 896): the class kernel's run-time compiled form serves
+	// them as well (ca3d_jit_class_*_np2: uint4 loads, two extra dword loads per row for the edge words). Measured (us per step,
+	// class np2 / rows; profiles/r4_s_rows_vs_class_np2.txt): start-up rule 384 5.8 / 5.5, 640 13.9 / 17.8, 768 22.9 / 32.4,
+	// 896 33.8 / 43.5; clustered 384 12.8 / 9.0, 640 35.8 / 32.1, 768 54.9 / 57.2, 896 82.5 / 76.8 — face-only rules on the larger
+	// grids stay with the uint4 loads, rules with diagonal classes (nine rows per plane: the edge loads triple) take the rows kernel.
+	// CA3D_ROWS_NP2 = 0 / 1 forces one of them (tuning).
+	static const int np2_env = getenv("CA3D_ROWS_NP2") ? atoi(getenv("CA3D_ROWS_NP2")) : -1;
+	if (G % 128u == 0) return np2_env >= 0 ? np2_env != 0 : (class_zrun(r) == 4 || G < 512u);
+	return true;
 }
 
 bool use_class_kernel(const CanonRules &r, uint32_t G, int variant)
@@ -545,6 +581,25 @@ hipError_t launch_packed_step(const PackedLaunch &l, hipStream_t stream, const c
 		return launch_packed_step(only, stream, nullptr);
 	}
 	if (vn_kernel_applies(r, l.pr.G, l.variant)) return launch_packed_vn(l, stream);
+	if (const RowsJit *rj = l.rows_jit; rj && rj->G == l.pr.G && rj->main == (int)r.main && rj->e == r.need[1] && rj->c == r.need[2] && rj->deep && rj->flat)
+	{
+		const bool two = l.pr.hi2 > l.pr.lo2;
+		const u32 G = l.pr.G, C = G / 32u, R = C >= 64u ? 1u : 64u / C, bpp = ((G + R - 1u) / R + 3u) / 4u;
+		const u32 planes1 = l.pr.hi - l.pr.lo, planes2 = two ? l.pr.hi2 - l.pr.lo2 : 0u;
+		const u32 shortest = two ? (planes1 < planes2 ? planes1 : planes2) : planes1;
+		const u32 Z = shortest >= (u32)rj->zrun && (size_t)bpp * ((planes1 + planes2) / (u32)rj->zrun) >= 1024u ? (u32)rj->zrun : 1u; // deep only while it fills the chip
+		RowsArgs a;
+		a.runs1 = (planes1 + Z - 1u) / Z;
+		a.nt = (size_t)l.pr.nplanes * G * C * sizeof(u32) <= (16u << 20) ? 1u : 0u; // as ca_packed_vn: while both buffers sit in the Infinity Cache with room to spare
+		const u32 nruns = a.runs1 + (planes2 + Z - 1u) / Z;
+		const u32 *in = l.in;
+		u32 *out = l.out;
+		PlaneRange pr = l.pr;
+		if (!two) pr.lo2 = pr.hi2 = 0;
+		void *args[] = {(void *)&in, (void *)&out, (void *)&pr, (void *)&a};
+		if (kernel_name) *kernel_name = "ca_packed_rows(jit)";
+		return hipModuleLaunchKernel((hipFunction_t)(Z > 1u ? rj->deep : rj->flat), bpp * nruns, 1, 1, 256, 1, 1, 0, stream, args, nullptr);
+	}
 	if (l.pr.hi2 > l.pr.lo2 && !use_class_kernel(r, l.pr.G, l.variant))
 	{
 		// the generic kernel takes one range per launch

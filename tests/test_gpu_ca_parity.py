@@ -26,8 +26,10 @@ def test_one_and_many_steps_random_fill(eng, G, name):
     for jit in (1, 0):  # run-time compiled rule specialisation (where one applies), then the pre-built kernels
         eng.set_option("jit", jit)
         set_rules(eng, r)
-        # power-of-two grids from 128 up have a specialisation; the start-up rule's is pre-built from 256 up
-        assert (b"(jit)" in eng.info().kernel_name) == (bool(jit) and G >= 128 and not (name == "default" and G >= 256))
+        # every grid has a kernel compiled for the rule at run time (power-of-two grids from 128 up: the uint4 kernels; the others:
+        # the rows kernel); the start-up rule's is pre-built on power-of-two grids from 256 up
+        assert (b"(jit)" in eng.info().kernel_name) == (bool(jit) and not (name == "default" and G >= 256))
+        assert (b"ca_packed_rows" in eng.info().kernel_name) == (bool(jit) and G < 128)
         for rounds in (0, 3):
             st = host.random_fill(host.words_per_buffer(G), seed=0xCA3D0001 + G, and_rounds=rounds)
             eng.upload_state(st)
@@ -97,6 +99,54 @@ def test_random_rules_through_the_rule_compilers(eng):
             np.testing.assert_array_equal(eng.read_state(), want, err_msg=f"{kw} jit={jit} variant={variant} {eng.info().kernel_name}")
     eng.set_option("jit", 1)
     eng.set_option("variant", 0)
+
+
+@pytest.mark.parametrize("G", [96, 160, 384, 640])
+@pytest.mark.parametrize("name", list(RULESETS))
+def test_rows_kernel_on_grids_that_are_not_powers_of_two(eng, G, name):
+    """The grids the reference UI offers are the multiples of 32 up to 1024 (main_pathtraced.js:268-279, 675-693). Those that are not
+    powers of two run the rows kernel (ca_packed_rows_kernel.inc, compiled for grid and rule at run time): against the oracle, and
+    against the kernels that served them before (option rows 0: the class kernel's pre-built form on multiples of 128, else the
+    generic kernel)."""
+    r = rules(name)
+    eng.configure(G)
+    set_rules(eng, r)
+    # rows of whole uint4 (G % 128 == 0) keep the class kernel — its run-time compiled non-power-of-two form — for face-only rules on
+    # the larger grids (measured faster there: ca_packed.hip, rows_kernel_applies); everything else is the rows kernel
+    face_only = name in ("default", "vn2d", "vn_b24_s135")
+    want_rows = G % 128 != 0 or G < 512 or not face_only
+    assert (eng.info().kernel_name == b"ca_packed_rows(jit)") == want_rows and b"(jit)" in eng.info().kernel_name
+    for rounds in (0, 4):
+        st = host.random_fill(host.words_per_buffer(G), seed=0xCA3D0001 + G, and_rounds=rounds)
+        eng.upload_state(st)
+        eng.step(1)
+        want1 = ol.packed_step(G, st, r)
+        np.testing.assert_array_equal(eng.read_state(), want1)
+        eng.step(5)  # batches of more than one step: z-runs of several planes, graph replay
+        want6 = ol.packed_run(G, want1, r, 5)
+        np.testing.assert_array_equal(eng.read_state(), want6)
+    eng.set_option("rows", 0)
+    try:
+        assert b"rows" not in eng.info().kernel_name
+        eng.upload_state(st)
+        eng.step(6)
+        np.testing.assert_array_equal(eng.read_state(), want6)
+    finally:
+        eng.set_option("rows", 1)
+
+
+@pytest.mark.parametrize("name", ["default", "clustered"])
+def test_rows_kernel_at_992(eng, name):
+    """"1000" in the reference UI becomes 992 (_gridSizeUIFormatter): rows of 31 words, two rows per wave."""
+    G = 992
+    r = rules(name)
+    eng.configure(G)
+    set_rules(eng, r)
+    assert eng.info().kernel_name == b"ca_packed_rows(jit)"
+    st = host.random_fill(host.words_per_buffer(G), seed=992, and_rounds=1)
+    eng.upload_state(st)
+    eng.step(3)
+    np.testing.assert_array_equal(eng.read_state(), ol.packed_run(G, st, r, 3, 16))
 
 
 @pytest.mark.parametrize("G", [128, 256])

@@ -79,8 +79,22 @@ namespace jit
 }
 """
 
+ROWS_PROGRAM = b"""
+#include "ca_device_types.h"
+namespace ca3d
+{
+namespace jit
+{
+#include "ca_bitops.inc"
+#include "ca_jit_rule.inc"
+#include "ca_bitslice.inc"
+#include "ca_packed_rows_kernel.inc"
+}
+}
+"""
+
 HEADERS = [b"ca_bitops.inc", b"ca_packed_vn_kernel.inc", b"ca_device_types.h", b"ca_bitslice.inc", b"ca_packed_class_kernel.inc",
-           b"ca_packed_roll_kernel.inc", b"ca_resident_kernel.inc", b"ca_resident_class_kernel.inc"]
+           b"ca_packed_roll_kernel.inc", b"ca_resident_kernel.inc", b"ca_resident_class_kernel.inc", b"ca_packed_rows_kernel.inc"]
 
 
 #: the clustered rule as rule_synth.cpp writes it (the generated header the engine passes as "ca_jit_rule.inc")
@@ -137,6 +151,21 @@ def test_class_kernel_source_compiles_with_hiprtc(main, e, c, zr, tables):
     defines += [b"-DCA3D_JIT_%s=%du" % (n, t) for n, t in zip([b"TS0", b"TB0", b"TS1", b"TB1", b"TS2", b"TB2"], tables)]
     code = _compile(rtc, CLASS_PROGRAM, b"ca3d_jit_class.hip", defines)
     assert b"ca3d_jit_class_deep" in code and b"ca3d_jit_class_deep_za" in code and b"ca3d_jit_class_flat" in code
+
+
+@pytest.mark.parametrize("G,main,e,c,zr,tables", [
+    (992, 0, "false", "false", 2, (0x7F, 0x0A, 0, 0, 0, 0)),                                 # "1000" in the UI, the start-up rule
+    (96, 2, "true", "true", 4, (0x000000F0, 0x000000E0, 0x0038, 0x0010, 0x0014, 0x0008)),   # rows of 3 words, the clustered rule's shape
+    (32, 3, "false", "false", 2, (0x000C, 0x0008, 0, 0, 0, 0)),                              # one word per row
+    (1984, 5, "true", "false", 4, (0x0014, 0x0008, 0x0038, 0x0010, 0, 0)),                   # rows of 62 words: one row per wave
+])
+def test_rows_kernel_source_compiles_with_hiprtc(G, main, e, c, zr, tables):
+    """ca_packed_rows_kernel.inc: the kernel of every grid that is not a power of two (any multiple of 32)."""
+    rtc = _hiprtc()
+    defines = [b"-DCA3D_JIT_G=%d" % G, b"-DCA3D_JIT_MAIN=%d" % main, b"-DCA3D_JIT_E=" + e.encode(), b"-DCA3D_JIT_C=" + c.encode(), b"-DCA3D_JIT_ZR=%d" % zr]
+    defines += [b"-DCA3D_JIT_%s=%du" % (n, t) for n, t in zip([b"TS0", b"TB0", b"TS1", b"TB1", b"TS2", b"TB2"], tables)]
+    code = _compile(rtc, ROWS_PROGRAM, b"ca3d_jit_rows.hip", defines)
+    assert b"ca3d_jit_rows_deep" in code and b"ca3d_jit_rows_flat" in code
 
 
 @pytest.mark.parametrize("cvl,lut_s,lut_b", [(2, 0x2A, 0x14), (1, 0xFF, 0x0A), (6, 0x00, 0x7E)])

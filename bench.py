@@ -102,6 +102,7 @@ def parse(argv=None):
                     help="N=1: also time the same calls under the other submission mode (`other_submission` in the JSON line; off by default so "
                          "that a profile of the default command holds launches of one length only)")
     ap.add_argument("--queue", type=int, default=2048, help="steps per submission with --submit queued")
+    ap.add_argument("--no-schedule-compare", action="store_true", help="N>1: do not time the other batch schedule (overlap on / off) behind the headline")
     ap.add_argument("--check", action="store_true", help="verify the final state against the oracle (small grids)")
     ap.add_argument("--verify-steps", type=int, default=-1,
                     help="before the timed region run this many steps from the bench state through the headline path and compare the state (N>1: every "
@@ -718,6 +719,20 @@ def main():
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             ok = bool(flag.item())
 
+    schedules = None
+    if world > 1 and not a.no_schedule_compare:
+        # The same slabs under the OTHER batch schedule, timed right behind the headline (state carried on): overlap on = edge zones,
+        # exchange posted, interior under it; off = exchange, then the whole slab in one launch. On one GPU's loopback the split form
+        # measured slower (two smaller launches per step) — whether the transfer it hides pays for that is a property of the real links,
+        # so every multi-GPU line carries both and the reader picks.
+        first = bool(se.overlap)
+        se.overlap = not first
+        dt_o, reps_o, _, _, _ = timed_region(se.run, se.stream, a.steps, a.steps, a.min_seconds / 2, barrier, world, a.backend)
+        se.overlap = first
+        rec = lambda d, r: {"ms_per_step": round(d * 1e3 / (a.steps * r), 6), "value": round(cells * a.steps * r / d / 1e9, 3), "unit": "Gcells/s"}
+        schedules = {"overlap_on" if first else "overlap_off": rec(dt, reps), "overlap_off" if first else "overlap_on": rec(dt_o, reps_o),
+                     "headline": "overlap_on" if first else "overlap_off",
+                     "why_headline": ("BASELINE configs[4] names the overlapped schedule" if a.config == 5 else "--overlap / slab.py's automatic choice")}
     multi_render = None
     if world > 1 and a.multi_render:
         multi_render = render_leg_multi(se, G, a, world, rank, barrier)
@@ -748,6 +763,8 @@ def main():
             ceiling = copy_ceiling_gbs(eng)
             out["copy_ceiling"] = {"value": round(ceiling, 1), "unit": "GB/s",
                                    "how": "1 GiB float4-per-lane device-to-device copy, non-temporal stores (ca3d_measure_copy), bytes read + bytes written per second, measured in this run"}
+        if schedules is not None:
+            out["schedules"] = schedules
         if ok is not None:
             out["oracle_match"] = ok
         if world == 1 and single_verified is not None:

@@ -1984,6 +1984,22 @@ namespace ca3d
 {
 int engine_device(const ca3d_engine *h) { return h->device; }
 hipStream_t engine_stream(const ca3d_engine *h) { return h->stream; }
+
+// A full-grid engine that only ever RECEIVES its state on the device (the group's frame: peer copies of the slabs): both buffers
+// cleared on the engine's stream, marked as holding a state — no host copy of the grid, no synchronous upload.
+int engine_mark_state(ca3d_engine *h)
+{
+	if (!h || !h->configured || h->slab) return fail(CA3D_ERR_NOT_CONFIGURED, "engine_mark_state: a configured full-grid engine is needed");
+	int rc = bind_device(h);
+	if (rc) return rc;
+	HIP_TRY(hipMemsetAsync(h->buf[0], 0, h->buffer_words() * sizeof(uint32_t), h->stream));
+	HIP_TRY(hipMemsetAsync(h->buf[1], 0, h->buffer_words() * sizeof(uint32_t), h->stream));
+	h->step = 0;
+	h->cur = 0;
+	h->has_state = true;
+	h->binary_state = true;
+	return CA3D_OK;
+}
 void engine_set_ghosts_valid(ca3d_engine *h, bool valid) { h->ghosts_valid = valid; }
 bool engine_ghosts_valid(const ca3d_engine *h) { return h->ghosts_valid; }
 

@@ -354,6 +354,10 @@ int ca3d_group_render(ca3d_group_t *g, const float uniforms[128], uint32_t width
 		{
 			ca3d_t *f = nullptr;
 			int rc = ca3d_create(g->devices[(size_t)k], &f);
+			// this engine never steps: no run-time compilation, no resident kernel (three kernel selections — configure, set_rules,
+			// set_stream — would otherwise each compile for nothing)
+			if (rc == CA3D_OK) rc = ca3d_set_option(f, "jit", 0);
+			if (rc == CA3D_OK) rc = ca3d_set_option(f, "resident", 0);
 			if (rc == CA3D_OK) rc = ca3d_configure(f, g->G, g->G, g->G, g->layout);
 			if (rc == CA3D_OK) rc = ca3d_set_rules(f, g->r_main.data(), (uint32_t)g->r_main.size(), g->r_edges.data(), (uint32_t)g->r_edges.size(), g->r_corners.data(),
 			                                        (uint32_t)g->r_corners.size(), g->r_survive, g->r_born);
@@ -361,9 +365,9 @@ int ca3d_group_render(ca3d_group_t *g, const float uniforms[128], uint32_t width
 			if (rc) { if (f) ca3d_destroy(f); destroy_full(g); return rc; }
 			g->full.push_back(f);
 		}
-		// a full-grid engine wants a state before it renders; the gather below overwrites it
-		std::vector<uint32_t> zero((size_t)(g->G / 32u) * g->G * g->G, 0u);
-		for (ca3d_t *f : g->full) G_TRY(ca3d_upload_state(f, zero.data(), zero.size()));
+		// a full-grid engine wants a state before it renders; the gather below overwrites it (cleared on the device: no host copy of
+		// the grid — 1 GiB at 2048^3 — and no synchronous upload)
+		for (ca3d_t *f : g->full) G_TRY(engine_mark_state(f));
 	}
 	// every slab's owned planes -> every rank's full volume (the ranks' own batches are done: ev_done)
 	for (int k = 0; k < n; k++)

@@ -249,6 +249,7 @@ hipError_t launch_unpacked_step(const UnpackedLaunch &l, hipStream_t stream, con
 int set_error(int code, const char *fmt, ...);
 int engine_device(const ca3d_engine *h);
 hipStream_t engine_stream(const ca3d_engine *h);
+int engine_mark_state(ca3d_engine *h); // both buffers zeroed on the engine's stream, "has a state" — for engines whose state arrives by device copies
 void engine_set_ghosts_valid(ca3d_engine *h, bool valid);
 bool engine_ghosts_valid(const ca3d_engine *h);
 int engines_rccl_init_all(ca3d_engine **engines, int n);

@@ -1693,7 +1693,7 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 		l.stream_scratch = h->r_stream;
 		l.stream_check = h->render_stream_check != 0;
 	}
-	if (h->render_mode == 1 && h->render_frame_bricks && frame_bricks_applies(h->G))
+	if (h->render_frame_bricks && frame_bricks_applies(h->G) && (h->render_mode == 1 || l.stream_scratch))
 	{
 		const size_t need = frame_bricks_bytes(h->G);
 		if (h->r_bricks_bytes != need)

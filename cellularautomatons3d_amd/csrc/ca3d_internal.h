@@ -160,8 +160,9 @@ struct RenderLaunch
 	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 	// mode 0, packed, scheduled: scratch of the ray-stream pipeline (render_stream.hip; stream_scratch_bytes(W, H, spp) bytes) — with it the
 	// dense-volume part of the frame is drawn by the stream passes instead of ca_render_packed_sched (same frame, bit for bit). Null: not used.
-	uint32_t *bricks = nullptr; // mode 1: room for the bricked copy of the volume (frame_bricks_bytes(G)); with it — and a power-of-two grid — the
-	                            // frame is drawn by render_frame.hip's batched march instead of ca_render_frame_packed (same frame, bit for bit)
+	uint32_t *bricks = nullptr; // room for the bricked copy of the volume (frame_bricks_bytes(G)); with it — and a power-of-two grid — mode 1's frame is
+	                            // drawn by render_frame.hip's batched march instead of ca_render_frame_packed, and mode 0's stream walks read the bricks
+	                            // (same frames, bit for bit)
 	void *stream_scratch = nullptr;
 	bool stream_check = false; // diagnostics: every live-cell decision of the interval filter is checked against the slab test and contradictions counted
 };
@@ -177,7 +178,8 @@ size_t stream_scratch_bytes(uint32_t W, uint32_t H, uint32_t spp, size_t *hit_of
 size_t frame_bricks_bytes(uint32_t G);
 bool frame_bricks_applies(uint32_t G);
 hipError_t launch_render_frame_bricks(const void *frame_params, uint32_t *bricks, hipStream_t stream);
-hipError_t launch_render_stream(const void *params, void *scratch, uint32_t W, uint32_t H, bool check, hipStream_t stream);
+hipError_t launch_brick_volume(const uint32_t *cells, uint32_t *bricks, uint32_t G, hipStream_t stream);
+hipError_t launch_render_stream(const void *params, void *scratch, uint32_t W, uint32_t H, bool check, uint32_t *bricks, hipStream_t stream);
 
 // ca_packed.hip / ca_unpacked.hip
 hipError_t launch_packed_step(const PackedLaunch &l, hipStream_t stream, const char **kernel_name);

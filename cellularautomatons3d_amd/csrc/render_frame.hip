@@ -328,6 +328,16 @@ size_t frame_bricks_bytes(uint32_t G) { return (size_t)G * G * G / 8u; }
 
 bool frame_bricks_applies(uint32_t G) { return G >= 32u && (G & (G - 1u)) == 0u; }
 
+// The bricked copy of a packed state (power-of-two grids): one pass, on `stream`.
+hipError_t launch_brick_volume(const uint32_t *cells, uint32_t *bricks, uint32_t G, hipStream_t stream)
+{
+	u32 lg = 0;
+	while ((1u << lg) < G) lg++;
+	const size_t words = (size_t)G * G * G / 32u;
+	hipLaunchKernelGGL(ca_brick_volume, dim3((unsigned)((words + 255u) / 256u)), dim3(256), 0, stream, cells, bricks, lg, words);
+	return hipGetLastError();
+}
+
 // One literal frame over the bricked copy of `cells` (rebuilt here): `frame_params` is render.hip's FrameParams.
 hipError_t launch_render_frame_bricks(const void *frame_params, uint32_t *bricks, hipStream_t stream)
 {
@@ -337,8 +347,8 @@ hipError_t launch_render_frame_bricks(const void *frame_params, uint32_t *bricks
 	B.bricks = bricks;
 	B.lg = 0;
 	while ((1u << B.lg) < P.G) B.lg++;
-	const size_t words = (size_t)P.G * P.G * P.G / 32u;
-	hipLaunchKernelGGL(ca_brick_volume, dim3((unsigned)((words + 255u) / 256u)), dim3(256), 0, stream, P.cells, bricks, B.lg, words);
+	hipError_t eb = launch_brick_volume(P.cells, bricks, P.G, stream);
+	if (eb != hipSuccess) return eb;
 	B.tiles_x = (P.W + 15u) / 16u;
 	B.tiles = B.tiles_x * ((P.H + 15u) / 16u);
 	const u32 per = (B.tiles + 7u) >> 3;

@@ -296,6 +296,107 @@ __device__ __forceinline__ int walk_cell(const StreamParams &S, Walker &w, int k
 	return (outside || t >= w.tmax) ? 2 : 0;
 }
 
+// ---- the batched form of the stepping loop -----------------------------------------------------------------------------------
+// The walk's next cell depends on arithmetic only (the boundary times), never on what the volume holds: a lane can run kBatch cells
+// ahead, ask for all their words at once and test them in order when they arrive — ONE memory round trip per kBatch cells instead
+// of one per cell (the literal frame's batched march, render_frame.hip, for a walk whose positions come from a DDA). A batch:
+//   forward   kBatch x { key and bit of the cell, read issued, advance } from a saved copy of the boundary state; cells past the walk's
+//             end are masked;
+//   test      the live bits of the valid cells (the shadow ray's start cell exempt), a mask per lane;
+//   replay    lanes with a live cell (one in eight batches at the bench scene's density) go back to the saved state and advance to each
+//             live cell in turn for the interval filter / slab test — a hit ends the walk there, with the walker standing on the
+//             hit cell as the retire step expects; a lane without a hit ends where the forward pass ended.
+// Cells visited, hits and the state a hit leaves are those of the cell-by-cell loop (the same advance, the same filter).
+constexpr int kBatch = 4;
+
+// advance along the axis whose boundary comes first; true: the walk is over (left the volume or ran out of range)
+__device__ __forceinline__ bool walk_advance(const RenderParams &P, Walker &w)
+{
+	const float t = fminf(fminf(w.tx, w.ty), w.tz);
+	const bool mx = w.tx == t, my = !mx && w.ty == t, mz = !mx && !my;
+	w.t = t;
+	w.tx += mx ? w.dx : 0.0f;
+	w.ty += my ? w.dy : 0.0f;
+	w.tz += mz ? w.dz : 0.0f;
+	w.ix += mx ? w.sx : 0;
+	w.iy += my ? w.sy : 0;
+	w.iz += mz ? w.sz : 0;
+	const bool outside = (u32)(w.ix | w.iy | w.iz) >= P.G;
+	return outside || t >= w.tmax;
+}
+
+// the live cell the walker stands on: does the ray meet its visible cube? (interval filter, slab test inside its error band)
+template <bool SHADOW, bool CHECK>
+__device__ __forceinline__ bool walk_hit_test(const StreamParams &S, const Walker &w, v3 vhalf, float k0, float k1, float eps_a, const float *ctx, int stride)
+{
+	const RenderParams &P = S.R;
+	const float tn = fmaxf(fmaxf(__builtin_fmaf(-k1, w.dx, w.tx), __builtin_fmaf(-k1, w.dy, w.ty)), __builtin_fmaf(-k1, w.dz, w.tz));
+	const float tf = fminf(fminf(__builtin_fmaf(-k0, w.dx, w.tx), __builtin_fmaf(-k0, w.dy, w.ty)), __builtin_fmaf(-k0, w.dz, w.tz));
+	const float gap = tf - tn, lead = SHADOW ? tn : tf;
+	const float eps = __builtin_fmaf(__builtin_fmaf(eps_a, w.t, 3.814697265625e-6f), w.t, w.eps_b);
+	const bool yes = gap > eps && lead > eps, no = gap < -eps || lead < -eps;
+	float e;
+	if (CHECK)
+	{
+		const bool truth = slab_test<SHADOW>(P, w, vhalf, ctx, stride, e);
+		if ((yes && !truth) || (no && truth)) atomicAdd(&S.ctl[2], 1u);
+		return truth;
+	}
+	if (yes) return true;
+	if (no) return false;
+	return slab_test<SHADOW>(P, w, vhalf, ctx, stride, e);
+}
+
+// One batch for a lane with a ray. Returns the cells it visited; term: 0 keep walking, 1 hit (the walker stands on the cell), 2 over.
+template <bool SHADOW, int LAYOUT, bool CHECK>
+__device__ __forceinline__ u32 walk_batch(const StreamParams &S, Walker &w, bool &exempt, int &term, v3 vhalf, float k0, float k1, float eps_a,
+                                          const float *ctx, int stride)
+{
+	const RenderParams &P = S.R;
+	const float stx = w.tx, sty = w.ty, stz = w.tz, st = w.t;
+	const int six = w.ix, siy = w.iy, siz = w.iz;
+	u32 word[kBatch], pos = 0, nvalid = 0; // pos: 6 bits per cell — bit position, 32 for a cell past the walk's end
+	bool over = false;
+#pragma unroll
+	for (int k = 0; k < kBatch; k++)
+	{
+		const int key = over ? 0 : word_key<LAYOUT>(S, w.ix, w.iy, w.iz);
+		word[k] = *reinterpret_cast<const u32 *>(reinterpret_cast<const char *>(S.volume) + ((u32)key << 2));
+		pos |= (over ? 32u : word_bit<LAYOUT>(w.ix, w.iy)) << (6 * k);
+		nvalid += over ? 0u : 1u;
+		over = walk_advance(P, w) || over;
+	}
+	u32 live = 0;
+#pragma unroll
+	for (int k = 0; k < kBatch; k++)
+	{
+		const u32 b = (pos >> (6 * k)) & 63u;
+		live |= (b < 32u ? (word[k] >> b) & 1u : 0u) << k;
+	}
+	if (exempt) live &= ~1u; // the cell the shadow ray starts in: only ever the first cell of a walk
+	exempt = false;
+	u32 visited = nvalid;
+	bool hit = false;
+	if (live)
+	{
+		w.tx = stx; w.ty = sty; w.tz = stz; w.t = st; w.ix = six; w.iy = siy; w.iz = siz;
+#pragma unroll
+		for (int k = 0; k < kBatch; k++)
+		{
+			if (!hit)
+			{
+				if ((live >> k) & 1u)
+				{
+					if (walk_hit_test<SHADOW, CHECK>(S, w, vhalf, k0, k1, eps_a, ctx, stride)) { hit = true; visited = (u32)k + 1u; }
+				}
+				if (!hit) walk_advance(P, w);
+			}
+		}
+	}
+	term = hit ? 1 : (over ? 2 : 0);
+	return visited;
+}
+
 // Job source of the walk passes. The rectangle's jobs come in chunks (a pixel block x its samples, a power of two of jobs). Chunks
 // are handed to WORKGROUPS — eight queues, one per XCD (workgroups go to the XCDs round-robin), a load before the atomic so that an
 // empty queue costs none, the first chunk of a workgroup its own (thousands of pullers asking at once queue for tens of
@@ -309,7 +410,7 @@ __device__ __forceinline__ int walk_cell(const StreamParams &S, Walker &w, int k
 // balanced (1.55 ms against 0.90).
 constexpr int kWalkThreads = 512, kWalkWaves = kWalkThreads / 64, kSlots = 8;
 
-template <bool SHADOW, int LAYOUT, bool CHECK>
+template <bool SHADOW, int LAYOUT, bool CHECK, bool BATCHED>
 __global__ __launch_bounds__(kWalkThreads, kStreamWaves) void ca_stream_walk(StreamParams S)
 {
 	const RenderParams &P = S.R;
@@ -502,6 +603,19 @@ __global__ __launch_bounds__(kWalkThreads, kStreamWaves) void ca_stream_walk(Str
 		// (readfirstlane: the loop's bookkeeping — counts, threshold, exit — is wave-uniform and the compiler is told so: scalar
 		// registers and a scalar branch instead of an exec-masked loop with its per-iteration v_cndmask / v_cmp of uniform values)
 		const int leave_at = __builtin_amdgcn_readfirstlane(more ? 64 - S.refill : 0);
+		if (BATCHED)
+		{
+			do
+			{
+				u32 n = 0;
+				if (job >= 0 && term == 0) n = walk_batch<SHADOW, LAYOUT, CHECK>(S, w, exempt, term, vhalf, k0, k1, eps_a, ctx, stride);
+				// cells visited by the wave: n is 0 .. kBatch per lane
+#pragma unroll
+				for (int k = 0; k < kBatch; k++) visits += (u32)__builtin_amdgcn_readfirstlane(__popcll(__ballot(n > (u32)k)));
+				walking = __builtin_amdgcn_readfirstlane(__popcll(__ballot(job >= 0 && term == 0)));
+			} while (walking > leave_at);
+		}
+		else
 		// An iteration = one read of the volume per lane that needs one, then up to kInner cells (kInner > 1: the lanes whose next cell
 		// lies in what they hold go on without reading). What the loop is bound by was probed from every side (1080p, 4 samples, dense
 		// scene, kernel ms): 8 -> 4 waves per SIMD 0.87 -> 0.90; ten instructions fewer per cell (scalar bookkeeping, 32-bit offsets) no
@@ -628,12 +742,12 @@ __global__ __launch_bounds__(256) void ca_stream_resolve(StreamParams S)
 	}
 }
 
-template <int P2, bool CHECK>
+template <int P2, bool CHECK, bool BATCHED = false>
 void launch_walks(const StreamParams &S, u32 wgs, u32 job_blocks, hipStream_t stream)
 {
-	hipLaunchKernelGGL((ca_stream_walk<false, P2, CHECK>), dim3(wgs), dim3(kWalkThreads), 0, stream, S);
+	hipLaunchKernelGGL((ca_stream_walk<false, P2, CHECK, BATCHED>), dim3(wgs), dim3(kWalkThreads), 0, stream, S);
 	hipLaunchKernelGGL(ca_stream_shadow_rays, dim3(job_blocks), dim3(256), 0, stream, S);
-	hipLaunchKernelGGL((ca_stream_walk<true, P2, CHECK>), dim3(wgs), dim3(kWalkThreads), 0, stream, S);
+	hipLaunchKernelGGL((ca_stream_walk<true, P2, CHECK, BATCHED>), dim3(wgs), dim3(kWalkThreads), 0, stream, S);
 }
 
 } // namespace
@@ -706,7 +820,8 @@ hipError_t launch_render_stream(const void *params, void *scratch, uint32_t W, u
 	{
 		hipError_t eb = launch_brick_volume(P.cells, bricks, P.G, stream); // one pass over the state per frame (~10 us at 512^3)
 		if (eb != hipSuccess) return eb;
-		if (bricks_env == 2) { if (check) launch_walks<kBricks, true>(S, wgs, job_blocks, stream); else launch_walks<kBricks, false>(S, wgs, job_blocks, stream); }
+		if (bricks_env == 3) { if (check) launch_walks<kBricks, true, true>(S, wgs, job_blocks, stream); else launch_walks<kBricks, false, true>(S, wgs, job_blocks, stream); }
+		else if (bricks_env == 2) { if (check) launch_walks<kBricks, true>(S, wgs, job_blocks, stream); else launch_walks<kBricks, false>(S, wgs, job_blocks, stream); }
 		else if (check) launch_walks<kBricks64, true>(S, wgs, job_blocks, stream);
 		else launch_walks<kBricks64, false>(S, wgs, job_blocks, stream);
 	}

@@ -113,7 +113,7 @@ def test_rows_kernel_on_grids_that_are_not_powers_of_two(eng, G, name):
     set_rules(eng, r)
     # rows of whole uint4 (G % 128 == 0) keep the class kernel — its run-time compiled non-power-of-two form — for face-only rules on
     # the larger grids (measured faster there: ca_packed.hip, rows_kernel_applies); everything else is the rows kernel
-    face_only = name in ("default", "vn2d", "vn_b24_s135")
+    face_only = name in ("default", "vn2d", "vn_b24_s135", "life2d")  # (no rows of the planes above / below: two planes per thread)
     want_rows = G % 128 != 0 or G < 512 or not face_only
     assert (eng.info().kernel_name == b"ca_packed_rows(jit)") == want_rows and b"(jit)" in eng.info().kernel_name
     for rounds in (0, 4):

@@ -307,6 +307,9 @@ __device__ __forceinline__ int walk_cell(const StreamParams &S, Walker &w, int k
 //             live cell in turn for the interval filter / slab test — a hit ends the walk there, with the walker standing on the
 //             hit cell as the retire step expects; a lane without a hit ends where the forward pass ended.
 // Cells visited, hits and the state a hit leaves are those of the cell-by-cell loop (the same advance, the same filter).
+// Measured (CA3D_STREAM_BRICKS=3 selects it; bit-identical frames, the check mode passes): 1080p 4 spp 0.888 against 0.900 ms, one
+// sample 0.529 against 0.549, 4K 2.27 against 2.14 — a quarter of the memory round trips and no faster: like every other probe of
+// the stepping loop (see the cell-by-cell loop below) it says the walks are not waiting for the volume. Kept as an option.
 constexpr int kBatch = 4;
 
 // advance along the axis whose boundary comes first; true: the walk is over (left the volume or ran out of range)

@@ -626,7 +626,12 @@ __global__ __launch_bounds__(kWalkThreads, kStreamWaves) void ca_stream_walk(Str
 		// a whole 8 x 8 z-slice per lane (40 % fewer reads) - 4 %; kInner = 3 (a third fewer wave-level reads, more passes at low lane
 		// occupancy) + 13 %. PMC: the waves sit in s_waitcnt for 64-72 % of their cycles and issue VALU in 10-13 %. A latency chain per
 		// wave — cell -> key -> read -> test -> advance — that more waves do not hide (they queue behind the same vector L1) and that
-		// fewer instructions do not shorten much: the per-cell cost is the chain.
+		// fewer instructions do not shorten much: the per-cell cost is the chain. Two more forms were built on top, both bit-identical,
+		// neither faster: the batched loop below (four cells per memory round trip) and ray set-up moved out of the walkers into
+		// one-lane-per-job passes that leave 64-byte ray records (the walkers' refill was 40 % of their vector instructions: 926 static
+		// VALU and 25 divisions per round, against ~55 per cell) — 0.93 ms against 0.87 at 1080p, 2.43 against 2.14 at 4K: the record
+		// traffic cost more than the instructions it removed, the per-wave timeline (tools/stream_trace.py) stayed what it was — every
+		// wave alive for the first 45 % of a launch, mean life 225 of 369 us, 11 refill rounds of ~3 us of latency each.
 		do
 		{
 			int key = word_key<LAYOUT>(S, w.ix, w.iy, w.iz);

@@ -518,12 +518,12 @@ bool rows_kernel_applies(const CanonRules &r, uint32_t G, int variant)
 	if (p2_uint4) return false;
 	// Rows of whole uint4 that are not a power of two of them (384, 640, 768, 896): the class kernel's run-time compiled form serves
 	// them as well (ca3d_jit_class_*_np2: uint4 loads, two extra dword loads per row for the edge words). Measured (us per step,
-	// class np2 / rows; profiles/r4_s_rows_vs_class_np2.txt): start-up rule 384 5.8 / 5.5, 640 13.9 / 17.8, 768 22.9 / 32.4,
-	// 896 33.8 / 43.5; clustered 384 12.8 / 9.0, 640 35.8 / 32.1, 768 54.9 / 57.2, 896 82.5 / 76.8 — face-only rules on the larger
-	// grids stay with the uint4 loads, rules with diagonal classes (nine rows per plane: the edge loads triple) take the rows kernel.
-	// CA3D_ROWS_NP2 = 0 / 1 forces one of them (tuning).
+	// class np2 / rows with its z-run chosen by grid; profiles/r4_s_rows_vs_class_np2.txt): start-up rule 384 5.2 / 4.7, 640 13.5 / 12.2,
+	// 768 22.4 / 25.1, 896 30.7 / 32.0; clustered 384 12.7 / 8.5, 640 35.9 / 30.2, 768 54.5 / 50.8, 896 81.3 / 70.9 — face-only rules on
+	// the largest of these grids stay with the uint4 loads, everything else (rules with diagonal classes: nine rows per plane, the edge
+	// loads triple) takes the rows kernel. CA3D_ROWS_NP2 = 0 / 1 forces one of them (tuning).
 	static const int np2_env = getenv("CA3D_ROWS_NP2") ? atoi(getenv("CA3D_ROWS_NP2")) : -1;
-	if (G % 128u == 0) return np2_env >= 0 ? np2_env != 0 : (class_zrun(r) == 4 || G < 512u);
+	if (G % 128u == 0) return np2_env >= 0 ? np2_env != 0 : (class_zrun(r) == 4 || G < 768u);
 	return true;
 }
 

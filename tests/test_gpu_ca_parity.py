@@ -101,7 +101,7 @@ def test_random_rules_through_the_rule_compilers(eng):
     eng.set_option("variant", 0)
 
 
-@pytest.mark.parametrize("G", [96, 160, 384, 640])
+@pytest.mark.parametrize("G", [96, 160, 384, 768])
 @pytest.mark.parametrize("name", list(RULESETS))
 def test_rows_kernel_on_grids_that_are_not_powers_of_two(eng, G, name):
     """The grids the reference UI offers are the multiples of 32 up to 1024 (main_pathtraced.js:268-279, 675-693). Those that are not
@@ -114,7 +114,7 @@ def test_rows_kernel_on_grids_that_are_not_powers_of_two(eng, G, name):
     # rows of whole uint4 (G % 128 == 0) keep the class kernel — its run-time compiled non-power-of-two form — for face-only rules on
     # the larger grids (measured faster there: ca_packed.hip, rows_kernel_applies); everything else is the rows kernel
     face_only = name in ("default", "vn2d", "vn_b24_s135", "life2d")  # (no rows of the planes above / below: two planes per thread)
-    want_rows = G % 128 != 0 or G < 512 or not face_only
+    want_rows = G % 128 != 0 or G < 768 or not face_only
     assert (eng.info().kernel_name == b"ca_packed_rows(jit)") == want_rows and b"(jit)" in eng.info().kernel_name
     for rounds in (0, 4):
         st = host.random_fill(host.words_per_buffer(G), seed=0xCA3D0001 + G, and_rounds=rounds)

@@ -551,9 +551,15 @@ int check_resident(ca3d_engine *h)
 	for (size_t i = idx; i < h->res_pending.size(); i++) total += h->res_pending[i].n;
 	h->res_pending.clear();
 	drop_graph(h);
+	// The three buffers only rotate: whichever of them is neither the failed launch's input nor its other buffer is the spare — not
+	// `p.spare`, which is null when that launch was a one-step one issued before a later queued launch allocated the third buffer
+	// (restoring null would leak it).
+	uint32_t *third = p.spare;
+	for (uint32_t *q : {h->buf[0], h->buf[1], h->spare})
+		if (q && q != p.in && q != p.other) third = q;
 	h->buf[p.cur_before] = p.in;
 	h->buf[p.cur_before ^ 1u] = p.other;
-	h->spare = p.spare;
+	h->spare = third;
 	h->cur = p.cur_before;
 	h->step = p.step_before;
 	HIP_TRY(hipMemsetAsync(h->res_mail, 0, h->res_mail_bytes, h->stream));

@@ -1601,7 +1601,12 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 	if (h->render_mode == 1 && spp != 1) return fail(CA3D_ERR_INVALID_ARGUMENT, "the literal frame mode takes one jittered sample per pixel (spp = 1)");
 	int rc = bind_device(h);
 	if (rc) return rc;
-	rc = settle_resident(h); // the frame shows a state the engine has verified
+	// The frame shows a state the engine has verified — when the caller gets the frame back on the host. A frame that stays on the
+	// device (no host pointers: the reference's render pass, which only enqueues) does not block on the step batch in front of it: a
+	// resident launch that has ALREADY given up (pinned flag set) is recovered first, one still running is left pending — the next
+	// call that waits for the stream verifies it, and a frame drawn from a launch that later turns out to have timed out (a foreign
+	// kernel holding CUs for 200 ms) is simply the wrong frame once.
+	if (presentation_rgba8 || light_rgba16f || depth_rg16f || (h->res_status_host && *h->res_status_host)) rc = settle_resident(h);
 	if (rc) return rc;
 	const size_t px = (size_t)width * height;
 	if (width != h->rw || height != h->rh)

@@ -172,6 +172,9 @@ struct ca3d_engine
 	int render_frame_bricks = 1; // literal frame mode: the batched march over a bricked copy of the volume (render_frame.hip); 0: ca_render_frame_packed
 	uint32_t *r_bricks = nullptr;
 	size_t r_bricks_bytes = 0;
+	// what the renderer's derived buffers (occupancy bits, bricks) were last built from: serial (bumped by everything that writes the state
+	// other than a step: uploads, buffers handed out, gathers), step count, buffer
+	uint64_t state_serial = 1, r_occ_key[3] = {0, 0, 0}, r_bricks_key[3] = {0, 0, 0};
 	void *r_stream = nullptr;    // scratch of the stream passes
 	size_t r_stream_bytes = 0;
 	int r_swap = 0;
@@ -562,6 +565,7 @@ int check_resident(ca3d_engine *h)
 	h->spare = third;
 	h->cur = p.cur_before;
 	h->step = p.step_before;
+	h->state_serial++; // whatever the renderer derived from the buffers of the failed launches is void
 	HIP_TRY(hipMemsetAsync(h->res_mail, 0, h->res_mail_bytes, h->stream));
 	HIP_TRY(hipMemsetAsync(h->res_status, 0, kResStatusBytes, h->stream));
 	h->res_status_host[0] = h->res_status_host[1] = 0;
@@ -975,6 +979,7 @@ int ca3d_upload_state(ca3d_t *h, const uint32_t *words, size_t n_words)
 	HIP_TRY(hipStreamSynchronize(h->stream));
 	h->step = 0;
 	h->cur = 0;
+	h->state_serial++;
 	h->pending_edges = 0; // a restart between the two phases of a batch abandons the batch
 	h->ghosts_valid = false;
 	h->res_pending.clear(); // their results have just been overwritten
@@ -1377,6 +1382,7 @@ int ca3d_slab_gather(ca3d_t *h, ca3d_t *full)
 		HIP_TRY(hipStreamWaitEvent(full->stream, h->ev_gather, 0));
 	}
 	full->has_state = true;
+	full->state_serial++;
 	return CA3D_OK;
 }
 
@@ -1486,6 +1492,7 @@ int ca3d_device_buffer(ca3d_t *h, int which, void **device_ptr, size_t *n_bytes)
 	if (int rcs = settle_resident(h)) return rcs;
 	*device_ptr = h->buf[which];
 	*n_bytes = h->buffer_words() * sizeof(uint32_t);
+	h->state_serial++; // the caller may write through the pointer: what the renderer derived from the state is stale from here on
 	return CA3D_OK;
 }
 
@@ -1653,9 +1660,10 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 	if (h->render_skip && h->layout == CA3D_LAYOUT_PACKED32)
 	{
 		const size_t fine = (size_t)(h->G / 32u) * (h->G / 8u) * (h->G / 8u); // fine bits, count word, coarse bits (render.hip)
-		const size_t words = (fine + 63u) / 64u + 1u + (fine / 64u + 63u) / 64u;
+		const size_t words = (fine + 63u) / 64u + 1u + (fine / 64u + 63u) / 64u + 3u; // (+ the six words of the live box)
 		if (words != h->r_occ_words)
 		{
+			h->r_occ_key[0] = 0;
 			if (h->r_occ) HIP_TRY(hipFree(h->r_occ));
 			h->r_occ = nullptr;
 			h->r_occ_words = 0;
@@ -1663,6 +1671,9 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 			h->r_occ_words = words;
 		}
 		l.occ = h->r_occ;
+		const uint64_t key[3] = {h->state_serial, h->step, (uint64_t)(uintptr_t)l.cells};
+		l.occ_valid = !memcmp(key, h->r_occ_key, sizeof key);
+		memcpy(h->r_occ_key, key, sizeof key);
 	}
 	l.mode = h->render_mode;
 	l.sched = h->render_sched;
@@ -1715,8 +1726,12 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 			h->r_bricks_bytes = 0;
 			HIP_TRY(hipMalloc((void **)&h->r_bricks, need));
 			h->r_bricks_bytes = need;
+			h->r_bricks_key[0] = 0;
 		}
 		l.bricks = h->r_bricks;
+		const uint64_t key[3] = {h->state_serial, h->step, (uint64_t)(uintptr_t)l.cells};
+		l.bricks_valid = !memcmp(key, h->r_bricks_key, sizeof key);
+		memcpy(h->r_bricks_key, key, sizeof key);
 	}
 	HIP_TRY(hipEventRecord(h->rev_start, h->stream));
 	hipError_t e = launch_render(l, h->stream);
@@ -2009,6 +2024,7 @@ int engine_mark_state(ca3d_engine *h)
 	h->cur = 0;
 	h->has_state = true;
 	h->binary_state = true;
+	h->state_serial++;
 	return CA3D_OK;
 }
 void engine_set_ghosts_valid(ca3d_engine *h, bool valid) { h->ghosts_valid = valid; }

@@ -1006,13 +1006,19 @@ hipError_t launch_render(const RenderLaunch &l, hipStream_t stream)
 		const u32 nblocks = P.cols * (l.G >> 3) * (l.G >> 3);
 		P.occ_words = (nblocks + 63u) / 64u;
 		P.occ_coarse = l.G % 128u == 0 ? 1u : 0u;
-		hipError_t e = hipMemsetAsync(l.occ + P.occ_words, 0, sizeof(unsigned long long), stream);
-		if (e != hipSuccess) return e;
-		u32 *box = l.counters ? reinterpret_cast<u32 *>(l.counters + 4) : nullptr; // three of the counter words the per-frame memset clears
-		hipLaunchKernelGGL(ca_occupancy, dim3((nblocks + 255u) / 256u), dim3(256), 0, stream, l.cells, l.occ, l.G, P.cols, nblocks, P.occ_words, box);
+		// the box of the occupied blocks: six words behind the coarse bits (kept with the bits: l.occ_valid)
+		const size_t coarse_words = (nblocks / 64u + 63u) / 64u;
+		u32 *box = reinterpret_cast<u32 *>(l.occ + P.occ_words + 1u + coarse_words);
+		if (!l.occ_valid) // the engine says the bits are those of this very state (a frame of the same state was drawn before)
+		{
+			hipError_t e = hipMemsetAsync(l.occ + P.occ_words, 0, sizeof(unsigned long long), stream);
+			if (e == hipSuccess) e = hipMemsetAsync(box, 0, 6u * sizeof(u32), stream);
+			if (e != hipSuccess) return e;
+			hipLaunchKernelGGL(ca_occupancy, dim3((nblocks + 255u) / 256u), dim3(256), 0, stream, l.cells, l.occ, l.G, P.cols, nblocks, P.occ_words, box);
+			if (P.occ_coarse)
+				hipLaunchKernelGGL(ca_occupancy_coarse, dim3((nblocks / 64u + 255u) / 256u), dim3(256), 0, stream, l.occ, l.G, P.cols, nblocks / 64u, P.occ_words);
+		}
 		P.live_box = box;
-		if (P.occ_coarse)
-			hipLaunchKernelGGL(ca_occupancy_coarse, dim3((nblocks / 64u + 255u) / 256u), dim3(256), 0, stream, l.occ, l.G, P.cols, nblocks / 64u, P.occ_words);
 		P.occ = l.occ;
 	}
 	P.row0 = l.row0;
@@ -1027,7 +1033,7 @@ hipError_t launch_render(const RenderLaunch &l, hipStream_t stream)
 		F.prev_depth = l.prev_depth;
 		if (l.bricks && frame_bricks_applies(l.G))
 		{
-			hipError_t e = launch_render_frame_bricks(&F, l.bricks, stream);
+			hipError_t e = launch_render_frame_bricks(&F, l.bricks, l.bricks_valid, stream);
 			if (e != hipSuccess) return e;
 		}
 		else hipLaunchKernelGGL(ca_render_frame_packed, grid, dim3(256), 0, stream, F);
@@ -1063,7 +1069,7 @@ hipError_t launch_render(const RenderLaunch &l, hipStream_t stream)
 			const bool streamed = l.stream_scratch && !P.legacy && !P.trace;
 			if (streamed)
 			{
-				hipError_t e = launch_render_stream(&P, l.stream_scratch, l.W, l.H, l.stream_check, l.bricks, stream);
+				hipError_t e = launch_render_stream(&P, l.stream_scratch, l.W, l.H, l.stream_check, l.bricks, l.bricks_valid, stream);
 				if (e != hipSuccess) return e;
 			}
 			if (one)

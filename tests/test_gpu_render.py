@@ -182,6 +182,60 @@ def test_light_gizmo_and_empty_volume(eng):
     assert eng.render_stats().shadow_rays == 0
 
 
+def test_derived_buffers_follow_the_state(eng):
+    """The occupancy bits and the bricked copy of the volume are rebuilt only when the state has changed since the frame before
+    (step count, uploads, buffers handed out): frames of a changing state must never show the old one — dense and sparse scenes, both
+    frame modes, a same-sized second upload, stepping between frames."""
+    G, W, H = 64, 160, 90
+    u = host.uniform_block(W, H, host.orbit_camera())
+    eng.configure(G)
+    set_rules(eng, rules("default"))
+    a = host.random_fill(host.words_per_buffer(G), seed=31, and_rounds=3)
+    b = host.random_fill(host.words_per_buffer(G), seed=32, and_rounds=3)
+    sparse = host.initial_state(G)
+
+    def frame(mode):
+        eng.set_render_mode(mode)
+        try:
+            if mode:
+                eng.reset_render_history()
+            return [x.copy() for x in eng.render(u, W, H, 1)]
+        finally:
+            eng.set_render_mode(False)
+
+    def fresh(state, steps, mode):
+        from cellularautomatons3d_amd import Engine
+
+        with Engine(0) as e2:
+            e2.configure(G)
+            set_rules(e2, rules("default"))
+            e2.upload_state(state)
+            if steps:
+                e2.step(steps)
+            e2.set_render_mode(mode)
+            if mode:
+                e2.reset_render_history()
+            return [x.copy() for x in e2.render(u, W, H, 1)]
+
+    for mode in (False, True):
+        eng.upload_state(a)
+        f1 = frame(mode)
+        f1b = frame(mode)  # same state again: the cached buffers
+        for x, y in zip(f1, f1b):
+            np.testing.assert_array_equal(x.view(np.uint8), y.view(np.uint8))
+        eng.upload_state(b)  # same size, same step count, same buffers: only the serial tells
+        for x, y in zip(frame(mode), fresh(b, 0, mode)):
+            np.testing.assert_array_equal(x.view(np.uint8), y.view(np.uint8))
+        eng.step(2)
+        for x, y in zip(frame(mode), fresh(b, 2, mode)):
+            np.testing.assert_array_equal(x.view(np.uint8), y.view(np.uint8))
+        eng.upload_state(sparse)  # dense -> sparse: the other set of kernels, the live box
+        eng.step(3)
+        for x, y in zip(frame(mode), fresh(sparse, 3, mode)):
+            np.testing.assert_array_equal(x.view(np.uint8), y.view(np.uint8))
+        assert not np.array_equal(f1[0], fresh(b, 0, mode)[0])
+
+
 def test_render_follows_step_parity(eng):
     # the render pass binds buffer [step % 2] (main_pathtraced.js:1788)
     G, W, H = 64, 96, 54

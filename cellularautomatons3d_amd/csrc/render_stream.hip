@@ -150,7 +150,7 @@ struct Walker
 	float tx, ty, tz, dx, dy, dz, t, tmax;
 	int ix, iy, iz, sx, sy, sz;
 	int wkey;
-	u32 word, word_hi; // (word_hi: rows 4 .. 7 of the slice, kBricks64)
+	u32 word;
 	float eps_b; // constant term of the filter's error bound (below); +inf: always ask the slab test
 };
 
@@ -160,18 +160,18 @@ struct Walker
 // 32 KiB plane: the 64 lanes of a wave, a few cells apart, read as many cache lines as there are lanes, and the kernels measured bound
 // by exactly that — the vector L1 taking a line per cycle (137 M accesses in 0.96 M cycles per CU x 256 CUs), insensitive to the waves
 // per SIMD (4 or 8) and to ten fewer instructions per cell. In bricks seven of eight steps along any axis stay inside the 64 bytes.
-// kBricks64: the walker keeps a brick's whole z-slice (8 x 8 cells, the brick's words 2 (z & 7) and 2 (z & 7) + 1: one aligned 8-byte
-// read) in two registers: only a step in z, or out of the brick in x or y, reads again.
-enum { kRowsP2 = 0, kRowsAny = 1, kBricks = 2, kBricks64 = 3 };
+// kBricksRead: bricks, and the walker reads its cell's word at every cell instead of keeping the last word in a register (no key to
+// compare, no branch around the read; the default). Measured on top of each other (1080p / 4K, 4 samples, ms per frame): rows 0.88 /
+// 2.32, bricks 0.80 / 1.98, bricks + a read per cell 0.785 / 1.94; a whole 8 x 8 z-slice per lane in two registers 0.805 / 2.11.
+enum { kRowsP2 = 0, kRowsAny = 1, kBricks = 2, kBricksRead = 3 };
 
 template <int LAYOUT>
 __device__ __forceinline__ int word_key(const StreamParams &S, int ix, int iy, int iz)
 {
-	if (LAYOUT == kBricks || LAYOUT == kBricks64)
+	if (LAYOUT == kBricks || LAYOUT == kBricksRead)
 	{
 		const u32 lnb = S.lg - 3u;
 		const u32 b = (((((u32)iz >> 3) << lnb) + ((u32)iy >> 3)) << lnb) + ((u32)ix >> 3);
-		if (LAYOUT == kBricks64) return (int)((b << 3) + ((u32)iz & 7u)); // index of the 8-byte slice
 		return (int)((b << 4) + (((u32)iz & 7u) << 1) + (((u32)iy & 7u) >> 2));
 	}
 	if (LAYOUT == kRowsP2) return (int)(((((u32)iz << S.lg) + (u32)iy) << S.lc) + ((u32)ix >> 5));
@@ -180,7 +180,7 @@ __device__ __forceinline__ int word_key(const StreamParams &S, int ix, int iy, i
 template <int LAYOUT>
 __device__ __forceinline__ u32 word_bit(int ix, int iy)
 {
-	return (LAYOUT == kBricks || LAYOUT == kBricks64) ? (((u32)ix & 7u) | (((u32)iy & 3u) << 3)) : ((u32)ix & 31u);
+	return (LAYOUT == kBricks || LAYOUT == kBricksRead) ? (((u32)ix & 7u) | (((u32)iy & 3u) << 3)) : ((u32)ix & 31u);
 }
 
 // walk_begin of render.hip / the head of walk(): first cell, boundary times, increments
@@ -243,15 +243,7 @@ __device__ __forceinline__ int walk_cell(const StreamParams &S, Walker &w, int k
 	const RenderParams &P = S.R;
 	// (a 32-bit byte offset from the scalar base: one shift instead of a sign extension and a 64-bit add per visit)
 	u32 cur;
-	if (LAYOUT == kBricks64)
-	{
-		if (LOAD && key != w.wkey)
-		{
-			const uint2 v = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(S.volume) + ((u32)key << 3));
-			w.word = v.x; w.word_hi = v.y; w.wkey = key;
-		}
-		cur = (w.iy & 4) ? w.word_hi : w.word;
-	}
+	if (LAYOUT == kBricksRead) cur = *reinterpret_cast<const u32 *>(reinterpret_cast<const char *>(S.volume) + ((u32)key << 2));
 	else
 	{
 		if (LOAD && key != w.wkey) { w.word = *reinterpret_cast<const u32 *>(reinterpret_cast<const char *>(S.volume) + ((u32)key << 2)); w.wkey = key; }
@@ -821,7 +813,7 @@ hipError_t launch_render_stream(const void *params, void *scratch, uint32_t W, u
 	if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
 	const u32 wgs = min(S.chunks, (u32)cus * (u32)kStreamWaves * 4u / (u32)kWalkWaves); // persistent: what the chip holds at kStreamWaves per SIMD
 	const u32 job_blocks = (S.chunks * per + 255u) / 256u;
-	static const int bricks_env = getenv("CA3D_STREAM_BRICKS") ? atoi(getenv("CA3D_STREAM_BRICKS")) : 1;
+	static const int bricks_env = getenv("CA3D_STREAM_BRICKS") ? atoi(getenv("CA3D_STREAM_BRICKS")) : 1; // tuning: 0 rows, 1 default, 2 bricks with a cached word, 3 batched loop
 	const bool bricked = bricks && bricks_env && frame_bricks_applies(P.G);
 	S.volume = bricked ? bricks : P.cells;
 	if (bricked)
@@ -833,8 +825,8 @@ hipError_t launch_render_stream(const void *params, void *scratch, uint32_t W, u
 		}
 		if (bricks_env == 3) { if (check) launch_walks<kBricks, true, true>(S, wgs, job_blocks, stream); else launch_walks<kBricks, false, true>(S, wgs, job_blocks, stream); }
 		else if (bricks_env == 2) { if (check) launch_walks<kBricks, true>(S, wgs, job_blocks, stream); else launch_walks<kBricks, false>(S, wgs, job_blocks, stream); }
-		else if (check) launch_walks<kBricks64, true>(S, wgs, job_blocks, stream);
-		else launch_walks<kBricks64, false>(S, wgs, job_blocks, stream);
+		else if (check) launch_walks<kBricksRead, true>(S, wgs, job_blocks, stream);
+		else launch_walks<kBricksRead, false>(S, wgs, job_blocks, stream);
 	}
 	else if (p2) { if (check) launch_walks<kRowsP2, true>(S, wgs, job_blocks, stream); else launch_walks<kRowsP2, false>(S, wgs, job_blocks, stream); }
 	else { if (check) launch_walks<kRowsAny, true>(S, wgs, job_blocks, stream); else launch_walks<kRowsAny, false>(S, wgs, job_blocks, stream); }

@@ -290,7 +290,7 @@ int enqueue_step(ca3d_engine *h, int src, uint32_t lo, uint32_t hi, hipStream_t 
 	{
 		pr.lo2 = lo2;
 		pr.hi2 = hi2;
-		PackedLaunch l{h->buf[src], h->buf[src ^ 1], pr, &h->rules, h->variant, h->vn_jit.cvl >= 0 ? &h->vn_jit : nullptr, h->class_jit.main >= 0 ? &h->class_jit : nullptr, h->roll_jit.cvl >= 0 ? &h->roll_jit : nullptr, h->roll_z, h->roll_tile, h->rows_jit.main >= 0 ? &h->rows_jit : nullptr};
+		PackedLaunch l{h->buf[src], h->buf[src ^ 1], pr, &h->rules, h->variant, h->vn_jit.cvl >= 0 ? &h->vn_jit : nullptr, h->class_jit.main >= 0 ? &h->class_jit : nullptr, (h->roll_jit.cvl >= 0 || h->roll_jit.cv_np2 > 0) ? &h->roll_jit : nullptr, h->roll_z, h->roll_tile, h->rows_jit.main >= 0 ? &h->rows_jit : nullptr};
 		e = fused ? launch_packed_fused(l, s, &h->kernel_name) : launch_packed_step(l, s, &h->kernel_name);
 	}
 	else
@@ -351,6 +351,13 @@ void select_kernels(ca3d_engine *h)
 		}
 	}
 	if (!h->use_jit) return;
+	if (h->use_roll && roll_np2_applies(h->rules, h->G, h->variant))
+	{
+		// rows of 3, 5, 6 or 7 uint4 and a rule with diagonal neighbour classes: the rolling-window kernel's whole-rows-per-wave form
+		if (hipSetDevice(h->device) != hipSuccess) return;
+		RollJit rj;
+		if (jit_roll_np2_kernels(h->device, h->rules, (int)(h->G / 128u), &rj, &h->jit_log) == CA3D_OK) { h->roll_jit = rj; h->kernel_name = "ca_packed_roll_np2(jit)"; return; }
+	}
 	if (h->use_rows && rows_kernel_applies(h->rules, h->G, h->variant))
 	{
 		// grids without a uint4 kernel that has the rule compiled in (not a power of two, or rows that are not whole uint4)
@@ -1519,6 +1526,7 @@ int ca3d_get_info(ca3d_t *h, ca3d_info *out)
 		else if (h->res_ready && h->use_resident && !h->res_failed && h->res_class) name = "ca_resident_class(jit)";
 		else if (h->res_ready && h->use_resident && !h->res_failed) name = h->res_jit_fn ? "ca_resident_vn(jit)" : "ca_resident_vn";
 		else if (h->slab && h->res_slab_fn && h->use_resident && !h->res_failed) name = "ca_resident_slab_vn(jit)";
+		else if (h->roll_jit.cv_np2 > 0) name = "ca_packed_roll_np2(jit)";
 		else if (h->rows_jit.main >= 0) name = "ca_packed_rows(jit)";
 		else name = h->vn_jit.cvl >= 0 ? "ca_packed_vn(jit)" : packed_kernel_name(h->rules, h->G, h->variant);
 	}

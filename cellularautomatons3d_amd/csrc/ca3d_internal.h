@@ -85,6 +85,8 @@ struct RollJit
 	void *loop[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; // looped forms [tile][Z = 15, 30]: the plane loop rolled up in groups of three
 	void *w2[2] = {nullptr, nullptr};    // two words per thread (five waves per SIMD) for Z = 8, 16; null on rows of 32 uint4 and more
 	void *wtile[2] = {nullptr, nullptr}; // wave tiles (one wave per workgroup, LDS exchange without a barrier) for Z = 8, 16; null on rows of 64 uint4
+	void *np2[3] = {nullptr, nullptr, nullptr}; // roll_step_np2 for Z = 2, 4, 8: the module of a grid with cv_np2 uint4 per row (not a power of two)
+	int cv_np2 = 0;                            // uint4 per row of the np2 module; 0: none
 	int cvl = -1;                              // log2(G / 128); -1: none
 	int main = -1;
 	bool e = false, c = false;
@@ -208,6 +210,9 @@ int jit_rows_kernels(int device, const CanonRules &r, uint32_t G, RowsJit *out, 
 // Whether the rows kernel is the one to use for these rules on this grid: named classes, and no uint4 kernel with the rule compiled in
 bool rows_kernel_applies(const CanonRules &r, uint32_t G, int variant);
 int jit_roll_kernels(int device, const CanonRules &r, int cvl, RollJit *out, std::string *log);
+// ... for a grid of `cv` uint4 per row, cv not a power of two (384, 640, 768, 896): out->np2, out->cv_np2
+int jit_roll_np2_kernels(int device, const CanonRules &r, int cv, RollJit *out, std::string *log);
+bool roll_np2_applies(const CanonRules &r, uint32_t G, int variant);
 // Whether the rolling-window kernel is the one to use for these rules on this grid (diagonal neighbour classes in
 // play, power-of-two grid of 256 and up)
 bool roll_kernel_applies(const CanonRules &r, uint32_t G, int variant);

@@ -501,6 +501,20 @@ bool roll_kernel_applies(const CanonRules &r, uint32_t G, int variant)
 	return diagonals_or_z;
 }
 
+// Rows of whole uint4, not a power of two of them (384, 640, 768, 896), and a rule whose counts reach into the planes above and
+// below (every rule but the 2D neighbourhoods): the rolling-window kernel's whole-rows-per-wave form (ca_packed_roll_kernel.inc,
+// roll_step_np2). Measured against the kernels these grids had (us per step, MI355X, profiles/r4_zz_roll_np2.txt): clustered
+// 384 8.69 -> 8.88, 640 29.6 -> 26.4, 768 51.4 -> 39.6, 896 69.0 -> 53.7; start-up rule 5.43 -> 4.66, 11.9 -> 11.4, 20.5 -> 18.0,
+// 32.6 -> 27.0. CA3D_ROLL_NP2 = 0 keeps the earlier kernels (rows / class np2; tuning).
+bool roll_np2_applies(const CanonRules &r, uint32_t G, int variant)
+{
+	static const int env = getenv("CA3D_ROLL_NP2") ? atoi(getenv("CA3D_ROLL_NP2")) : 1;
+	if (!env || variant == 1 || !r.fast || G % 128u) return false;
+	const uint32_t cv = G / 128u;
+	if ((cv & (cv - 1u)) == 0 || cv < 3u || cv > 7u) return false;
+	return r.need[1] || r.need[2] || r.main == MAIN_MOORE || r.main == MAIN_EDGES || r.main == MAIN_CORNERS || r.main == MAIN_VN;
+}
+
 int class_zrun(const CanonRules &r)
 {
 	const bool diagonals = r.need[1] || r.need[2] || r.main == MAIN_MOORE || r.main == MAIN_EDGES || r.main == MAIN_CORNERS;
@@ -581,6 +595,31 @@ hipError_t launch_packed_step(const PackedLaunch &l, hipStream_t stream, const c
 		return launch_packed_step(only, stream, nullptr);
 	}
 	if (vn_kernel_applies(r, l.pr.G, l.variant)) return launch_packed_vn(l, stream);
+	if (const RollJit *rj = l.roll_jit; rj && rj->cv_np2 > 0 && (u32)rj->cv_np2 * 128u == l.pr.G && rj->main == (int)r.main && rj->e == r.need[1] && rj->c == r.need[2])
+	{
+		// rows of 3 / 5 / 6 / 7 uint4: the rolling-window kernel with whole rows per wave (roll_step_np2). Z = the deepest of 8 / 4 / 2 planes
+		// per thread that the shortest range holds and that still leaves two waves for every SIMD; ranges shorter than two planes
+		// (a slab's edge phase) fall through to the kernels below.
+		const bool two = l.pr.hi2 > l.pr.lo2;
+		const u32 G = l.pr.G, CV = G / 128u, R = 64u / CV, bpp = ((G + R - 1u) / R + 3u) / 4u;
+		const u32 planes1 = l.pr.hi - l.pr.lo, planes2 = two ? l.pr.hi2 - l.pr.lo2 : 0u;
+		const u32 shortest = two ? (planes1 < planes2 ? planes1 : planes2) : planes1;
+		for (int zi = 2; zi >= 0; zi--)
+		{
+			const u32 Z = 2u << zi;
+			if (shortest < Z || !rj->np2[zi]) continue;
+			const u32 runs1 = (planes1 + Z - 1u) / Z, nruns = runs1 + (planes2 + Z - 1u) / Z;
+			if (l.roll_z ? l.roll_z != (int)Z : (zi > 0 && (size_t)bpp * nruns < 512u)) continue; // option roll_z forces a depth (tests, tuning)
+			RollArgs a;
+			a.lo = l.pr.lo; a.hi = l.pr.hi; a.nplanes = l.pr.nplanes; a.wrap_full = l.pr.wrap_full; a.zbase = l.pr.zbase;
+			a.lo2 = l.pr.lo2; a.hi2 = two ? l.pr.hi2 : l.pr.lo2; a.runs1 = runs1;
+			const u32 *in = l.in;
+			u32 *out = l.out;
+			void *args[] = {(void *)&in, (void *)&out, (void *)&a};
+			if (kernel_name) *kernel_name = "ca_packed_roll_np2(jit)";
+			return hipModuleLaunchKernel((hipFunction_t)rj->np2[zi], bpp * nruns, 1, 1, 256, 1, 1, 0, stream, args, nullptr);
+		}
+	}
 	if (const RowsJit *rj = l.rows_jit; rj && rj->G == l.pr.G && rj->main == (int)r.main && rj->e == r.need[1] && rj->c == r.need[2] && rj->deep && rj->flat)
 	{
 		const bool two = l.pr.hi2 > l.pr.lo2;

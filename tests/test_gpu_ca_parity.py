@@ -111,11 +111,18 @@ def test_rows_kernel_on_grids_that_are_not_powers_of_two(eng, G, name):
     r = rules(name)
     eng.configure(G)
     set_rules(eng, r)
-    # rows of whole uint4 (G % 128 == 0) keep the class kernel — its run-time compiled non-power-of-two form — for face-only rules on
-    # the larger grids (measured faster there: ca_packed.hip, rows_kernel_applies); everything else is the rows kernel
-    face_only = name in ("default", "vn2d", "vn_b24_s135", "life2d")  # (no rows of the planes above / below: two planes per thread)
-    want_rows = G % 128 != 0 or G < 768 or not face_only
-    assert (eng.info().kernel_name == b"ca_packed_rows(jit)") == want_rows and b"(jit)" in eng.info().kernel_name
+    # rows of whole uint4 that are not a power of two of them (384, 768): every 3D rule takes the rolling-window kernel's
+    # whole-rows-per-wave form (roll_step_np2); the 2D rules keep the class kernel's run-time compiled np2 form on the larger grids
+    # (measured faster there: ca_packed.hip, rows_kernel_applies) and the rows kernel on the smaller; every other grid: rows
+    flat = name in ("vn2d", "life2d")  # counts from the cell's own plane only: nothing to gain from a window along z
+    if G % 128 == 0 and not flat:
+        want = b"ca_packed_roll_np2(jit)"
+    elif G % 128 != 0 or G < 768:
+        want = b"ca_packed_rows(jit)"
+    else:
+        want = None  # the class kernel, run-time compiled
+    name_now = eng.info().kernel_name
+    assert (name_now == want if want else (b"class" in name_now and b"(jit)" in name_now)), name_now
     for rounds in (0, 4):
         st = host.random_fill(host.words_per_buffer(G), seed=0xCA3D0001 + G, and_rounds=rounds)
         eng.upload_state(st)
@@ -125,14 +132,36 @@ def test_rows_kernel_on_grids_that_are_not_powers_of_two(eng, G, name):
         eng.step(5)  # batches of more than one step: z-runs of several planes, graph replay
         want6 = ol.packed_run(G, want1, r, 5)
         np.testing.assert_array_equal(eng.read_state(), want6)
-    eng.set_option("rows", 0)
+    # ... and the kernels that served these grids before: without the rolling form (rows / class np2), then without the rows kernel too
     try:
-        assert b"rows" not in eng.info().kernel_name
-        eng.upload_state(st)
-        eng.step(6)
-        np.testing.assert_array_equal(eng.read_state(), want6)
+        for off in ("roll", "rows"):
+            eng.set_option(off, 0)
+            assert b"roll_np2" not in eng.info().kernel_name and (off == "roll" or b"rows" not in eng.info().kernel_name)
+            eng.upload_state(st)
+            eng.step(6)
+            np.testing.assert_array_equal(eng.read_state(), want6, err_msg=eng.info().kernel_name.decode())
     finally:
+        eng.set_option("roll", 1)
         eng.set_option("rows", 1)
+
+
+@pytest.mark.parametrize("G,name,z", [(640, "clustered", 8), (640, "moore_wide", 4), (896, "clustered", 2), (384, "edges_main", 8), (384, "clustered", 4),
+                                      (896, "vn_corners_only", 0)])
+def test_roll_np2_kernel_plane_depths(eng, G, name, z):
+    """roll_step_np2 at every depth it is compiled for (option roll_z forces 2 / 4 / 8 planes per thread; 0: the launcher's choice), rows of
+    3, 5 and 7 uint4 (21, 12 and 9 whole rows per wave), three steps from a sparse state against the oracle."""
+    r = rules(name)
+    eng.configure(G)
+    set_rules(eng, r)
+    assert eng.info().kernel_name == b"ca_packed_roll_np2(jit)"
+    st = host.random_fill(host.words_per_buffer(G), seed=G + z, and_rounds=1)
+    eng.set_option("roll_z", z)
+    try:
+        eng.upload_state(st)
+        eng.step(3)
+        np.testing.assert_array_equal(eng.read_state(), ol.packed_run(G, st, r, 3, 16))
+    finally:
+        eng.set_option("roll_z", 0)
 
 
 @pytest.mark.parametrize("name", ["default", "clustered"])

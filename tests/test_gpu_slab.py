@@ -108,10 +108,12 @@ def test_packed_slabs_equal_full_grid(P, K, steps, name):
 
 
 @pytest.mark.parametrize("G,P,K,steps,name", [(128, 2, 4, 9, "default"), (128, 4, 3, 7, "clustered"), (128, 8, 2, 5, "default"),
-                                                (128, 4, 8, 17, "default"), (512, 4, 6, 13, "default"), (512, 8, 16, 33, "vn_b24_s135")])
+                                                (128, 4, 8, 17, "default"), (512, 4, 6, 13, "default"), (512, 8, 16, 33, "vn_b24_s135"),
+                                                (384, 4, 3, 7, "clustered"), (384, 2, 4, 9, "default"), (640, 4, 5, 6, "edges_main")])
 def test_packed_slabs_overlapped_schedule(G, P, K, steps, name):
     """Edge phase -> exchange concurrent with the interior phase: equals the full grid (the (128, 4, 8) case is too
-    thin to split: the edge phase then runs whole batches)."""
+    thin to split: the edge phase then runs whole batches). The 384 / 640 cases: slabs of a grid whose rows are 3 / 5 uint4 (the
+    rolling-window kernel's whole-rows-per-wave form on plane ranges with a z offset, two ranges per launch, no wrap)."""
     r = rules(name)
     full = host.random_fill(host.words_per_buffer(G), seed=77)
     got = _run_slabs_overlapped(G, P, K, steps, r, LAYOUT_PACKED32, full)

@@ -188,6 +188,21 @@ def test_roll_kernel_source_compiles_with_hiprtc(cvl, main, e, c, tables):
     assert b"ca3d_jit_roll_z2" in code and b"ca3d_jit_roll_z4" in code and b"ca3d_jit_roll_z8" in code
 
 
+@pytest.mark.parametrize("cv,main,e,c,tables", [
+    (5, 2, "true", "true", (0x000000F0, 0x000000E0, 0x0038, 0x0010, 0x0014, 0x0008)),   # 640^3, the clustered rule's shape
+    (3, 4, "false", "true", (0x0350, 0x0244, 0, 0, 0x0002, 0x0000)),                     # 384^3, edges main + corners set
+    (7, 0, "false", "false", (0x002A, 0x0014, 0, 0, 0, 0)),                              # 896^3, a von Neumann rule
+])
+def test_roll_np2_kernel_source_compiles_with_hiprtc(cv, main, e, c, tables):
+    """The rolling-window kernel for rows of 3 / 5 / 6 / 7 uint4 (roll_step_np2): its own module, its own three entry points."""
+    rtc = _hiprtc()
+    defines = [b"-DCA3D_JIT_CV_NP2=%d" % cv, b"-DCA3D_JIT_MAIN=%d" % main, b"-DCA3D_JIT_E=" + e.encode(), b"-DCA3D_JIT_C=" + c.encode()]
+    defines += [b"-DCA3D_JIT_%s=%du" % (n, t) for n, t in zip([b"TS0", b"TB0", b"TS1", b"TB1", b"TS2", b"TB2"], tables)]
+    code = _compile(rtc, ROLL_PROGRAM, b"ca3d_jit_roll_np2.hip", defines, *([CLUSTERED_RULE_FN] if main == 2 and e == "true" else []))
+    assert b"ca3d_jit_roll_np2_z2" in code and b"ca3d_jit_roll_np2_z4" in code and b"ca3d_jit_roll_np2_z8" in code
+    assert b"ca3d_jit_roll_z8" not in code
+
+
 def test_resident_kernel_source_compiles_with_hiprtc():
     code = _compile(_hiprtc(), RESIDENT_PROGRAM, b"ca3d_jit_resident.hip", [b"-DCA3D_JIT_LS=%d" % 0x2A, b"-DCA3D_JIT_LB=%d" % 0x14])
     assert b"ca3d_jit_resident" in code

@@ -69,7 +69,8 @@ def parse(argv=None):
     ap.add_argument("--grid", type=int, default=0, help="grid edge (overrides the configuration's)")
     ap.add_argument("--rule", choices=sorted(RULES), default="", help="rule-set (overrides the configuration's)")
     ap.add_argument("--density-rounds", type=int, default=0, help="AND rounds of the hashed fill: density 2^-(1+r)")
-    ap.add_argument("--ghost", type=int, default=32, help="ghost planes per side = steps between halo exchanges (N>1)")
+    ap.add_argument("--ghost", type=int, default=0, help="ghost planes per side = steps between halo exchanges (N>1); 0: 32, or the deepest of 32 / 16 / 8 "
+                    "with which a rank's share of a 1024^3 default-rule grid still runs the resident slab kernel (8 ranks: 32; 4 ranks: 16)")
     ap.add_argument("--min-seconds", type=float, default=MIN_TIMED_SECONDS, help="repeat the batch until this much is timed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -117,11 +118,26 @@ def parse(argv=None):
     a.overlap = a.overlap or cfg.get("overlap", "auto")
     if a.config == 5 and a.gpus > 1:
         a.multi_render = True
+    if a.ghost <= 0:
+        a.ghost = auto_ghost(a.grid, a.rule, a.gpus)
     if a.verify_steps < 0:
         # N = 1: warm-up + 40 steps through the headline path (one queued submission: the resident kernel where there is one) on grids
         # the oracle steps in about a second; N > 1: past one halo exchange
         a.verify_steps = (a.ghost + 8 if a.grid <= 1024 else 0) if a.gpus > 1 else (a.warmup + 40 if a.grid <= 512 else 0)
     return a
+
+
+def auto_ghost(grid: int, rule: str, world: int) -> int:
+    """Ghost depth K (planes per side = steps between exchanges) when none is asked for: 32 — the exchange costs a fixed ~45 us of
+    launch latency on the GPU, DESIGN.md section 6 — unless a shallower one lets the rank's share run the resident slab kernel
+    (ca_resident.hip, resident_slab_planes: 1024^3, a von Neumann table pair, 8 tile layers of an even number of planes <= 36):
+    a quarter of 1024^3 is 256 + 2 K planes, resident with K = 16 (8.3 against 12.5 us per step in loopback), not with K = 32."""
+    if world > 1 and grid == 1024 and rule in ("default", "vn_b24_s135") and grid % world == 0:
+        for k in (32, 16, 8):
+            planes = grid // world + 2 * k
+            if planes % 8 == 0 and (planes // 8) % 2 == 0 and planes // 8 <= 36:
+                return k
+    return 32
 
 
 def spawn_ranks(a) -> int:

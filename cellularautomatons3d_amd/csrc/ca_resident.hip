@@ -107,8 +107,10 @@ int resident_slab_planes(const CanonRules &r, uint32_t G, uint32_t nplanes, int 
 {
 	if (G != 1024u || !vn_kernel_applies(r, G, variant) || nplanes % (uint32_t)kSlabTZ) return 0;
 	const uint32_t pz = nplanes / (uint32_t)kSlabTZ;
-	// even (the face pass runs whole waves), at most 24 planes (128 VGPRs at 1024 threads per workgroup)
-	return pz >= 4u && pz <= 24u && pz % 2u == 0 ? (int)pz : 0;
+	// even (the face pass runs whole waves); up to 24 planes a thread holds the rows either side of its own for every plane (128 VGPRs
+	// at 1024 threads per workgroup), up to 36 — a share of a quarter of the grid with ghosts up to 16 planes deep; the one LDS image
+	// of 34 rows x 36 planes is 153 of the CU's 160 KB — it reads them four planes at a time inside the pass (kLate)
+	return pz >= 4u && pz <= (uint32_t)kSlabMaxPZ && pz % 2u == 0 ? (int)pz : 0;
 }
 
 namespace

@@ -4,7 +4,7 @@
 // grid, default rule, and 1080p / 4 spp frames, driven through ca3d.js -> ca3d_napi.node -> libca3d.so. Prints one
 // JSON line; bench.py (the driver's contract) measures the same kernels from Python.
 //   node cellularautomatons3d_amd/js/bench.js [--grid 512] [--steps 2048] [--reps 10] [--warmup 256] [--frames 10 --uniforms u.f32]
-//   node cellularautomatons3d_amd/js/bench.js --gpus 8 [--grid 1024] [--ghost 32] [--transport copy|rccl] [--check 40]
+//   node cellularautomatons3d_amd/js/bench.js --gpus 8 [--grid 1024] [--ghost K] [--transport copy|rccl] [--check 40]
 //       the Z-slab split over the GPUs of a node (BASELINE configs[3]) driven by this ONE thread through EngineGroup
 //       (ca3d_group_*); --devices 0,0,0,0 places several slabs on one GPU (rehearsal); --check n first verifies n steps
 //       against the JS CPU stepper on a 128-plane-deep sample of rank boundaries (small grids: the whole grid)
@@ -26,7 +26,16 @@ if (gpus > 1 || devicesArg) { runGroup(); return; }
 function runGroup()
 {
 	const devices = devicesArg ? devicesArg.split(",").map(Number) : Array.from({ length: gpus }, (_, i) => i);
-	const Gm = arg("grid", 1024), ghost = arg("ghost", 32), stepsM = arg("steps", 2048), warm = arg("warmup", 256), repsM = arg("reps", 10);
+	const Gm = arg("grid", 1024), stepsM = arg("steps", 2048), warm = arg("warmup", 256), repsM = arg("reps", 10);
+	// ghost depth as bench.py's auto_ghost: 32, or the deepest of 32 / 16 / 8 that keeps a rank's share of 1024^3 on the resident slab kernel
+	// (8 tile layers of an even number of planes <= 36: four slabs -> 16)
+	let ghost = arg("ghost", 0);
+	if (ghost <= 0)
+	{
+		ghost = 32;
+		if (Gm === 1024 && Gm % devices.length === 0)
+			for (const k of [32, 16, 8]) { const pl = Gm / devices.length + 2 * k; if (pl % 16 === 0 && pl / 8 <= 36) { ghost = k; break; } }
+	}
 	const transport = sarg("transport") === "rccl" ? 1 : 0, check = arg("check", 0);
 	const grp = new c.EngineGroup(devices);
 	grp.configure(Gm, ghost);

@@ -149,16 +149,18 @@ def test_packed_slabs_at_the_baseline_widths(G, P, K, steps, name, overlapped):
     assert np.array_equal(got, want)  # (assert_array_equal would format 1 GiB arrays on failure)
 
 
-@pytest.mark.parametrize("K,steps,name", [(16, 25, "default"), (32, 41, "vn_b24_s135")])
-def test_resident_slab_kernel(K, steps, name):
+@pytest.mark.parametrize("P,K,steps,name", [(8, 16, 25, "default"), (8, 32, 41, "vn_b24_s135"), (4, 16, 25, "default"), (4, 8, 19, "vn_b24_s135")])
+def test_resident_slab_kernel(P, K, steps, name):
     """The slab form of the resident kernel (ca_resident_kernel.inc): a rank's share of a 1024^3 grid — 128 owned planes
     + 2 K ghost planes — runs a batch of K sub-steps in ONE launch, tiles in registers. P = 8 engines on one GPU, ghosts
     moved by device copies after every batch (product halo plan); batches shorter than resident_min and the per-step
     kernels (option off) must give the same state; all against the oracle's full-grid run. Rank 7's high ghost holds the
-    copy of global plane 0 (dead plane below it, a run-time plane index inside a tile); rank 0's low ghost is never valid."""
+    copy of global plane 0 (dead plane below it, a run-time plane index inside a tile); rank 0's low ghost is never valid.
+    P = 4 (round 4): 256 + 2 K planes, 36 / 34 planes per tile layer — the form that reads the rows either side of a thread's own four
+    planes at a time inside its main pass."""
     from cellularautomatons3d_amd import Engine
 
-    G, P = 1024, 8
+    G = 1024
     r = rules(name)
     full = host.random_fill(host.words_per_buffer(G), seed=4242 + K)
     probe = Engine(0)
@@ -400,12 +402,12 @@ def test_bench_plain_invocation_spawns_its_ranks():
 
 
 @pytest.mark.parametrize("name,G,P,K,steps", [("default", 256, 4, 8, (8, 13, 3)), ("clustered", 256, 8, 4, (9, 4)), ("default", 1024, 8, 16, (33,)),
-                                              ("life2d", 128, 2, 5, (11,))])
+                                              ("default", 1024, 4, 16, (21,)), ("life2d", 128, 2, 5, (11,))])
 def test_engine_group_single_thread_split(name, G, P, K, steps):
     """`ca3d_group_*` (SURVEY 8(b)'s `ca3d_create(device_ids, n_devices, ...)`): ONE host thread drives P slab engines — here all on
     GPU 0, ghost planes as device copies ordered by events — through batches of <= K sub-steps; the full-grid state equals the
     oracle's after every call. 1024^3 over 8 slabs of 128 + 2 x 16 planes is BASELINE configs[3]'s split (the resident slab
-    kernel runs the batches)."""
+    kernel runs the batches); over 4 slabs of 256 + 2 x 16 planes it is the resident slab kernel's 36-planes-per-tile-layer form."""
     from cellularautomatons3d_amd import EngineGroup
 
     rr = rules(name)

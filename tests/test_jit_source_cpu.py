@@ -208,6 +208,30 @@ def test_resident_kernel_source_compiles_with_hiprtc():
     assert b"ca3d_jit_resident" in code
 
 
+@pytest.mark.parametrize("pz", [20, 24, 34, 36])
+def test_resident_slab_kernel_fits_its_registers_and_lds(pz):
+    """The slab form of the resident kernel for a rank's share of 1024^3 over eight (20 / 24 planes per tile layer) and over four
+    ranks (34 / 36: the form that reads the rows beside a thread's own inside its main pass). A launch is only resident as a whole at
+    four waves per SIMD (1024 threads per CU): no more than 128 registers, nothing spilled to scratch, the one LDS image inside
+    the CU's 160 KB — read from the code object's metadata."""
+    import re
+    import subprocess
+    code = _compile(_hiprtc(), RESIDENT_PROGRAM, b"ca3d_jit_resident_slab.hip", [b"-DCA3D_JIT_LS=255", b"-DCA3D_JIT_LB=10", b"-DCA3D_JIT_SLAB_PZ=%d" % pz])
+    readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not os.path.exists(readelf):
+        pytest.skip("llvm-readelf not in this image")
+    path = os.path.join(os.environ.get("TMPDIR", "/tmp"), "ca3d_slab_%d.co" % pz)
+    with open(path, "wb") as f:
+        f.write(code)
+    notes = subprocess.run([readelf, "--notes", path], capture_output=True, text=True, check=True).stdout
+    os.unlink(path)
+    blk = [b for b in notes.split(".agpr_count") if re.search(r"\.name:\s+ca3d_jit_resident_slab\b", b)]
+    assert len(blk) == 1
+    field = lambda name: int(re.search(r"\.%s:\s+(\d+)" % name, blk[0]).group(1))
+    assert field("vgpr_count") <= 128 and field("vgpr_spill_count") == 0 and field("private_segment_fixed_size") == 0
+    assert field("group_segment_fixed_size") <= 160 * 1024 and field("max_flat_workgroup_size") == 1024
+
+
 def test_resident_class_kernel_source_compiles_with_hiprtc():
     """Both tile geometries (512^3: 16 words x 32 planes, 256^3: 8 x 8) of the resident class kernel, for the clustered rule."""
     main, e, c, tables = 2, "true", "true", (0x000000F0, 0x000000E0, 0x0038, 0x0010, 0x0014, 0x0008)

@@ -126,6 +126,7 @@ struct ca3d_engine
 	uint64_t launches_total = 0;          // kernel launches the step calls issued since ca3d_create
 	bool res_deep = false;                // 256^3 von Neumann form: two steps per hand-off (option "resident_deep")
 	bool res_pair = true;                 // 512^3 von Neumann form: the row-pair kernel (option "resident_pair"; 2.48 against 2.52 us per step)
+	bool res_stagger = false;             // ... its staggered form: the two z groups of a tile half a step apart (option "resident_stagger"; 2.36 against 2.35: off)
 	uint32_t res_rows = 32;               // rows per tile of the von Neumann form (ca_resident_kernel.inc: 32 or 16)
 	uint32_t res_zsplit = 1;              // thread groups along z of the von Neumann form (option "resident_zsplit"; 2 = twice the threads, four waves per
 	                                      // SIMD: measured SLOWER with 32-row tiles — 2.61 vs 2.52 us per step at 512^3, 1.37 vs 1.26 at 256^3 — and faster
@@ -314,7 +315,7 @@ int enqueue_step(ca3d_engine *h, int src, uint32_t lo, uint32_t hi, hipStream_t 
 // creation). A failed compile leaves the ahead-of-time kernels in charge.
 // the 512^3 von Neumann form runs as the row-pair kernel (32-row tiles, one z group: its own geometry)
 bool vn_deep(const ca3d_engine *h) { return h->res_deep && h->G == 256u; }
-bool vn_pair(const ca3d_engine *h) { return h->res_pair && h->G == 512u && h->res_rows == 32u && h->res_zsplit == 1u; } // another geometry asked for: the general form
+int vn_pair(const ca3d_engine *h) { return h->res_pair && h->G == 512u && h->res_rows == 32u && h->res_zsplit == 1u ? (h->res_stagger ? 2 : 1) : 0; } // 2: the staggered form; // another geometry asked for: the general form
 
 void select_kernels(ca3d_engine *h)
 {
@@ -417,7 +418,7 @@ void check_residency(ca3d_engine *h)
 	if (h->res_ready)
 	{
 		const uint32_t rows = (h->res_class || h->G == 256u || vn_pair(h)) ? 32u : h->res_rows;
-		if (resident_capacity(h->G, rows, h->res_class ? resident_class_zsplit(h->G) : h->res_zsplit, !h->res_class && vn_pair(h), !h->res_class && vn_deep(h), h->res_jit_fn, h->stream, &tiles, &cap) && cap < tiles)
+		if (resident_capacity(h->G, rows, h->res_class ? resident_class_zsplit(h->G) : h->res_zsplit, h->res_class ? 0 : vn_pair(h), !h->res_class && vn_deep(h), h->res_jit_fn, h->stream, &tiles, &cap) && cap < tiles)
 		{
 			h->res_ready = false;
 			h->res_class = false;
@@ -685,7 +686,7 @@ int resident_steps(ca3d_engine *h, uint32_t n)
 	l.jit_fn = h->res_jit_fn;
 	l.rows = (h->res_class || vn_pair(h)) ? 32u : h->res_rows;
 	l.zsplit = h->res_class ? resident_class_zsplit(h->G) : h->res_zsplit;
-	l.pair = !h->res_class && vn_pair(h);
+	l.pair = h->res_class ? 0 : vn_pair(h);
 	l.deep = !h->res_class && vn_deep(h);
 	hipError_t e = launch_resident(l, h->stream);
 	if (e != hipSuccess) return fail(CA3D_ERR_DEVICE, "resident kernel launch failed: %s", hipGetErrorString(e));
@@ -1571,7 +1572,7 @@ int ca3d_get_kernel_variant(ca3d_t *h, char *buf, size_t n_bytes, size_t *needed
 	const bool res = !strncmp(info.kernel_name, "ca_resident", 11);
 	if (res)
 		snprintf(text, sizeof text, "%s;G=%u;rule=%016llx;rows=%u;zsplit=%u;pair=%d;deep=%d;rc256zs=%s;src=%016llx", info.kernel_name, h->G, (unsigned long long)rh,
-		         (h->res_class || vn_pair(h)) ? 32u : h->res_rows, h->res_class ? resident_class_zsplit(h->G) : h->res_zsplit, !h->res_class && vn_pair(h) ? 1 : 0,
+		         (h->res_class || vn_pair(h)) ? 32u : h->res_rows, h->res_class ? resident_class_zsplit(h->G) : h->res_zsplit, h->res_class ? 0 : vn_pair(h),
 		         !h->res_class && vn_deep(h) ? 1 : 0, zs ? zs : "-", (unsigned long long)jit_sources_hash());
 	else
 		snprintf(text, sizeof text, "%s;G=%u;rule=%016llx;variant=%d;src=%016llx", info.kernel_name, h->G, (unsigned long long)rh, h->variant, (unsigned long long)jit_sources_hash());
@@ -1953,6 +1954,21 @@ int ca3d_set_option(ca3d_t *h, const char *name, int64_t value)
 			HIP_TRY(hipStreamSynchronize(h->stream));
 			free_resident(h); // the tiling may change with it (32-row tiles): start from clean mailboxes
 			h->res_pair = value != 0;
+			refresh_kernels(h);
+			note_jit_failure(h);
+		}
+		return CA3D_OK;
+	}
+	if (!strcmp(name, "resident_stagger"))
+	{
+		if (value != 0 && value != 1) return fail(CA3D_ERR_INVALID_ARGUMENT, "resident_stagger must be 0 or 1");
+		if ((value != 0) != h->res_stagger)
+		{
+			int rc2 = bind_device(h);
+			if (rc2) return rc2;
+			HIP_TRY(hipStreamSynchronize(h->stream));
+			free_resident(h);
+			h->res_stagger = value != 0;
 			refresh_kernels(h);
 			note_jit_failure(h);
 		}

@@ -125,7 +125,7 @@ struct ResidentLaunch
 	uint32_t fault_tile = 0;       // diagnostics: tile + 1 that leaves at once (a workgroup that never became resident), 0: none
 	uint32_t zsplit = 1;           // thread groups along z: 2 = twice the threads per tile, four waves per SIMD (ca_resident_kernel.inc, ZS)
 	bool deep = false;             // 256^3 von Neumann form: two steps per hand-off (resident_deep_run); 256 threads per tile
-	bool pair = false;             // 512^3 von Neumann form: a thread owns two adjacent rows x 16 planes (resident_pair_run); rows = 32, zsplit = 1
+	int pair = 0;                  // 512^3 von Neumann form: a thread owns two adjacent rows x 16 planes; rows = 32, zsplit = 1. 1: resident_pair_run, 2: its staggered form (resident_stagger_run)
 };
 
 struct UnpackedLaunch
@@ -226,9 +226,9 @@ hipError_t launch_resident(const ResidentLaunch &l, hipStream_t stream);
 // Workgroups a resident launch of this shape needs (`tiles`) and how many of them the device can hold at once on `stream`
 // (occupancy of the kernel per CU x the CUs the stream may use): the launch only completes when capacity >= tiles.
 // Returns false when the runtime cannot tell (the caller then relies on the kernel's bounded waits alone).
-bool resident_capacity(uint32_t G, uint32_t rows, uint32_t zsplit, bool pair, bool deep, void *jit_fn, hipStream_t stream, uint32_t *tiles, uint32_t *capacity);
+bool resident_capacity(uint32_t G, uint32_t rows, uint32_t zsplit, int pair, bool deep, void *jit_fn, hipStream_t stream, uint32_t *tiles, uint32_t *capacity);
 bool resident_slab_capacity(void *fn, hipStream_t stream, uint32_t *tiles, uint32_t *capacity);
-int jit_resident_kernel(int device, uint32_t lut_s, uint32_t lut_b, uint32_t rows, uint32_t zsplit, bool pair, bool deep, void **fn, std::string *log);
+int jit_resident_kernel(int device, uint32_t lut_s, uint32_t lut_b, uint32_t rows, uint32_t zsplit, int pair, bool deep, void **fn, std::string *log);
 // the resident kernel for rules with diagonal neighbour classes (ca_resident_class_kernel.inc; 512^3 and 256^3, run-time compiled)
 bool resident_class_applies(const CanonRules &r, uint32_t G, int variant);
 int jit_resident_class_kernel(int device, const CanonRules &r, uint32_t G, uint32_t zsplit, void **fn, std::string *log); // G: 512 (zsplit 1) or 256 (2 | 1)

@@ -135,7 +135,7 @@ uint32_t usable_cus(hipStream_t stream)
 }
 } // namespace
 
-bool resident_capacity(uint32_t G, uint32_t rows, uint32_t zsplit, bool pair, bool deep, void *jit_fn, hipStream_t stream, uint32_t *tiles, uint32_t *capacity)
+bool resident_capacity(uint32_t G, uint32_t rows, uint32_t zsplit, int pair, bool deep, void *jit_fn, hipStream_t stream, uint32_t *tiles, uint32_t *capacity)
 {
 
 	if (pair) { rows = 32u; zsplit = 1u; } // the row-pair form: the tiles and the 512 threads of the 32-row form
@@ -147,7 +147,7 @@ bool resident_capacity(uint32_t G, uint32_t rows, uint32_t zsplit, bool pair, bo
 	hipError_t e;
 	if (jit_fn) e = hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (hipFunction_t)jit_fn, (int)threads, 0);
 	else if (deep) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, z2 ? (const void *)ca_resident_vn256_deep<kDefaultS, kDefaultB, 2> : (const void *)ca_resident_vn256_deep<kDefaultS, kDefaultB, 1>, (int)threads, 0);
-	else if (pair) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)ca_resident_vn_pair<kDefaultS, kDefaultB>, (int)threads, 0);
+	else if (pair) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pair == 2 ? (const void *)ca_resident_vn_stagger<kDefaultS, kDefaultB> : (const void *)ca_resident_vn_pair<kDefaultS, kDefaultB>, (int)threads, 0);
 	else if (G == 256u) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, z2 ? (const void *)ca_resident_vn256<kDefaultS, kDefaultB, 2> : (const void *)ca_resident_vn256<kDefaultS, kDefaultB, 1>, (int)threads, 0);
 	else if (rows == 16u) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, z2 ? (const void *)ca_resident_vn<kDefaultS, kDefaultB, 16, 2> : (const void *)ca_resident_vn<kDefaultS, kDefaultB, 16, 1>, (int)threads, 0);
 	else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, z2 ? (const void *)ca_resident_vn<kDefaultS, kDefaultB, 32, 2> : (const void *)ca_resident_vn<kDefaultS, kDefaultB, 32, 1>, (int)threads, 0);
@@ -242,7 +242,8 @@ hipError_t launch_resident(const ResidentLaunch &l, hipStream_t stream)
 		}
 		if (l.lut_s != (u32)kDefaultS || l.lut_b != (u32)kDefaultB) return hipErrorInvalidValue;
 		return chained_launch(stream, [&]() {
-			hipLaunchKernelGGL((ca_resident_vn_pair<kDefaultS, kDefaultB>), dim3(256), dim3(512), 0, stream, a);
+			if (l.pair == 2) hipLaunchKernelGGL((ca_resident_vn_stagger<kDefaultS, kDefaultB>), dim3(256), dim3(512), 0, stream, a);
+			else hipLaunchKernelGGL((ca_resident_vn_pair<kDefaultS, kDefaultB>), dim3(256), dim3(512), 0, stream, a);
 			return hipGetLastError();
 		});
 	}

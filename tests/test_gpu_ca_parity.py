@@ -427,7 +427,7 @@ def test_rolling_window_kernel_launcher_choice(eng, name, G):
 
 
 @pytest.mark.parametrize("tables,rows,zsplit", [("default", 32, 2), ("vn_b24_s135", 32, 2), ("default", 16, 2), ("default", 32, 1), ("vn_b24_s135", 16, 1),
-                                                ("default", "pair", 1), ("vn_b24_s135", "pair", 1)])
+                                                ("default", "pair", 1), ("vn_b24_s135", "pair", 1), ("default", "stagger", 1), ("vn_b24_s135", "stagger", 1)])
 def test_resident_multi_step_kernel(eng, tables, rows, zsplit):
     """The resident kernel (ca_resident_kernel.inc): K steps of a 512^3 von Neumann rule in one launch, the state in
     registers, tile faces handed over through tagged granules. Batches of several lengths back to back (the state tags
@@ -436,8 +436,10 @@ def test_resident_multi_step_kernel(eng, tables, rows, zsplit):
     G = 512
     r = rules(tables)
     eng.configure(G)
-    pair = rows == "pair"  # the row-pair form: 32-row tiles, a thread owns two adjacent rows x 16 planes (resident_pair_run)
+    stagger = rows == "stagger"  # the row-pair form with the two z groups of a tile half a step apart (resident_stagger_run)
+    pair = rows == "pair" or stagger  # the row-pair form: 32-row tiles, a thread owns two adjacent rows x 16 planes (resident_pair_run)
     eng.set_option("resident_pair", int(pair))
+    eng.set_option("resident_stagger", int(stagger))
     rows = 32 if pair else rows
     eng.set_option("resident_rows", rows)  # tiles of 32 rows (one workgroup per CU) or 16 rows (two per CU)
     eng.set_option("resident_zsplit", zsplit)  # 2: two threads per (row, word) column, half the planes each — four waves per SIMD
@@ -483,22 +485,26 @@ def test_resident_multi_step_kernel(eng, tables, rows, zsplit):
         np.testing.assert_array_equal(got, ol.packed_run(G, st, r, 1000), err_msg="1000 resident steps vs the oracle")
     assert eng.recovered_launches() == 0
     eng.set_option("resident_pair", 1)  # the defaults again
+    eng.set_option("resident_stagger", 0)
     eng.set_option("resident_rows", 32)
     eng.set_option("resident_zsplit", 1)
 
 
-@pytest.mark.parametrize("name,G,n", [("default", 512, 40), ("default", 256, 33), ("clustered", 512, 16), ("clustered", 256, 20)])
-def test_resident_launch_that_gives_up_is_recovered(name, G, n):
+@pytest.mark.parametrize("name,G,n,stagger", [("default", 512, 40, 0), ("default", 256, 33, 0), ("clustered", 512, 16, 0), ("clustered", 256, 20, 0),
+                                              ("default", 512, 40, 1)])
+def test_resident_launch_that_gives_up_is_recovered(name, G, n, stagger):
     """A resident launch only completes when all its workgroups are on the chip. Simulate one that is not (option
     "resident_fault_tile": that tile leaves at once, exactly what a workgroup stuck in the dispatcher's queue looks like to
     its neighbours) with a short timeout: the neighbours' waits expire, the launch and the resident launches queued behind
     it write nothing, and the engine re-runs their steps from the intact input through the per-step kernels — the call
-    sequence ends bit-exact with the oracle, the resident path is off afterwards and can be turned on again."""
+    sequence ends bit-exact with the oracle, the resident path is off afterwards and can be turned on again. (stagger: the form whose
+    two z groups run half a step apart — its waves meet the give-up word behind different barriers of their program.)"""
     from cellularautomatons3d_amd import Engine
 
     r = rules(name)
     with Engine(0) as e:
         e.configure(G)
+        e.set_option("resident_stagger", stagger)
         set_rules(e, r)
         assert e.info().kernel_name.startswith(b"ca_resident")
         st = host.random_fill(host.words_per_buffer(G), seed=404, and_rounds=1)

@@ -37,6 +37,7 @@ int main(int argc, char **argv)
 		CK(hipEventRecord(e0));
 		if (deep && zs == 2) hipLaunchKernelGGL((ca_resident_vn256_deep<0xFF, 0x0A, 2>), dim3(256), dim3(512), 0, 0, a);
 		else if (deep) hipLaunchKernelGGL((ca_resident_vn256_deep<0xFF, 0x0A, 1>), dim3(256), dim3(256), 0, 0, a);
+		else if (rows == 34) hipLaunchKernelGGL((ca_resident_vn_stagger<0xFF, 0x0A>), dim3(256), dim3(512), 0, 0, a); // 34: the staggered row-pair form
 		else if (rows == 33) hipLaunchKernelGGL((ca_resident_vn_pair<0xFF, 0x0A>), dim3(256), dim3(512), 0, 0, a); // 33: the row-pair form
 		else if (rows == 256 && zs == 2) hipLaunchKernelGGL((ca_resident_vn256<0xFF, 0x0A, 2>), dim3(256), dim3(512), 0, 0, a);
 		else if (rows == 256) hipLaunchKernelGGL((ca_resident_vn256<0xFF, 0x0A, 1>), dim3(256), dim3(256), 0, 0, a);
@@ -69,7 +70,9 @@ int main(int argc, char **argv)
 			CK(hipMemcpy(tt.data(), status, 616 * 4, hipMemcpyDeviceToHost));
 			static const char *nm[7] = {"poll", "halo+barrier", "face pass", "ym/yp reads", "z faces+prefetch", "main pass", "to_image"};
 			CK(hipMemcpy(tt.data(), status, 700 * 4, hipMemcpyDeviceToHost));
-			if (rows == 33) { for (int w = 0; w < 8; w++) { printf("  wave %d cycles/step:", w); u32 tot = 0; for (int i = 0; i < 7; i++) { printf(" %s %u", nm[i], tt[600 + w * 8 + i]); tot += tt[600 + w * 8 + i]; } printf("  total %u  (request answered %u) stale polls per 1000 steps %u\n", tot, tt[600 + w * 8 + 7], tt[680 + w]); } }
+			static const char *nm34[7] = {"faces+reads+z", "main 1", "barrier", "main 2", "to_image", "poll+halo", "barrier"};
+			if (rows == 34) { for (int w = 0; w < 8; w++) { printf("  wave %d cycles/step:", w); u32 tot = 0; for (int i = 0; i < 7; i++) { printf(" %s %u", nm34[i], tt[600 + w * 8 + i]); tot += tt[600 + w * 8 + i]; } printf("  total %u  stale polls per 1000 steps %u\n", tot, tt[680 + w]); } }
+			else if (rows == 33) { for (int w = 0; w < 8; w++) { printf("  wave %d cycles/step:", w); u32 tot = 0; for (int i = 0; i < 7; i++) { printf(" %s %u", nm[i], tt[600 + w * 8 + i]); tot += tt[600 + w * 8 + i]; } printf("  total %u  (request answered %u) stale polls per 1000 steps %u\n", tot, tt[600 + w * 8 + 7], tt[680 + w]); } }
 			else for (int w = 0; w < 2; w++) { printf("  wave %d cycles/step:", w * (rows >= 32 ? 4 : 2) * zs); u32 tot = 0; for (int i = 0; i < 7; i++) { printf(" %s %u", nm[i], tt[600 + w * 8 + i]); tot += tt[600 + w * 8 + i]; } printf("  total %u\n", tot); }
 		}
 #endif

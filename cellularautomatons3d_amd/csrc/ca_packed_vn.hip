@@ -85,12 +85,14 @@ bool vn_kernel_applies(const CanonRules &r, uint32_t G, int variant)
 
 void vn_tables(const CanonRules &r, uint32_t *lut_s, uint32_t *lut_b)
 {
-	// Entry 7 of a table is never read (a cell has at most 6 von Neumann neighbours): give it the value that makes
-	// the table constant when the other seven agree, so the specialised kernels can drop the evaluation.
+	// Entry 7 of a table is never read (a cell has at most 6 von Neumann neighbours): give it the value the other odd entries share,
+	// when they share one — a table whose seven entries agree becomes constant (the specialised kernels drop the evaluation), and one that
+	// answers every odd count alike stays so with the entry in (vn_next drops the carry out of the count's plane 0 then: ca_bitops.inc,
+	// vn_same_for_parity).
 	*lut_s = r.onset_survive[0] & 0x7Fu;
 	*lut_b = r.onset_born[0] & 0x7Fu;
-	if (*lut_s == 0x7Fu) *lut_s = 0xFFu;
-	if (*lut_b == 0x7Fu) *lut_b = 0xFFu;
+	if ((*lut_s & 0x2Au) == 0x2Au) *lut_s |= 0x80u;
+	if ((*lut_b & 0x2Au) == 0x2Au) *lut_b |= 0x80u;
 }
 
 bool vn_tables_prebuilt(uint32_t lut_s, uint32_t lut_b) { return lut_s == (u32)kDefaultS && lut_b == (u32)kDefaultB; }

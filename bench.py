@@ -127,6 +127,30 @@ def parse(argv=None):
     return a
 
 
+def group_leg(device: int, G: int, parts: int, ghost: int, min_seconds: float) -> dict:
+    """G^3 on ONE device as `parts` slabs driven by one thread through the group handle; returns the rate and the kernel that ran."""
+    from cellularautomatons3d_amd import EngineGroup, host
+    steps = 16 * ghost
+    with EngineGroup([device] * parts) as g:
+        g.configure(G, ghost)
+        g.set_rule_strings(**RULES["default"])
+        g.upload_state(host.random_fill(host.words_per_buffer(G), seed=0xCA3D0001))
+        g.step(2 * ghost)
+        g.synchronize()
+        reps, dt = 0, 0.0
+        t0 = time.perf_counter()
+        while True:
+            g.step(steps)
+            g.synchronize()
+            reps += 1
+            dt = time.perf_counter() - t0
+            if dt >= min(min_seconds, 0.5) or reps >= 64:
+                break
+        return {"value": round(float(G) ** 3 * steps * reps / dt / 1e9, 3), "unit": "Gcells/s", "ms_per_step": round(dt * 1e3 / (steps * reps), 6),
+                "slabs": parts, "ghost": ghost, "steps": steps, "reps": reps, "kernel": g.kernel_name(0), "timing": "host clock around step + synchronize",
+                "note": "one GPU, the group handle's peer-copy transport between slabs of the same device"}
+
+
 def auto_ghost(grid: int, rule: str, world: int) -> int:
     """Ghost depth K (planes per side = steps between exchanges) when none is asked for: 32 — the exchange costs a fixed ~45 us of
     launch latency on the GPU, DESIGN.md section 6 — unless a shallower one lets the rank's share run the resident slab kernel
@@ -868,6 +892,11 @@ def main():
                                            "`python bench.py --gpus 1 --config 5` gives the base of the 2048^3 clustered curve"}
             out["scaling_base"]["roofline"]["frac_of_copy_ceiling"] = round(out["scaling_base"]["roofline"]["achieved"] / ceiling, 4)
             e2.close()
+            # The same grid on the same GPU as FOUR Z-slabs behind the group handle (ca3d_group_*, all slabs on this device): every slab's
+            # 256 + 2 x 16 planes run their 16-step batches through the resident slab kernel, ghost planes refreshed by device copies — the
+            # state crosses HBM once per batch instead of once per step. Bit-exactness of this split: tests/test_gpu_slab.py::
+            # test_engine_group_single_thread_split (1024^3, four slabs).
+            out["scaling_base"]["as_four_resident_slabs"] = group_leg(local_rank, 1024, 4, 16, a.min_seconds)
         if multi_render is not None:
             out["render"] = multi_render
             if multi_render.get("frame_match") is False:

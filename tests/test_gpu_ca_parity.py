@@ -926,6 +926,26 @@ def test_bench_line_single_gpu_queued_and_per_call():
         assert json.load(open(os.path.join(root, rf["counter_source"])))["variant"] == rf["variant"]
 
 
+def test_bench_scaling_base_names_both_single_gpu_paths():
+    """The N = 1 line's `scaling_base`: 1024^3 on one GPU through the full-grid engine (per-step kernels) and, beside it, as four Z-slabs
+    behind the group handle on the same device (resident slab kernel: the state crosses HBM once per 16-step batch)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "20", "--warmup", "5", "--min-seconds", "0.05", "--no-cpu-baseline", "--no-render",
+           "--no-per-step-leg", "--no-per-call-leg", "--no-grid-256", "--no-interactive", "--verify-steps", "0"]
+    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    sb = d["scaling_base"]
+    assert sb["grid"] == 1024 and sb["roofline"]["kernel"].startswith("ca_packed_vn") and sb["value"] > 0
+    g4 = sb["as_four_resident_slabs"]
+    assert g4["kernel"].startswith("ca_resident_slab") and g4["slabs"] == 4 and g4["ghost"] == 16 and g4["value"] > 0
+
+
 def test_bench_interactive_frame_leg():
     """bench.py's `interactive_frame`: the reference's own loop — ca3d_step(1) + one literal frame per submission (main_pathtraced.js:1821-1854)
     — at the driver's grid, with the kernels that ran; and the literal frame leg beside the converged one."""

@@ -463,6 +463,16 @@ hipError_t launch_ballot_f(const UnpackedLaunch &l, hipStream_t stream, const Pa
 	const u32 tiles16 = ((l.pr.G + kBTY - 1) / kBTY) * ((l.pr.hi - l.pr.lo + 15u) / 16u);
 	// the pipelined form (loads of the next plane group under the stores of this one) where rows are whole dwordx4 wave-loads
 	static const int pipe_env = getenv("CA3D_UNPACKED_PIPE") ? atoi(getenv("CA3D_UNPACKED_PIPE")) : 1;
+	// Tiles of 32 planes where they fit (round 4): the first group's loads and the last group's stores of a tile have nothing to overlap
+	// with, and a tile twice as deep has half as many of them per plane, and 1.13 x instead of 1.19 x the cells read — 512^3: 219 -> 209 us
+	// per step (0.61 -> 0.64 of 8 TB/s), what the phase model of DESIGN 4.4 priced. One workgroup per CU then (90 KB of LDS): the
+	// range must divide into 32-plane tiles, give every CU one, and the row must be short enough for the image (512^3; 1024^3 keeps 16).
+	// CA3D_UNPACKED_TZ = 16 keeps the 16-plane tiles (tuning).
+	static const int tz_env = getenv("CA3D_UNPACKED_TZ") ? atoi(getenv("CA3D_UNPACKED_TZ")) : 32;
+	const u32 planes = l.pr.hi - l.pr.lo, C32 = l.pr.G / 32u;
+	const size_t lds32 = ((size_t)34u * (kBTY + 2) + (size_t)2 * 8u * kBTY) * C32 * sizeof(u32); // (up to 8 planes per group)
+	if (pipe_env && tz_env == 32 && l.pr.G >= 512u && planes % 32u == 0 && ((l.pr.G + kBTY - 1) / kBTY) * (planes / 32u) >= 256u && lds32 <= 160u * 1024u)
+		return launch_pipe_fz<MAIN, FAST, 32>(l, stream, prog);
 	if (pipe_env && l.pr.G >= 512u) // (256^3: 35 us against 31.5 — a tile is 8 planes there, two groups: too little to overlap)
 		return tiles16 >= 512u ? launch_pipe_fz<MAIN, FAST, 16>(l, stream, prog) : launch_pipe_fz<MAIN, FAST, 8>(l, stream, prog);
 	return tiles16 >= 512u ? launch_ballot_fz<MAIN, FAST, 16>(l, stream, prog) : launch_ballot_fz<MAIN, FAST, 8>(l, stream, prog);

@@ -112,3 +112,23 @@ def test_graph_replay_after_a_non_binary_upload():
             for _ in range(n):
                 cur = ol.unpacked_step(G, cur, r.main, r.survive, r.born)
             np.testing.assert_array_equal(e.read_state(), cur)
+
+
+@pytest.mark.parametrize("kw,rounds", [(dict(), 0), (dict(neighbourhood="moore", born="5-7", survive="4-9"), 3)])
+def test_pipelined_kernel_at_512(kw, rounds):
+    """512^3 in the one-u32-per-cell layout (512 MiB per buffer) takes the pipelined form of the ballot kernel — tiles of 32 planes walked in
+    groups of four, the next group's rows loaded under this group's stores: two steps from a dense (start-up rule) / a sparse (a Moore rule)
+    0 / 1 state against the oracle's restatement of compute.wgsl."""
+    from cellularautomatons3d_amd import Engine
+
+    G = 512
+    r = ol.Rules.from_strings(**kw)
+    with Engine(0) as e:
+        e.configure(G, LAYOUT_UNPACKED)
+        set_rules(e, r)
+        st = (host.random_fill(G ** 3 // 32, seed=512 + rounds, and_rounds=rounds)[:, None] >> np.arange(32, dtype=np.uint32) & 1).astype(np.uint32).ravel()
+        e.upload_state(st)
+        e.step(2)
+        assert e.info().kernel_name == b"ca_unpacked_ballot"
+        cur = ol.unpacked_step(G, ol.unpacked_step(G, st, r.main, r.survive, r.born), r.main, r.survive, r.born)
+        assert np.array_equal(e.read_state(), cur)  # (assert_array_equal would format 512 MiB arrays on failure)

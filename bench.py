@@ -717,6 +717,8 @@ def main():
         else:
             se = slab.SlabEngine(G, rank, world, ghost=a.ghost, device=local_rank, host_staging=a.backend == "gloo",
                                  overlap={"auto": "auto", "on": True, "off": False}[a.overlap])
+        if not a.resident:
+            se.engine.set_option("resident", 0)  # per-step slab kernels only (rehearsals with several ranks on one GPU: a resident launch needs the whole device)
         se.engine.set_rules(*offs, s, b)
         se.upload_state(full[se.z0 * pw:(se.z0 + se.nz) * pw])
         core = se.engine

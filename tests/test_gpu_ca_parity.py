@@ -101,6 +101,30 @@ def test_random_rules_through_the_rule_compilers(eng):
     eng.set_option("variant", 0)
 
 
+VN_TABLE_PAIRS = [  # (born, survive) over the von Neumann count 0 .. 6, chosen by what vn_next (ca_bitops.inc) does with them
+    ("1,3", "0-6"), ("1,5", "1,3"), ("3", "1,3,5"), ("1,3,5", ""),            # one answer for every EVEN count: the carry out of plane 0 is dropped
+    ("2,4", "1,3,5"), ("0,2", "0,1,3,5,6"), ("4,6", "2"), ("0,2,4,6", "0,6"),  # one answer for every ODD count: the carry is the first adder's sum
+    ("1,2", "2,3"), ("2", "1-3"), ("3,4,5", "0,1,6"), ("6", "5"),             # neither: the full adder tree
+    ("1,3,5", "1,3,5"), ("2,3,6", "2,3,6"), ("4-6", "4-6"), ("0-3", "4-6"),  # tables that need one or two count planes only
+]
+
+
+@pytest.mark.parametrize("born,survive", VN_TABLE_PAIRS)
+def test_von_neumann_tables_through_every_branch_of_vn_next(eng, born, survive):
+    """The run-time compiled von Neumann kernels drop what a rule's tables make unnecessary (count planes nobody reads, the carry out of
+    plane 0 when one parity of counts is answered alike — vn_same_for_parity): rules from each of those classes, two steps of the
+    per-step kernel at 128^3 and a 24-step resident batch at 256^3, dense and sparse, against the oracle."""
+    r = ol.Rules.from_strings("von neumann", born, survive)
+    for G, steps in ((128, 2), (256, 24)):
+        eng.configure(G)
+        set_rules(eng, r)
+        for rounds in (0, 3):
+            st = host.random_fill(host.words_per_buffer(G), seed=7 * G + rounds, and_rounds=rounds)
+            eng.upload_state(st)
+            eng.step(steps)
+            np.testing.assert_array_equal(eng.read_state(), ol.packed_run(G, st, r, steps), err_msg=f"B{born}/S{survive} at {G} ({eng.info().kernel_name})")
+
+
 @pytest.mark.parametrize("G", [96, 160, 384, 768])
 @pytest.mark.parametrize("name", list(RULESETS))
 def test_rows_kernel_on_grids_that_are_not_powers_of_two(eng, G, name):

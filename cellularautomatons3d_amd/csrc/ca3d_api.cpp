@@ -1666,6 +1666,8 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 	l.light = h->r_light[h->r_swap];
 	l.depth = h->r_depth[h->r_swap];
 	l.counters = h->r_counters;
+	const uint64_t state_key[3] = {h->state_serial, h->step, (uint64_t)(uintptr_t)l.cells}; // what the occupancy bits / the bricks were built from
+	bool occ_built = false, bricks_built = false;
 	if (h->render_skip && h->layout == CA3D_LAYOUT_PACKED32)
 	{
 		const size_t fine = (size_t)(h->G / 32u) * (h->G / 8u) * (h->G / 8u); // fine bits, count word, coarse bits (render.hip)
@@ -1680,9 +1682,8 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 			h->r_occ_words = words;
 		}
 		l.occ = h->r_occ;
-		const uint64_t key[3] = {h->state_serial, h->step, (uint64_t)(uintptr_t)l.cells};
-		l.occ_valid = !memcmp(key, h->r_occ_key, sizeof key);
-		memcpy(h->r_occ_key, key, sizeof key);
+		l.occ_valid = !memcmp(state_key, h->r_occ_key, sizeof state_key);
+		l.occ_built = &occ_built;
 	}
 	l.mode = h->render_mode;
 	l.sched = h->render_sched;
@@ -1738,13 +1739,19 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 			h->r_bricks_key[0] = 0;
 		}
 		l.bricks = h->r_bricks;
-		const uint64_t key[3] = {h->state_serial, h->step, (uint64_t)(uintptr_t)l.cells};
-		l.bricks_valid = !memcmp(key, h->r_bricks_key, sizeof key);
-		memcpy(h->r_bricks_key, key, sizeof key);
+		l.bricks_valid = !memcmp(state_key, h->r_bricks_key, sizeof state_key);
+		l.bricks_built = &bricks_built;
 	}
 	HIP_TRY(hipEventRecord(h->rev_start, h->stream));
 	hipError_t e = launch_render(l, h->stream);
-	if (e != hipSuccess) return fail(CA3D_ERR_DEVICE, "render launch failed: %s", hipGetErrorString(e));
+	if (e != hipSuccess)
+	{
+		h->r_occ_key[0] = h->r_bricks_key[0] = 0; // whatever was half built is not to be trusted
+		return fail(CA3D_ERR_DEVICE, "render launch failed: %s", hipGetErrorString(e));
+	}
+	// the derived buffers this call rebuilt now describe this state; the ones it did not touch keep the key of the state they were built from
+	if (occ_built) memcpy(h->r_occ_key, state_key, sizeof state_key);
+	if (bricks_built) memcpy(h->r_bricks_key, state_key, sizeof state_key);
 	HIP_TRY(hipEventRecord(h->rev_stop, h->stream));
 	h->rev_valid = true;
 	if (trace_path)

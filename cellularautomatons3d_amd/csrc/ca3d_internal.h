@@ -169,6 +169,10 @@ struct RenderLaunch
 	// state is: step count, uploads, buffers handed out): the passes that rebuild them are skipped. A static scene — a camera moving
 	// around a paused automaton — pays for them once (512^3: 30 us of a 0.87 ms frame; 2048^3: 2 ms of 3.7).
 	bool occ_valid = false, bricks_valid = false;
+	// ... and told back: set by the passes that (re)build them in THIS call — the engine takes a buffer for current only then (a frame in
+	// the literal mode builds no occupancy bits, a frame whose volume is off screen no bricks: taking either for built would leave the
+	// next frame of the same state with stale ones — a converged frame right after literal ones came out black that way)
+	bool *occ_built = nullptr, *bricks_built = nullptr;
 	void *stream_scratch = nullptr;
 	bool stream_check = false; // diagnostics: every live-cell decision of the interval filter is checked against the slab test and contradictions counted
 };
@@ -183,9 +187,9 @@ size_t stream_scratch_bytes(uint32_t W, uint32_t H, uint32_t spp, size_t *hit_of
 // render_frame.hip: the literal frame over a bricked copy of the volume (`frame_params`: render.hip's FrameParams)
 size_t frame_bricks_bytes(uint32_t G);
 bool frame_bricks_applies(uint32_t G);
-hipError_t launch_render_frame_bricks(const void *frame_params, uint32_t *bricks, bool bricks_valid, hipStream_t stream);
+hipError_t launch_render_frame_bricks(const void *frame_params, uint32_t *bricks, bool bricks_valid, hipStream_t stream, bool *bricks_built = nullptr);
 hipError_t launch_brick_volume(const uint32_t *cells, uint32_t *bricks, uint32_t G, hipStream_t stream);
-hipError_t launch_render_stream(const void *params, void *scratch, uint32_t W, uint32_t H, bool check, uint32_t *bricks, bool bricks_valid, hipStream_t stream);
+hipError_t launch_render_stream(const void *params, void *scratch, uint32_t W, uint32_t H, bool check, uint32_t *bricks, bool bricks_valid, hipStream_t stream, bool *bricks_built = nullptr);
 
 // ca_packed.hip / ca_unpacked.hip
 hipError_t launch_packed_step(const PackedLaunch &l, hipStream_t stream, const char **kernel_name);

@@ -1015,6 +1015,7 @@ hipError_t launch_render(const RenderLaunch &l, hipStream_t stream)
 			if (e == hipSuccess) e = hipMemsetAsync(box, 0, 6u * sizeof(u32), stream);
 			if (e != hipSuccess) return e;
 			hipLaunchKernelGGL(ca_occupancy, dim3((nblocks + 255u) / 256u), dim3(256), 0, stream, l.cells, l.occ, l.G, P.cols, nblocks, P.occ_words, box);
+			if (l.occ_built) *l.occ_built = true;
 			if (P.occ_coarse)
 				hipLaunchKernelGGL(ca_occupancy_coarse, dim3((nblocks / 64u + 255u) / 256u), dim3(256), 0, stream, l.occ, l.G, P.cols, nblocks / 64u, P.occ_words);
 		}
@@ -1033,7 +1034,7 @@ hipError_t launch_render(const RenderLaunch &l, hipStream_t stream)
 		F.prev_depth = l.prev_depth;
 		if (l.bricks && frame_bricks_applies(l.G))
 		{
-			hipError_t e = launch_render_frame_bricks(&F, l.bricks, l.bricks_valid, stream);
+			hipError_t e = launch_render_frame_bricks(&F, l.bricks, l.bricks_valid, stream, l.bricks_built);
 			if (e != hipSuccess) return e;
 		}
 		else hipLaunchKernelGGL(ca_render_frame_packed, grid, dim3(256), 0, stream, F);
@@ -1069,7 +1070,7 @@ hipError_t launch_render(const RenderLaunch &l, hipStream_t stream)
 			const bool streamed = l.stream_scratch && !P.legacy && !P.trace;
 			if (streamed)
 			{
-				hipError_t e = launch_render_stream(&P, l.stream_scratch, l.W, l.H, l.stream_check, l.bricks, l.bricks_valid, stream);
+				hipError_t e = launch_render_stream(&P, l.stream_scratch, l.W, l.H, l.stream_check, l.bricks, l.bricks_valid, stream, l.bricks_built);
 				if (e != hipSuccess) return e;
 			}
 			if (one)

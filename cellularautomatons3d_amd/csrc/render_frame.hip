@@ -361,7 +361,7 @@ hipError_t launch_brick_volume(const uint32_t *cells, uint32_t *bricks, uint32_t
 }
 
 // One literal frame over the bricked copy of `cells` (rebuilt here): `frame_params` is render.hip's FrameParams.
-hipError_t launch_render_frame_bricks(const void *frame_params, uint32_t *bricks, bool bricks_valid, hipStream_t stream)
+hipError_t launch_render_frame_bricks(const void *frame_params, uint32_t *bricks, bool bricks_valid, hipStream_t stream, bool *bricks_built)
 {
 	FrameBricks B;
 	B.F = *static_cast<const FrameParams *>(frame_params);
@@ -373,6 +373,7 @@ hipError_t launch_render_frame_bricks(const void *frame_params, uint32_t *bricks
 	{
 		hipError_t eb = launch_brick_volume(P.cells, bricks, P.G, stream);
 		if (eb != hipSuccess) return eb;
+		if (bricks_built) *bricks_built = true;
 	}
 	B.tiles_x = (P.W + 15u) / 16u;
 	B.tiles = B.tiles_x * ((P.H + 15u) / 16u);

@@ -765,7 +765,7 @@ size_t stream_scratch_bytes(uint32_t W, uint32_t H, uint32_t spp, size_t *hit_of
 
 // The dense-volume part of a frame over the rectangle P.rx0 .. P.ry1 (render.hip's volume_rect), on `stream`. The caller has
 // cleared P.counters and, when there is one, run the occupancy pass (the passes here test its count on the device).
-hipError_t launch_render_stream(const void *params, void *scratch, uint32_t W, uint32_t H, bool check, uint32_t *bricks, bool bricks_valid, hipStream_t stream)
+hipError_t launch_render_stream(const void *params, void *scratch, uint32_t W, uint32_t H, bool check, uint32_t *bricks, bool bricks_valid, hipStream_t stream, bool *bricks_built)
 {
 	StreamParams S;
 	S.R = *static_cast<const RenderParams *>(params);
@@ -822,6 +822,7 @@ hipError_t launch_render_stream(const void *params, void *scratch, uint32_t W, u
 		{
 			hipError_t eb = launch_brick_volume(P.cells, bricks, P.G, stream); // one pass over the state (~10 us at 512^3, 0.66 ms at 2048^3)
 			if (eb != hipSuccess) return eb;
+			if (bricks_built) *bricks_built = true;
 		}
 		if (bricks_env == 3) { if (check) launch_walks<kBricks, true, true>(S, wgs, job_blocks, stream); else launch_walks<kBricks, false, true>(S, wgs, job_blocks, stream); }
 		else if (bricks_env == 2) { if (check) launch_walks<kBricks, true>(S, wgs, job_blocks, stream); else launch_walks<kBricks, false>(S, wgs, job_blocks, stream); }

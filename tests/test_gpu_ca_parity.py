@@ -1,4 +1,6 @@
 """GPU parity: the HIP CA step, called through the C ABI, against the CPU oracle — bit-exact."""
+import os
+
 import numpy as np
 import pytest
 
@@ -9,8 +11,10 @@ from gpu_common import RULESETS, rules, set_rules
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
+@pytest.fixture(scope=lambda fixture_name, config: os.environ.get("CA3D_TEST_ENGINE_SCOPE", "module"))
 def eng():
+    # one engine per file by default (faster, and state carried from test to test is itself a test); CA3D_TEST_ENGINE_SCOPE=function gives
+    # every test a fresh one: a test that only passes behind another shows up (round 4 found a renderer cache bug that way)
     from cellularautomatons3d_amd import Engine
 
     e = Engine(0)

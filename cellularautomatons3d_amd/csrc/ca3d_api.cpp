@@ -176,6 +176,9 @@ struct ca3d_engine
 	// what the renderer's derived buffers (occupancy bits, bricks) were last built from: serial (bumped by everything that writes the state
 	// other than a step: uploads, buffers handed out, gathers), step count, buffer
 	uint64_t state_serial = 1, r_occ_key[3] = {0, 0, 0}, r_bricks_key[3] = {0, 0, 0};
+	// ca3d_device_buffer handed a pointer out: until the call that ends its validity (step / upload / configure) the caller may write the
+	// state at any time without telling the engine, so no frame may reuse what an earlier frame derived from it
+	bool buffers_exposed = false;
 	void *r_stream = nullptr;    // scratch of the stream passes
 	size_t r_stream_bytes = 0;
 	int r_swap = 0;
@@ -905,6 +908,7 @@ static int configure_common(ca3d_t *h, uint32_t g, int layout)
 	if (rc) return rc;
 	HIP_TRY(hipStreamSynchronize(h->stream));
 	free_buffers(h);
+	h->buffers_exposed = false;
 	h->G = g;
 	h->layout = layout;
 	h->plane_words = layout == CA3D_LAYOUT_PACKED32 ? (size_t)(g / 32u) * g : (size_t)g * g;
@@ -988,6 +992,7 @@ int ca3d_upload_state(ca3d_t *h, const uint32_t *words, size_t n_words)
 	h->step = 0;
 	h->cur = 0;
 	h->state_serial++;
+	h->buffers_exposed = false;
 	h->pending_edges = 0; // a restart between the two phases of a batch abandons the batch
 	h->ghosts_valid = false;
 	h->res_pending.clear(); // their results have just been overwritten
@@ -1037,6 +1042,7 @@ static int submit_steps(ca3d_engine *h, uint32_t n_steps)
 	int rc = bind_device(h);
 	if (rc) return rc;
 	if (n_steps == 0) return CA3D_OK;
+	h->buffers_exposed = false; // (ca3d_device_buffer: the pointer it handed out was valid until this call)
 	if (h->want_stats) HIP_TRY(hipEventRecord(h->ev_start, h->stream));
 	uint32_t left = n_steps;
 	uint64_t launches = 0;
@@ -1136,6 +1142,7 @@ int slab_batch(ca3d_engine *h, uint32_t n_steps, int phase)
 	rc = bind_device(h);
 	if (rc) return rc;
 	if (n_steps == 0) return CA3D_OK;
+	h->buffers_exposed = false;
 	const uint32_t L = h->nplanes, K = h->ghost, n = n_steps;
 	// The packed kernel's bottom face is dead (z == -1 is dropped): the slab that owns global plane 0 never needs
 	// its low ghost.
@@ -1500,7 +1507,8 @@ int ca3d_device_buffer(ca3d_t *h, int which, void **device_ptr, size_t *n_bytes)
 	if (int rcs = settle_resident(h)) return rcs;
 	*device_ptr = h->buf[which];
 	*n_bytes = h->buffer_words() * sizeof(uint32_t);
-	h->state_serial++; // the caller may write through the pointer: what the renderer derived from the state is stale from here on
+	h->state_serial++; // the caller may write through the pointer: what the renderer derived from the state is stale from here on,
+	h->buffers_exposed = true; // and again before every frame while the pointer is valid (ca3d_render)
 	return CA3D_OK;
 }
 
@@ -1666,6 +1674,7 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 	l.light = h->r_light[h->r_swap];
 	l.depth = h->r_depth[h->r_swap];
 	l.counters = h->r_counters;
+	if (h->buffers_exposed) h->state_serial++; // a caller holds a pointer to the state and may have written it since the last frame
 	const uint64_t state_key[3] = {h->state_serial, h->step, (uint64_t)(uintptr_t)l.cells}; // what the occupancy bits / the bricks were built from
 	bool occ_built = false, bricks_built = false;
 	if (h->render_skip && h->layout == CA3D_LAYOUT_PACKED32)
@@ -2056,7 +2065,15 @@ int engine_mark_state(ca3d_engine *h)
 	h->has_state = true;
 	h->binary_state = true;
 	h->state_serial++;
+	h->buffers_exposed = false;
 	return CA3D_OK;
+}
+int engine_state_buffer(ca3d_engine *h, int which, void **device_ptr, size_t *n_bytes)
+{
+	const bool was = h ? h->buffers_exposed : false;
+	const int rc = ca3d_device_buffer(h, which, device_ptr, n_bytes);
+	if (h) h->buffers_exposed = was;
+	return rc;
 }
 void engine_set_ghosts_valid(ca3d_engine *h, bool valid) { h->ghosts_valid = valid; }
 bool engine_ghosts_valid(const ca3d_engine *h) { return h->ghosts_valid; }

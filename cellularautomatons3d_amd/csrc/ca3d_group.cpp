@@ -381,7 +381,7 @@ int ca3d_group_render(ca3d_group_t *g, const float uniforms[128], uint32_t width
 		G_TRY(ca3d_get_info(g->full[(size_t)d], &fi));
 		void *vol;
 		size_t vol_bytes;
-		G_TRY(ca3d_device_buffer(g->full[(size_t)d], fi.current_buffer, &vol, &vol_bytes));
+		G_TRY(engine_state_buffer(g->full[(size_t)d], fi.current_buffer, &vol, &vol_bytes));
 		G_HIP_TRY(hipSetDevice(g->devices[(size_t)d]));
 		hipStream_t s = engine_stream(g->eng[(size_t)d]);
 		for (int k = 0; k < n; k++)

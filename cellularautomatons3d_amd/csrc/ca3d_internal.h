@@ -162,7 +162,7 @@ struct RenderLaunch
 	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 	// mode 0, packed, scheduled: scratch of the ray-stream pipeline (render_stream.hip; stream_scratch_bytes(W, H, spp) bytes) — with it the
 	// dense-volume part of the frame is drawn by the stream passes instead of ca_render_packed_sched (same frame, bit for bit). Null: not used.
-	uint32_t *bricks = nullptr; // room for the bricked copy of the volume (frame_bricks_bytes(G)); with it — and a power-of-two grid — mode 1's frame is
+	uint32_t *bricks = nullptr; // room for the bricked copy of the volume (frame_bricks_bytes(G)); with it (any grid that is a multiple of 32 up to 2048) mode 1's frame is
 	                            // drawn by render_frame.hip's batched march instead of ca_render_frame_packed, and mode 0's stream walks read the bricks
 	                            // (same frames, bit for bit)
 	// The occupancy bits / the bricks in those buffers were built from exactly this state by an earlier frame (the engine tracks what the
@@ -265,6 +265,9 @@ int set_error(int code, const char *fmt, ...);
 int engine_device(const ca3d_engine *h);
 hipStream_t engine_stream(const ca3d_engine *h);
 int engine_mark_state(ca3d_engine *h); // both buffers zeroed on the engine's stream, "has a state" — for engines whose state arrives by device copies
+// ca3d_device_buffer for a writer inside the library (the group's peer copies): the state counts as rewritten by THIS call only — the
+// public call must assume writes at any later time and makes every frame rebuild its derived buffers while the pointer is valid
+int engine_state_buffer(ca3d_engine *h, int which, void **device_ptr, size_t *n_bytes);
 void engine_set_ghosts_valid(ca3d_engine *h, bool valid);
 bool engine_ghosts_valid(const ca3d_engine *h);
 int engines_rccl_init_all(ca3d_engine **engines, int n);

@@ -16,7 +16,9 @@
 //     march (ray_cube_inv: bit-identical to the shader's slab test).
 // The arithmetic of every sample — positions by repeated addition of the step, floor, the u32 conversions, the slab test, shading,
 // blend — is the first form's, operation for operation: tests/test_gpu_render.py compares the two frames for equality.
-// Power-of-two grids (masks for the modulo wrap of :268-290); other grids stay with the first form.
+// Every grid the UI offers (multiples of 32, main_pathtraced.js:675-693): power-of-two grids index the bricks by shifts and wrap by masks
+// (the modulo of :268-290); the others (96, 160, ..., 992: bricks of 8^3 divide every multiple of 32) by 24-bit multiply-adds and a
+// compare (a coordinate >= G — only the sample on a + face and a reprojected point outside the volume — takes a real modulo).
 #include <hip/hip_fp16.h>
 
 #include "ca3d_internal.h"
@@ -69,17 +71,61 @@ __global__ __launch_bounds__(256) void ca_brick_volume(const u32 *__restrict__ c
 	}
 }
 
+// the same for any G that is a multiple of 32 (rows of C = G / 32 words, G / 8 bricks per edge)
+__global__ __launch_bounds__(256) void ca_brick_volume_any(const u32 *__restrict__ cells, u32 *__restrict__ bricks, u32 G)
+{
+	__shared__ u32 src[64u * kBrickMaxC]; // [z & 7][y & 7][word]
+	const u32 C = G >> 5, nb = G >> 3;
+	const u32 by = blockIdx.x % nb, bz = blockIdx.x / nb;
+	const u32 words = 64u * C;
+	for (u32 i = threadIdx.x; i < words; i += 256u)
+	{
+		const u32 r = i / C, xw = i - r * C; // r = 8 z + y
+		src[i] = cells[xw + ((size_t)((bz << 3) + (r >> 3)) * G + ((by << 3) + (r & 7u))) * C];
+	}
+	__syncthreads();
+	uint4 *dst = reinterpret_cast<uint4 *>(bricks + (size_t)blockIdx.x * nb * 16u);
+	const u32 quads = nb * 4u;
+	for (u32 q = threadIdx.x; q < quads; q += 256u)
+	{
+		const u32 bx = q >> 2, w0 = (q & 3u) << 2;
+		const u32 xw = bx >> 2, sh = (bx & 3u) << 3;
+		u32 o[4];
+#pragma unroll
+		for (u32 k = 0; k < 4u; k++)
+		{
+			const u32 w = w0 + k, z = w >> 1, y0 = (w & 1u) << 2;
+			u32 v = 0;
+#pragma unroll
+			for (u32 r = 0; r < 4u; r++) v |= ((src[((z << 3) + y0 + r) * C + xw] >> sh) & 0xFFu) << (8u * r);
+			o[k] = v;
+		}
+		dst[q] = make_uint4(o[0], o[1], o[2], o[3]);
+	}
+}
+
+template <bool P2>
 struct BrickVolume
 {
 	const u32 *bricks;
-	u32 lg; // log2 G
+	u32 lg; // log2 G (P2)
+	u32 G;  // (!P2)
 	// word index and bit of cell (x, y, z), every coordinate modulo the grid (:268-290)
 	__device__ __forceinline__ u32 word_of(u32 x, u32 y, u32 z, u32 &bit) const
 	{
-		const u32 m = (1u << lg) - 1u, lnb = lg - 3u;
-		x &= m; y &= m; z &= m;
+		if (P2)
+		{
+			const u32 m = (1u << lg) - 1u, lnb = lg - 3u;
+			x &= m; y &= m; z &= m;
+			bit = (x & 7u) | ((y & 3u) << 3);
+			return ((((((z >> 3) << lnb) + (y >> 3)) << lnb) + (x >> 3)) << 4) + ((z & 7u) << 1) + ((y & 7u) >> 2);
+		}
+		if (__builtin_expect(x >= G, 0)) x %= G;
+		if (__builtin_expect(y >= G, 0)) y %= G;
+		if (__builtin_expect(z >= G, 0)) z %= G;
+		const u32 nb = G >> 3; // <= 256: the products below stay under 2^24
 		bit = (x & 7u) | ((y & 3u) << 3);
-		return ((((((z >> 3) << lnb) + (y >> 3)) << lnb) + (x >> 3)) << 4) + ((z & 7u) << 1) + ((y & 7u) >> 2);
+		return ((__umul24(__umul24(z >> 3, nb) + (y >> 3), nb) + (x >> 3)) << 4) + ((z & 7u) << 1) + ((y & 7u) >> 2);
 	}
 	__device__ __forceinline__ u32 state(u32 x, u32 y, u32 z) const
 	{
@@ -101,8 +147,8 @@ constexpr int kBatch = 8;
 // rayMarchDepth (:682-741, SHADOW false) and rayMarchShadow (:635-680, SHADOW true): samples at depth0, depth0 + step, ... (repeated
 // addition, as the shader's `depth += step`) while depth < march; a live cell whose visible cube the ray meets ends the march.
 // Returns true on such a hit (a_out: the cube's slab entry). `visits` counts the samples taken, the hit one included.
-template <bool SHADOW>
-__device__ __forceinline__ bool march_batched(const RenderParams &P, const BrickVolume &vol, v3 from, v3 dir, float march, float step, float depth0, v3 vhalf,
+template <bool SHADOW, bool P2>
+__device__ __forceinline__ bool march_batched(const RenderParams &P, const BrickVolume<P2> &vol, v3 from, v3 dir, float march, float step, float depth0, v3 vhalf,
                                               u32 ex, u32 ey, u32 ez, u32 &visits, float &a_out)
 {
 	const float cs = 1.0f / (float)P.G;
@@ -159,6 +205,7 @@ __device__ __forceinline__ bool march_batched(const RenderParams &P, const Brick
 	return false;
 }
 
+template <bool P2>
 __global__ __launch_bounds__(256, 4) void ca_render_frame_bricks(FrameBricks B)
 {
 	const FrameParams &F = B.F;
@@ -170,7 +217,7 @@ __global__ __launch_bounds__(256, 4) void ca_render_frame_bricks(FrameBricks B)
 	const u32 px = (tile % B.tiles_x) * 16u + (threadIdx.x & 15u);
 	const u32 py = (tile / B.tiles_x) * 16u + (threadIdx.x >> 4);
 	if (px >= P.W || py >= P.H) return;
-	const BrickVolume vol{B.bricks, B.lg};
+	const BrickVolume<P2> vol{B.bricks, B.lg, P.G};
 	const float *u = P.u;
 	const float *view = u + U_VIEW;
 	const float vu = ((float)px + 0.5f) / (float)P.W, vv = 1.0f - ((float)py + 0.5f) / (float)P.H;
@@ -203,7 +250,7 @@ __global__ __launch_bounds__(256, 4) void ca_render_frame_bricks(FrameBricks B)
 			const float march = len3(seg);
 			const float step = march / u[U_DEPTHSAMPLES];
 			float a = 0.0f;
-			if (march_batched<false>(P, vol, enter, dir, march, step, step * rnd + 0.01f, vhalf, 0, 0, 0, pvis, a)) final_point = enter + dir * a;
+			if (march_batched<false, P2>(P, vol, enter, dir, march, step, step * rnd + 0.01f, vhalf, 0, 0, 0, pvis, a)) final_point = enter + dir * a;
 		}
 		float uvx, uvy;
 		reprojected_uv(P, final_point, uvx, uvy);
@@ -253,7 +300,7 @@ __global__ __launch_bounds__(256, 4) void ca_render_frame_bricks(FrameBricks B)
 					const float march = len3(seg);
 					const float step = fmaxf(cs * u[U_CELLSIZE], march / u[U_SHADOWSAMPLES]);
 					float a = 0.0f;
-					if (march_batched<true>(P, vol, p, dir, march, step, step * rnd + 0.0025f, vhalf, cell.x, cell.y, cell.z, svis, a)) occ = kOcclusion;
+					if (march_batched<true, P2>(P, vol, p, dir, march, step, step * rnd + 0.0025f, vhalf, cell.x, cell.y, cell.z, svis, a)) occ = kOcclusion;
 				}
 				shadow = 1u;
 				const v3 N = face_normal(p, cell.origin);
@@ -348,15 +395,19 @@ __global__ __launch_bounds__(256, 4) void ca_render_frame_bricks(FrameBricks B)
 
 size_t frame_bricks_bytes(uint32_t G) { return (size_t)G * G * G / 8u; }
 
-bool frame_bricks_applies(uint32_t G) { return G >= 32u && G <= 2048u && (G & (G - 1u)) == 0u; } // (ca_brick_volume stages rows of up to 64 words)
+bool frame_bricks_applies(uint32_t G) { return G >= 32u && G <= 2048u && (G & 31u) == 0u; } // (ca_brick_volume stages rows of up to 64 words)
 
-// The bricked copy of a packed state (power-of-two grids): one pass, on `stream`.
+// The bricked copy of a packed state: one pass, on `stream`.
 hipError_t launch_brick_volume(const uint32_t *cells, uint32_t *bricks, uint32_t G, hipStream_t stream)
 {
-	u32 lg = 0;
-	while ((1u << lg) < G) lg++;
 	const u32 nb = G >> 3;
-	hipLaunchKernelGGL(ca_brick_volume, dim3(nb * nb), dim3(256), 0, stream, cells, bricks, lg);
+	if ((G & (G - 1u)) == 0u)
+	{
+		u32 lg = 0;
+		while ((1u << lg) < G) lg++;
+		hipLaunchKernelGGL(ca_brick_volume, dim3(nb * nb), dim3(256), 0, stream, cells, bricks, lg);
+	}
+	else hipLaunchKernelGGL(ca_brick_volume_any, dim3(nb * nb), dim3(256), 0, stream, cells, bricks, G);
 	return hipGetLastError();
 }
 
@@ -378,7 +429,8 @@ hipError_t launch_render_frame_bricks(const void *frame_params, uint32_t *bricks
 	B.tiles_x = (P.W + 15u) / 16u;
 	B.tiles = B.tiles_x * ((P.H + 15u) / 16u);
 	const u32 per = (B.tiles + 7u) >> 3;
-	hipLaunchKernelGGL(ca_render_frame_bricks, dim3(per * 8u), dim3(256), 0, stream, B);
+	if ((P.G & (P.G - 1u)) == 0u) hipLaunchKernelGGL(ca_render_frame_bricks<true>, dim3(per * 8u), dim3(256), 0, stream, B);
+	else hipLaunchKernelGGL(ca_render_frame_bricks<false>, dim3(per * 8u), dim3(256), 0, stream, B);
 	return hipGetLastError();
 }
 

@@ -59,6 +59,7 @@ struct StreamParams
 	                      // jobs of chunk c: [64 c, 64 c + 64), pixel-major, a pixel's samples next to each other
 	const u32 *volume;   // what the walks read: R.cells, or the bricked copy of it
 	u32 lg, lc;          // log2 G, log2 cols (power-of-two grids)
+	u32 nb;              // bricks per edge, G / 8
 	int refill;          // lanes without a ray at which a wave leaves the stepping loop to take new jobs (tuning: CA3D_STREAM_REFILL)
 	u32 lb;              // log2 of a chunk's pixel-block edge; jobs per chunk = spp << (2 lb)
 	u32 qmap;            // 0: queue q owns a contiguous eighth of the chunks (a band of the image); 1: every eighth chunk
@@ -163,11 +164,18 @@ struct Walker
 // kBricksRead: bricks, and the walker reads its cell's word at every cell instead of keeping the last word in a register (no key to
 // compare, no branch around the read; the default). Measured on top of each other (1080p / 4K, 4 samples, ms per frame): rows 0.88 /
 // 2.32, bricks 0.80 / 1.98, bricks + a read per cell 0.785 / 1.94; a whole 8 x 8 z-slice per lane in two registers 0.805 / 2.11.
-enum { kRowsP2 = 0, kRowsAny = 1, kBricks = 2, kBricksRead = 3 };
+// kBricksReadAny: the same over the bricks of a grid that is not a power of two (96, 160, ..., 992): G / 8 bricks per edge, the brick index by
+// two 24-bit multiply-adds (full rate) instead of shifts.
+enum { kRowsP2 = 0, kRowsAny = 1, kBricks = 2, kBricksRead = 3, kBricksReadAny = 4 };
 
 template <int LAYOUT>
 __device__ __forceinline__ int word_key(const StreamParams &S, int ix, int iy, int iz)
 {
+	if (LAYOUT == kBricksReadAny)
+	{
+		const u32 b = __umul24(__umul24((u32)iz >> 3, S.nb) + ((u32)iy >> 3), S.nb) + ((u32)ix >> 3); // nb <= 256: under 2^24
+		return (int)((b << 4) + (((u32)iz & 7u) << 1) + (((u32)iy & 7u) >> 2));
+	}
 	if (LAYOUT == kBricks || LAYOUT == kBricksRead)
 	{
 		const u32 lnb = S.lg - 3u;
@@ -180,7 +188,7 @@ __device__ __forceinline__ int word_key(const StreamParams &S, int ix, int iy, i
 template <int LAYOUT>
 __device__ __forceinline__ u32 word_bit(int ix, int iy)
 {
-	return (LAYOUT == kBricks || LAYOUT == kBricksRead) ? (((u32)ix & 7u) | (((u32)iy & 3u) << 3)) : ((u32)ix & 31u);
+	return (LAYOUT == kBricks || LAYOUT == kBricksRead || LAYOUT == kBricksReadAny) ? (((u32)ix & 7u) | (((u32)iy & 3u) << 3)) : ((u32)ix & 31u);
 }
 
 // walk_begin of render.hip / the head of walk(): first cell, boundary times, increments
@@ -243,7 +251,7 @@ __device__ __forceinline__ int walk_cell(const StreamParams &S, Walker &w, int k
 	const RenderParams &P = S.R;
 	// (a 32-bit byte offset from the scalar base: one shift instead of a sign extension and a 64-bit add per visit)
 	u32 cur;
-	if (LAYOUT == kBricksRead) cur = *reinterpret_cast<const u32 *>(reinterpret_cast<const char *>(S.volume) + ((u32)key << 2));
+	if (LAYOUT == kBricksRead || LAYOUT == kBricksReadAny) cur = *reinterpret_cast<const u32 *>(reinterpret_cast<const char *>(S.volume) + ((u32)key << 2));
 	else
 	{
 		if (LOAD && key != w.wkey) { w.word = *reinterpret_cast<const u32 *>(reinterpret_cast<const char *>(S.volume) + ((u32)key << 2)); w.wkey = key; }
@@ -284,7 +292,9 @@ __device__ __forceinline__ int walk_cell(const StreamParams &S, Walker &w, int k
 	w.iy += my ? w.sy : 0;
 	w.iz += mz ? w.sz : 0;
 	exempt = false; // the walk is monotone: once it has left the cell it started in it does not come back
-	const bool outside = (u32)(w.ix | w.iy | w.iz) >= P.G; // a negative coordinate sets the top bit
+	// (one v_max3_u32; a negative coordinate is a huge unsigned one. `ix | iy | iz` >= G, the first form, is the same test on power-of-two grids
+	// only: at G = 96 the cell (64, 32, z) reads as outside — a tenth of the pixels of a 96^3 frame were wrong until round 5 tested one)
+	const bool outside = max(max((u32)w.ix, (u32)w.iy), (u32)w.iz) >= P.G;
 	return (outside || t >= w.tmax) ? 2 : 0;
 }
 
@@ -316,7 +326,7 @@ __device__ __forceinline__ bool walk_advance(const RenderParams &P, Walker &w)
 	w.ix += mx ? w.sx : 0;
 	w.iy += my ? w.sy : 0;
 	w.iz += mz ? w.sz : 0;
-	const bool outside = (u32)(w.ix | w.iy | w.iz) >= P.G;
+	const bool outside = max(max((u32)w.ix, (u32)w.iy), (u32)w.iz) >= P.G;
 	return outside || t >= w.tmax;
 }
 
@@ -787,6 +797,7 @@ hipError_t launch_render_stream(const void *params, void *scratch, uint32_t W, u
 	const u32 per = P.spp << (2u * S.lb);
 	const bool p2 = (P.G & (P.G - 1u)) == 0u;
 	S.lg = S.lc = 0;
+	S.nb = P.G >> 3;
 	if (p2)
 	{
 		while ((1u << S.lg) < P.G) S.lg++;
@@ -824,7 +835,8 @@ hipError_t launch_render_stream(const void *params, void *scratch, uint32_t W, u
 			if (eb != hipSuccess) return eb;
 			if (bricks_built) *bricks_built = true;
 		}
-		if (bricks_env == 3) { if (check) launch_walks<kBricks, true, true>(S, wgs, job_blocks, stream); else launch_walks<kBricks, false, true>(S, wgs, job_blocks, stream); }
+		if (!p2) { if (check) launch_walks<kBricksReadAny, true>(S, wgs, job_blocks, stream); else launch_walks<kBricksReadAny, false>(S, wgs, job_blocks, stream); }
+		else if (bricks_env == 3) { if (check) launch_walks<kBricks, true, true>(S, wgs, job_blocks, stream); else launch_walks<kBricks, false, true>(S, wgs, job_blocks, stream); }
 		else if (bricks_env == 2) { if (check) launch_walks<kBricks, true>(S, wgs, job_blocks, stream); else launch_walks<kBricks, false>(S, wgs, job_blocks, stream); }
 		else if (check) launch_walks<kBricksRead, true>(S, wgs, job_blocks, stream);
 		else launch_walks<kBricksRead, false>(S, wgs, job_blocks, stream);

@@ -223,7 +223,11 @@ int ca3d_set_stream(ca3d_t *h, void *hip_stream);
 int ca3d_use_own_stream(ca3d_t *h);
 /* Device pointer of ping-pong buffer `which` (0/1) — whole allocation including ghosts. Valid until the next ca3d_step /
  * ca3d_upload_state / ca3d_configure on the engine: a resident multi-step launch writes its result to a third buffer and
- * rotates the three (buffer [step % 2] is always the current state, the other one the state one step earlier). */
+ * rotates the three (buffer [step % 2] is always the current state, the other one the state one step earlier).
+ * The caller may WRITE the state through the pointer (on the engine's stream, or ordered against it) without telling the
+ * engine: while the pointer is valid every ca3d_render rebuilds what it derives from the state (occupancy bits, the bricked
+ * copy) instead of reusing an earlier frame's — one extra pass over the state per frame, the price of not having to
+ * announce writes. */
 int ca3d_device_buffer(ca3d_t *h, int which, void **device_ptr, size_t *n_bytes);
 
 typedef struct ca3d_info

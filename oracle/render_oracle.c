@@ -599,9 +599,14 @@ static CellU cell_u(const Ctx *c, v3 p)
 	return r;
 }
 
+/* `flags` (optional) records which branches this pixel took: 1 the view ray meets the volume (:822); 2 the depth repair of
+ * estimateLikelyDepth replaced the marched depth (:779-786); 4 reprojected uv outside [0,1]^2 -> current sample unblended (:450-454);
+ * 8 cell identity differs -> unblended (:456-459); 16 blended with the history (:469); 32 the pixel is lit (colour != 0 before the
+ * blend). Tests use them to show that a moving-camera sequence really exercises every branch of R6 / R10. */
 static void frame_pixel(const Ctx *c, uint32_t W, uint32_t H, uint32_t px, uint32_t py, const float *prev_light,
-                        const float *prev_depth, float out_rgba[4], float *out_depth)
+                        const float *prev_depth, float out_rgba[4], float *out_depth, uint8_t *flags)
 {
+	uint8_t fl = 0;
 	const float *u = c->u;
 	const float *view = u + U_VIEW;
 	const float vu = ((float)px + 0.5f) / (float)W, vv = 1.0f - ((float)py + 0.5f) / (float)H;
@@ -615,6 +620,7 @@ static void frame_pixel(const Ctx *c, uint32_t W, uint32_t H, uint32_t px, uint3
 	const float cam_dist = sd_box(cam, half);
 	if (tn <= tf && tf >= 0.0f)
 	{
+		fl |= 1;
 		v3 enter = cam;
 		const v3 exitp = add(cam, scale(ray, tf));
 		if (cam_dist >= 0.0f) enter = add(cam, scale(ray, tn));
@@ -640,7 +646,7 @@ static void frame_pixel(const Ctx *c, uint32_t W, uint32_t H, uint32_t px, uint3
 			{
 				float a, b;
 				ray_cube(cam, view_ray, rc.origin, V(vis, vis, vis), &a, &b);
-				if (a <= b && a >= 0.0f) likely = a;
+				if (a <= b && a >= 0.0f) { likely = a; fl |= 2; }
 			}
 			(void)pd;
 		}
@@ -666,6 +672,7 @@ static void frame_pixel(const Ctx *c, uint32_t W, uint32_t H, uint32_t px, uint3
 				Cell ci; ci.origin = cell.origin; ci.cx = (int32_t)cell.x; ci.cy = (int32_t)cell.y; ci.cz = (int32_t)cell.z;
 				const v3 lit = lighting_at(c, p, ci, cam);
 				col[0] = occ * lit.x; col[1] = occ * lit.y; col[2] = occ * lit.z;
+				if (col[0] != 0.0f || col[1] != 0.0f || col[2] != 0.0f) fl |= 32;
 			}
 		}
 		/* mixWithReprojectedColor :429-471 */
@@ -678,9 +685,10 @@ static void frame_pixel(const Ctx *c, uint32_t W, uint32_t H, uint32_t px, uint3
 			const v3 rpoint = add(pcam, scale(rdir, pdr[0]));
 			const CellU rcell = cell_u(c, rpoint), ccell = cell_u(c, p);
 			const int outside = uvr[0] < 0.0f || uvr[0] > 1.0f || uvr[1] < 0.0f || uvr[1] > 1.0f;
-			if (outside || ccell.idx != rcell.idx) { out[0] = col[0]; out[1] = col[1]; out[2] = col[2]; out[3] = 1.0f; }
+			if (outside || ccell.idx != rcell.idx) { out[0] = col[0]; out[1] = col[1]; out[2] = col[2]; out[3] = 1.0f; fl |= outside ? 4 : 8; }
 			else
 			{
+				fl |= 16;
 				const float a = u[U_TEMPORALALPHA];
 				const float cur[4] = { col[0], col[1], col[2], 1.0f };
 				for (int k = 0; k < 4; k++) out[k] = clampf(pc[k] * (1.0f - a) + cur[k] * a, 0.0f, 1.0f); /* mix(x, y, a) = x*(1-a) + y*a */
@@ -696,10 +704,23 @@ static void frame_pixel(const Ctx *c, uint32_t W, uint32_t H, uint32_t px, uint3
 	if (u[U_SHOWDEPTH] == 1.0f && vu < 0.5f) { out[0] = mixed_depth; out[1] = 0; out[2] = 0; out[3] = 1; }
 	for (int k = 0; k < 4; k++) out_rgba[k] = out[k];
 	*out_depth = mixed_depth;
+	if (flags) *flags = fl;
 }
+
+int ca3d_oracle_render_frame_branches(const uint32_t *cells, uint32_t G, const float *uniforms, uint32_t W, uint32_t H,
+                                      const float *prev_light, const float *prev_depth, float *light, float *depth, float *presentation,
+                                      uint8_t *branches);
 
 int ca3d_oracle_render_frame(const uint32_t *cells, uint32_t G, const float *uniforms, uint32_t W, uint32_t H,
                              const float *prev_light, const float *prev_depth, float *light, float *depth, float *presentation)
+{
+	return ca3d_oracle_render_frame_branches(cells, G, uniforms, W, H, prev_light, prev_depth, light, depth, presentation, NULL);
+}
+
+/* the same frame; branches[H * W] (optional) receives frame_pixel's flags */
+int ca3d_oracle_render_frame_branches(const uint32_t *cells, uint32_t G, const float *uniforms, uint32_t W, uint32_t H,
+                                      const float *prev_light, const float *prev_depth, float *light, float *depth, float *presentation,
+                                      uint8_t *branches)
 {
 	if (!cells || !uniforms || G == 0 || (G % 32u)) return -1;
 	Ctx c = { cells, G, uniforms, (float)(1.0 / tan(37.5 * 3.14159265359 / 180.0)), 0, 0 };
@@ -710,8 +731,8 @@ int ca3d_oracle_render_frame(const uint32_t *cells, uint32_t G, const float *uni
 		for (uint32_t px = 0; px < W; px++)
 		{
 			float o[4], d;
-			frame_pixel(&c, W, H, px, py, prev_light, prev_depth, o, &d);
 			const size_t i = (size_t)py * W + px;
+			frame_pixel(&c, W, H, px, py, prev_light, prev_depth, o, &d, branches ? branches + i : NULL);
 			if (light) { light[4 * i] = o[0]; light[4 * i + 1] = o[1]; light[4 * i + 2] = o[2]; light[4 * i + 3] = 1.0f; }
 			if (depth) { depth[2 * i] = d; depth[2 * i + 1] = 1.0f; }
 			if (presentation)

@@ -176,9 +176,13 @@ def primary_bruteforce(cells, G, uniforms, W, H, px, py):
     return float(d), int(cell.value)
 
 
-def render_frame(cells, G, uniforms, W, H, prev_light=None, prev_depth=None):
+BRANCH_VOLUME, BRANCH_DEPTH_REPAIR, BRANCH_UV_OUTSIDE, BRANCH_CELL_DIFFERS, BRANCH_BLENDED, BRANCH_LIT = 1, 2, 4, 8, 16, 32
+
+
+def render_frame(cells, G, uniforms, W, H, prev_light=None, prev_depth=None, branches=False):
     """One literal reference frame (stochastic march + temporal history). prev_* are what the previous frame wrote,
-    already rounded to binary16 (float arrays [H,W,4] / [H,W,2]) or None for an empty history."""
+    already rounded to binary16 (float arrays [H,W,4] / [H,W,2]) or None for an empty history. branches=True appends a
+    uint8 [H,W] array of BRANCH_* flags: which branches of R6 / R10 each pixel took."""
     c, cp = _u32(cells)
     u = np.ascontiguousarray(uniforms, dtype=np.float32)
     fp = C.POINTER(C.c_float)
@@ -187,9 +191,11 @@ def render_frame(cells, G, uniforms, W, H, prev_light=None, prev_depth=None):
     pres = np.zeros((H, W, 4), dtype=np.float32)
     pl = np.ascontiguousarray(prev_light, dtype=np.float32) if prev_light is not None else None
     pd = np.ascontiguousarray(prev_depth, dtype=np.float32) if prev_depth is not None else None
-    rc = lib().ca3d_oracle_render_frame(cp, C.c_uint32(G), u.ctypes.data_as(fp), C.c_uint32(W), C.c_uint32(H),
-                                        pl.ctypes.data_as(fp) if pl is not None else None,
-                                        pd.ctypes.data_as(fp) if pd is not None else None,
-                                        light.ctypes.data_as(fp), depth.ctypes.data_as(fp), pres.ctypes.data_as(fp))
+    br = np.zeros((H, W), dtype=np.uint8) if branches else None
+    rc = lib().ca3d_oracle_render_frame_branches(cp, C.c_uint32(G), u.ctypes.data_as(fp), C.c_uint32(W), C.c_uint32(H),
+                                                 pl.ctypes.data_as(fp) if pl is not None else None,
+                                                 pd.ctypes.data_as(fp) if pd is not None else None,
+                                                 light.ctypes.data_as(fp), depth.ctypes.data_as(fp), pres.ctypes.data_as(fp),
+                                                 br.ctypes.data_as(C.POINTER(C.c_uint8)) if branches else None)
     assert rc == 0, rc
-    return light, depth, pres
+    return (light, depth, pres, br) if branches else (light, depth, pres)

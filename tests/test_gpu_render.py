@@ -77,6 +77,16 @@ def test_random_volume(eng, pose, spp):
     _compare(eng, cells, G, host.uniform_block(W, H, vm), W, H, spp)
 
 
+@pytest.mark.parametrize("G,W,H,spp", [(96, 320, 180, 4), (160, 320, 180, 1), (992, 1920, 1080, 4)])
+def test_grids_that_are_not_a_power_of_two(eng, G, W, H, spp):
+    """Every multiple of 32 is a UI grid (main_pathtraced.js:268-279, 675-693; "1000" -> 992): the ray-stream walks read the bricked
+    copy of such a volume too (bricks of 8^3 divide every multiple of 32; brick index by multiply-adds instead of shifts) — plain,
+    scheduled and stream forms bit for bit the same, the oracle's frame within the tolerance. 992^3: a 24-row band of the 1080p frame."""
+    cells = host.random_fill(host.words_per_buffer(G), seed=7, and_rounds=4)
+    _compare(eng, cells, G, host.uniform_block(W, H, host.orbit_camera()), W, H, spp, rows=(520, 544) if G == 992 else None)
+    assert eng.info().grid_size == G
+
+
 def test_evolved_seed_volume(eng):
     # state after 30 steps of the default rule from the single seed (SURVEY 8(d) render input)
     G, W, H = 128, 480, 270
@@ -240,6 +250,52 @@ def test_derived_buffers_follow_the_state(eng):
         assert not np.array_equal(f1[0], fresh(b, 0, mode)[0])
 
 
+def test_state_written_through_a_device_pointer(eng):
+    """ca3d_device_buffer hands out a pointer the caller may write through (slab.SlabRenderer over the torch transports does: every
+    gather_volume() copies the new state into it, the full-grid engine never steps and nothing else tells it): every later frame must
+    show what is in the buffer NOW. Round 4's cache of the derived buffers keyed them on {serial, step, pointer}, the serial bumped
+    only when the pointer was handed out — the second and all later frames drew the first volume."""
+    from cellularautomatons3d_amd import Engine, slab
+
+    G, W, H = 64, 160, 90
+    u = host.uniform_block(W, H, host.orbit_camera())
+    a = host.random_fill(host.words_per_buffer(G), seed=41, and_rounds=3)
+    b = host.random_fill(host.words_per_buffer(G), seed=42, and_rounds=3)
+    sparse = host.initial_state(G)
+    eng.configure(G)
+    set_rules(eng, rules("default"))
+    eng.upload_state(a)
+    import torch
+
+    vol = slab.device_tensor(*eng.device_buffer(0), 0)
+    for mode in (False, True):
+        eng.set_render_mode(mode)
+        try:
+            for state in (a, b, sparse, b):
+                vol.copy_(torch.from_numpy(state.view(np.int32)).view(vol.dtype).reshape(vol.shape))
+                torch.cuda.synchronize()
+                if mode:
+                    eng.reset_render_history()
+                got = [x.copy() for x in eng.render(u, W, H, 1)]
+                again = eng.render(u, W, H, 1) if not mode else got
+                with Engine(0) as e2:
+                    e2.configure(G)
+                    set_rules(e2, rules("default"))
+                    e2.upload_state(state)
+                    e2.set_render_mode(mode)
+                    want = e2.render(u, W, H, 1)
+                for x, y, z in zip(got, want, again):
+                    np.testing.assert_array_equal(x.view(np.uint8), y.view(np.uint8))
+                    np.testing.assert_array_equal(z.view(np.uint8), y.view(np.uint8))
+        finally:
+            eng.set_render_mode(False)
+    # the pointer's validity ends with the next upload: frames of an unchanged state reuse the derived buffers again
+    eng.upload_state(a)
+    f1 = eng.render(u, W, H, 1)
+    f2 = eng.render(u, W, H, 1)
+    np.testing.assert_array_equal(f1[0], f2[0])
+
+
 def test_render_follows_step_parity(eng):
     # the render pass binds buffer [step % 2] (main_pathtraced.js:1788)
     G, W, H = 64, 96, 54
@@ -381,11 +437,11 @@ def test_literal_frame_mode_tracks_the_oracle(eng):
             pres, light, depth = eng.render(u, W, H, 1)
             ol_light, ol_depth, ol_pres = ol.render_frame(cells, G, u, W, H, pl, pd)
             pl, pd = ol_light.astype(np.float16).astype(np.float32), ol_depth.astype(np.float16).astype(np.float32)
-            ok = (np.abs(light.astype(np.float32)[..., :3] - pl[..., :3]).max(-1) <= 4e-3) & \
+            ok = (np.abs(light.astype(np.float32)[..., :3] - pl[..., :3]).max(-1) <= 2e-3) & \
                  (np.abs(depth.astype(np.float32)[..., 0] - pd[..., 0]) <= 2e-3)
-            assert ok.mean() >= 0.99, (f, ok.mean())
+            assert ok.mean() >= 0.999, (f, ok.mean())
         want8 = np.rint(np.clip(ol_pres, 0, 1) * 255.0)
-        assert (np.abs(pres.astype(np.float32) - want8).max(-1) <= 2).mean() >= 0.99
+        assert (np.abs(pres.astype(np.float32) - want8).max(-1) <= 1).mean() >= 0.999
         # and the accumulated frame sits on the converged one
         eng.set_render_mode(False)
         _, limit, _ = eng.render(host.uniform_block(W, H, vm), W, H, 1)
@@ -394,6 +450,89 @@ def test_literal_frame_mode_tracks_the_oracle(eng):
             eng.set_render_mode(True)
             eng.render(u, W, H, 4)
     finally:
+        eng.set_render_mode(False)
+
+
+def _moving_camera(f):
+    """A camera path that takes every branch of R6 / R10 (checked on the oracle side below): an orbit of 0.04 rad per frame (frames
+    0-9: reprojected uvs on screen, cell identity decides), a pan that puts most of the volume off screen (10), the pan back (11: the
+    points that come back into view reproject OUTSIDE [0,1]^2), a jump to a pose inside the volume (12) and a turn there (13)."""
+    if f < 10:
+        return host.orbit_camera(1.3, (1.0, 0.4, 0.0), 0.7 + 0.04 * f)
+    if f == 10:
+        return host.camera_matrix((0.1, 0.05, 1.2), (0, 1, 0), 0.85)
+    if f == 11:
+        return host.camera_matrix((0.1, 0.05, 1.2), (0, 1, 0), 0.1)
+    if f == 12:
+        return host.camera_matrix((0.15, 0.0, 0.45), (0, 1, 0), 0.0)
+    return host.camera_matrix((0.15, 0.02, 0.5), (0, 1, 0), 0.3)
+
+
+@pytest.mark.parametrize("G,W,H,seed", [(32, 160, 90, 11), (256, 640, 360, 0xCA3D0001), (96, 320, 180, 5)])
+def test_literal_frame_under_a_moving_camera(eng, G, W, H, seed):
+    """R6 / R10 with previous matrices that DIFFER from the current ones (main_pathtraced.js:504-524 writes them on every frame the
+    user moves, :858-969): getReprojectedUV (:473-487), the prevCameraPos reconstruction and the out-of-range-uv / cell-identity
+    branches of mixWithReprojectedColor (:429-471), estimateLikelyDepth's repair (:743-798). GPU and oracle run 14 frames in
+    lock-step, each on its own history; the oracle reports which branch every pixel took, and the test requires each branch to have
+    been taken by many pixels — with a static camera `uv outside` cannot fire. Both forms of the frame (statement by statement /
+    batched march over bricks; 96^3 = a grid that is not a power of two) must also agree bit for bit under motion.
+
+    The bar is R-par's (this file's header): >= 99.9 % of pixels within 2e-3 linear RGB and 2e-3 depth (one binary16 ulp of the stored
+    depth is 9.8e-4 above 1). Rounds 3-4 asked only for 99 % within 4e-3 and did not say what the rest was; counted here (and
+    printed): on the three cases NO pixel of the 14 frames is outside the tolerance — the march's decisions (sample cells, repairs,
+    blends) come out the same on both sides, the jitter hash included (both evaluate sin in double precision and round to f32:
+    render_device.inc n1rand, render_oracle.c n1rand). Should a pixel ever differ, it must be one where the two sides made a different
+    DECISION (its depth differs too), not one whose shading arithmetic drifted: asserted below."""
+    cells = host.random_fill(host.words_per_buffer(G), seed=seed, and_rounds=4)
+    eng.configure(G)
+    set_rules(eng, rules("default"))
+    eng.upload_state(cells)
+    eng.set_render_mode(True)
+    try:
+        frames = {}
+        for bricks in (0, 1):
+            eng.set_option("render_frame_bricks", bricks)
+            eng.render(host.uniform_block(W, H, _moving_camera(0)), W, H, 1)
+            eng.reset_render_history()
+            seq, prev = [], None
+            for f in range(14):
+                vm = _moving_camera(f)
+                u = host.uniform_block(W, H, vm, elapsed_time=0.1 + 0.137 * f, prev_view_mat=prev)
+                seq.append(eng.render(u, W, H, 1))
+                prev = vm
+            frames[bricks] = seq
+        for a, b in zip(frames[0], frames[1]):
+            for x, y in zip(a, b):
+                np.testing.assert_array_equal(x.view(np.uint8), y.view(np.uint8))
+        pl = pd = prev = None
+        taken = dict(repair=0, outside=0, differs=0, blended=0, blended_lit=0)
+        bad = decided = 0
+        for f in range(14):
+            vm = _moving_camera(f)
+            u = host.uniform_block(W, H, vm, elapsed_time=0.1 + 0.137 * f, prev_view_mat=prev)
+            prev = vm
+            ol_light, ol_depth, _, br = ol.render_frame(cells, G, u, W, H, pl, pd, branches=True)
+            pl, pd = ol_light.astype(np.float16).astype(np.float32), ol_depth.astype(np.float16).astype(np.float32)
+            _, light, depth = frames[1][f]
+            ok_rgb = np.abs(light.astype(np.float32)[..., :3] - pl[..., :3]).max(-1) <= 2e-3
+            ok_d = np.abs(depth.astype(np.float32)[..., 0] - pd[..., 0]) <= 2e-3
+            ok = ok_rgb & ok_d
+            assert ok.mean() >= 0.999, (f, ok.mean())
+            bad += int((~ok).sum())
+            decided += int((~ok_d).sum())
+            if f:
+                taken["repair"] += int(((br & ol.BRANCH_DEPTH_REPAIR) != 0).sum())
+                taken["outside"] += int(((br & ol.BRANCH_UV_OUTSIDE) != 0).sum())
+                taken["differs"] += int(((br & ol.BRANCH_CELL_DIFFERS) != 0).sum())
+                taken["blended"] += int(((br & ol.BRANCH_BLENDED) != 0).sum())
+                taken["blended_lit"] += int(((br & (ol.BRANCH_BLENDED | ol.BRANCH_LIT)) == (ol.BRANCH_BLENDED | ol.BRANCH_LIT)).sum())
+        px = W * H
+        assert taken["outside"] > 0.1 * px and taken["differs"] > px and taken["blended_lit"] > 0.1 * px and taken["repair"] > 0.005 * px, taken
+        print(f"moving camera {G}^3 {W}x{H}: branches {taken}; pixels outside the tolerance {bad} of {14 * px} "
+              f"({bad / (14 * px):.5f}), of them with another depth (a different march decision) {decided}")
+        assert decided >= 0.8 * bad or bad < 20, (bad, decided)
+    finally:
+        eng.set_option("render_frame_bricks", 1)
         eng.set_render_mode(False)
 
 
@@ -431,9 +570,9 @@ def test_literal_frame_batched_march_at_256(eng):
             ol_light, ol_depth, ol_pres = ol.render_frame(cells, G, u, W, H, pl, pd)
             pl, pd = ol_light.astype(np.float16).astype(np.float32), ol_depth.astype(np.float16).astype(np.float32)
             (pres, light, depth), _ = frames[1][f]
-            ok = (np.abs(light.astype(np.float32)[..., :3] - pl[..., :3]).max(-1) <= 4e-3) & \
+            ok = (np.abs(light.astype(np.float32)[..., :3] - pl[..., :3]).max(-1) <= 2e-3) & \
                  (np.abs(depth.astype(np.float32)[..., 0] - pd[..., 0]) <= 2e-3)
-            assert ok.mean() >= 0.99, (f, ok.mean())
+            assert ok.mean() >= 0.999, (f, ok.mean())
         assert pl[..., :3].max() > 0.05
     finally:
         eng.set_option("render_frame_bricks", 1)

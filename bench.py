@@ -396,6 +396,25 @@ def interactive_leg(eng, G, a, frames=200):
             out[name] = {"ms_per_frame": round(dt * 1e3 / frames, 4), "frames_per_second": round(frames / dt, 1), "last_render_kernel_ms": round(gpu_ms, 4),
                          "step_kernel": step_kernel,
                          "render_kernels": "ca_brick_volume + ca_render_frame_bricks (render_frame.hip)"}
+            if start is not None:
+                # the same loop while the user holds a key (main_pathtraced.js:858-969 move the camera, :504-524 write prevViewMat /
+                # prevProjViewMatInv != current): the camera orbits 0.01 rad per frame, every frame reprojects into the previous pose
+                cams = [host.orbit_camera(1.4, (1.0, 1.0, 0.0), 0.6 + 0.01 * i) for i in range(frames + 1)]
+                usm = [host.uniform_block(W, H, cams[i + 1], elapsed_time=0.5 + 0.016 * i, prev_view_mat=cams[i]) for i in range(frames)]
+                eng.reset_render_history()
+                for i in range(5):
+                    eng.step(1)
+                    eng.render(usm[i], W, H, 1, readback=False)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(frames):
+                    eng.step(1)
+                    eng.render(usm[i], W, H, 1, readback=False)
+                torch.cuda.synchronize()
+                dtm = time.perf_counter() - t0
+                out[name + "_moving_camera"] = {"ms_per_frame": round(dtm * 1e3 / frames, 4), "frames_per_second": round(frames / dtm, 1),
+                                                "last_render_kernel_ms": round(eng.render_stats().gpu_ms, 4),
+                                                "camera": "orbit, 0.01 rad per frame; prevViewMat / prevProjViewMatInv = the previous frame's"}
     finally:
         eng.set_render_mode(False)
     return out

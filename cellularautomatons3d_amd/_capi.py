@@ -47,6 +47,22 @@ class RenderStats(C.Structure):
     ]
 
 
+class JitStats(C.Structure):
+    _fields_ = [
+        ("programs_compiled", C.c_uint64), ("programs_from_disk", C.c_uint64), ("programs_from_memory", C.c_uint64),
+        ("compile_ms", C.c_double), ("disk_read_ms", C.c_double), ("load_ms", C.c_double), ("cache_dir", C.c_char * 256),
+    ]
+
+
+def jit_stats() -> dict:
+    """The run-time compiler's counters for this process (include/ca3d.h ca3d_jit_stats) as a dict."""
+    st = JitStats()
+    check(load().ca3d_get_jit_stats(C.byref(st)))
+    return {"programs_compiled": int(st.programs_compiled), "programs_from_disk": int(st.programs_from_disk),
+            "programs_from_memory": int(st.programs_from_memory), "compile_ms": round(st.compile_ms, 2),
+            "disk_read_ms": round(st.disk_read_ms, 2), "load_ms": round(st.load_ms, 2), "cache_dir": st.cache_dir.decode()}
+
+
 #: every symbol include/ca3d.h declares: (name, restype, argtypes)
 _u32p = C.POINTER(C.c_uint32)
 _i32p = C.POINTER(C.c_int32)
@@ -54,6 +70,8 @@ _H = C.c_void_p
 SYMBOLS = [
     ("ca3d_abi_version", C.c_int, []),
     ("ca3d_last_error", C.c_char_p, []),
+    ("ca3d_selftest_exception", C.c_int, [C.c_int]),
+    ("ca3d_get_jit_stats", C.c_int, [C.c_void_p]),
     ("ca3d_device_count", C.c_int, [C.POINTER(C.c_int)]),
     ("ca3d_create", C.c_int, [C.c_int, C.POINTER(_H)]),
     ("ca3d_destroy", C.c_int, [_H]),

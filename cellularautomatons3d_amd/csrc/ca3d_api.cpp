@@ -8,6 +8,7 @@
 #include <vector>
 #include <map>
 #include <new>
+#include <stdexcept>
 #include <string>
 
 #include "ca3d_internal.h"
@@ -17,16 +18,27 @@ using namespace ca3d;
 namespace
 {
 
-thread_local std::string g_last_error;
+// the message slot of ca3d_last_error(): a fixed buffer per thread — setting it never allocates, so it can be set while reporting
+// std::bad_alloc (a std::string here could throw from inside the handler that reports the failure)
+thread_local char g_last_error[1024] = "";
+
+void set_last_error(const char *msg) noexcept
+{
+	if (!msg) msg = "";
+	size_t n = strlen(msg);
+	if (n >= sizeof g_last_error) n = sizeof g_last_error - 1;
+	memmove(g_last_error, msg, n); // (msg may point into the slot itself)
+	g_last_error[n] = 0;
+}
 
 int fail(int code, const char *fmt, ...)
 {
-	char buf[512];
+	char buf[1024];
 	va_list ap;
 	va_start(ap, fmt);
 	vsnprintf(buf, sizeof buf, fmt, ap);
 	va_end(ap);
-	g_last_error = buf;
+	set_last_error(buf);
 	return code;
 }
 
@@ -46,13 +58,42 @@ namespace ca3d
 // for the other translation units of the library (ca3d_group.cpp): same message slot as every entry point here
 int set_error(int code, const char *fmt, ...)
 {
-	char buf[512];
+	char buf[1024];
 	va_list ap;
 	va_start(ap, fmt);
 	vsnprintf(buf, sizeof buf, fmt, ap);
 	va_end(ap);
-	g_last_error = buf;
+	set_last_error(buf);
 	return code;
+}
+
+// Every entry point of include/ca3d.h is a function-try-block (CA3D_API_TRY ... CA3D_API_CATCH, ca3d_internal.h) whose handler lands
+// here: the header promises status codes, and an exception leaving an extern "C" function called from Node.js / ctypes ends the
+// process. What can throw inside the library is host allocation (std::string / std::vector / std::map in the rule canonicaliser,
+// the run-time compiler, the group) and whatever the standard library reports as std::exception.
+int exception_to_status() noexcept
+{
+	try
+	{
+		throw;
+	}
+	catch (const std::bad_alloc &)
+	{
+		set_last_error("out of host memory (std::bad_alloc inside the library)");
+		return CA3D_ERR_OUT_OF_MEMORY;
+	}
+	catch (const std::exception &e)
+	{
+		char buf[1024];
+		snprintf(buf, sizeof buf, "internal error: %s", e.what());
+		set_last_error(buf);
+		return CA3D_ERR_DEVICE;
+	}
+	catch (...)
+	{
+		set_last_error("internal error: unknown C++ exception inside the library");
+		return CA3D_ERR_DEVICE;
+	}
 }
 } // namespace ca3d
 
@@ -448,8 +489,8 @@ void refresh_kernels(ca3d_engine *h)
 // kernel that exists for the rules but cannot be co-resident on this device / stream.
 void note_jit_failure(const ca3d_engine *h)
 {
-	if (!h->jit_log.empty()) g_last_error = "run-time kernel specialisation failed, pre-built kernels in use: " + h->jit_log;
-	else if (!h->res_note.empty()) g_last_error = h->res_note;
+	if (!h->jit_log.empty()) fail(0, "run-time kernel specialisation failed, pre-built kernels in use: %s", h->jit_log.c_str());
+	else if (!h->res_note.empty()) set_last_error(h->res_note.c_str());
 }
 
 int check_ready(ca3d_engine *h)
@@ -594,7 +635,7 @@ int check_resident(ca3d_engine *h)
 		total -= n;
 	}
 	HIP_TRY(hipStreamSynchronize(h->stream));
-	g_last_error = h->res_note;
+	set_last_error(h->res_note.c_str());
 	return CA3D_OK;
 }
 
@@ -821,9 +862,26 @@ extern "C"
 
 int ca3d_abi_version(void) { return CA3D_ABI_VERSION; }
 
-const char *ca3d_last_error(void) { return g_last_error.c_str(); }
+const char *ca3d_last_error(void) { return g_last_error; }
 
-int ca3d_device_count(int *out_count)
+// Test hook: throws inside a guarded body so that the exception boundary itself can be exercised without a GPU.
+// kind 0: std::bad_alloc, 1: std::runtime_error, 2: a non-std exception, 3: a real allocation failure (a vector of SIZE_MAX / 2 bytes)
+int ca3d_selftest_exception(int kind) CA3D_API_TRY
+{
+	if (kind == 0) throw std::bad_alloc();
+	if (kind == 1) throw std::runtime_error("selftest");
+	if (kind == 2) throw 42;
+	if (kind == 3)
+	{
+		std::vector<char> v;
+		v.resize(v.max_size() / 2u); // std::length_error or std::bad_alloc, whichever the allocator reports
+		return fail(CA3D_ERR_DEVICE, "selftest: the allocation of %zu bytes succeeded", v.size());
+	}
+	return CA3D_OK;
+}
+CA3D_API_CATCH
+
+int ca3d_device_count(int *out_count) CA3D_API_TRY
 {
 	if (!out_count) return fail(CA3D_ERR_INVALID_ARGUMENT, "out_count is NULL");
 	int n = 0;
@@ -832,8 +890,9 @@ int ca3d_device_count(int *out_count)
 	*out_count = n;
 	return CA3D_OK;
 }
+CA3D_API_CATCH
 
-int ca3d_create(int device, ca3d_t **out)
+int ca3d_create(int device, ca3d_t **out) CA3D_API_TRY
 {
 	if (!out) return fail(CA3D_ERR_INVALID_ARGUMENT, "out is NULL");
 	*out = nullptr;
@@ -865,8 +924,9 @@ int ca3d_create(int device, ca3d_t **out)
 	*out = h;
 	return CA3D_OK;
 }
+CA3D_API_CATCH
 
-int ca3d_destroy(ca3d_t *h)
+int ca3d_destroy(ca3d_t *h) CA3D_API_TRY
 {
 	if (!h) return CA3D_OK;
 	hipSetDevice(h->device);
@@ -895,6 +955,7 @@ int ca3d_destroy(ca3d_t *h)
 	delete h;
 	return CA3D_OK;
 }
+CA3D_API_CATCH
 
 static int configure_common(ca3d_t *h, uint32_t g, int layout)
 {
@@ -915,7 +976,7 @@ static int configure_common(ca3d_t *h, uint32_t g, int layout)
 	return CA3D_OK;
 }
 
-int ca3d_configure(ca3d_t *h, uint32_t gx, uint32_t gy, uint32_t gz, int layout)
+int ca3d_configure(ca3d_t *h, uint32_t gx, uint32_t gy, uint32_t gz, int layout) CA3D_API_TRY
 {
 	if (gx != gy || gy != gz) return fail(CA3D_ERR_UNSUPPORTED, "only cubic grids exist in the reference (got %ux%ux%u)", gx, gy, gz);
 	if (h) h->queued = 0; // steps of a state that is being thrown away
@@ -930,8 +991,9 @@ int ca3d_configure(ca3d_t *h, uint32_t gx, uint32_t gy, uint32_t gz, int layout)
 	if (rc == CA3D_OK) { refresh_kernels(h); note_jit_failure(h); }
 	return rc;
 }
+CA3D_API_CATCH
 
-int ca3d_configure_slab(ca3d_t *h, uint32_t g, int layout, uint32_t z0, uint32_t nz, uint32_t ghost)
+int ca3d_configure_slab(ca3d_t *h, uint32_t g, int layout, uint32_t z0, uint32_t nz, uint32_t ghost) CA3D_API_TRY
 {
 	if (h) h->queued = 0;
 	int rc = configure_common(h, g, layout);
@@ -948,10 +1010,11 @@ int ca3d_configure_slab(ca3d_t *h, uint32_t g, int layout, uint32_t z0, uint32_t
 	if (rc == CA3D_OK) { refresh_kernels(h); note_jit_failure(h); }
 	return rc;
 }
+CA3D_API_CATCH
 
 int ca3d_set_rules(ca3d_t *h, const int32_t *main_offsets, uint32_t n_main, const int32_t *edges_offsets, uint32_t n_edges,
                    const int32_t *corners_offsets, uint32_t n_corners, const uint32_t survive[CA3D_LUT_LEN],
-                   const uint32_t born[CA3D_LUT_LEN])
+                   const uint32_t born[CA3D_LUT_LEN]) CA3D_API_TRY
 {
 	if (!h) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL engine handle");
 	FLUSH_QUEUED(h); // the steps encoded so far run under the rules they were encoded with
@@ -968,8 +1031,9 @@ int ca3d_set_rules(ca3d_t *h, const int32_t *main_offsets, uint32_t n_main, cons
 	note_jit_failure(h);
 	return CA3D_OK;
 }
+CA3D_API_CATCH
 
-int ca3d_upload_state(ca3d_t *h, const uint32_t *words, size_t n_words)
+int ca3d_upload_state(ca3d_t *h, const uint32_t *words, size_t n_words) CA3D_API_TRY
 {
 	if (!h) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL engine handle");
 	if (!h->configured) return fail(CA3D_ERR_NOT_CONFIGURED, "ca3d_configure has not been called");
@@ -1016,8 +1080,9 @@ int ca3d_upload_state(ca3d_t *h, const uint32_t *words, size_t n_words)
 	}
 	return CA3D_OK;
 }
+CA3D_API_CATCH
 
-int ca3d_read_state(ca3d_t *h, uint32_t *words, size_t n_words)
+int ca3d_read_state(ca3d_t *h, uint32_t *words, size_t n_words) CA3D_API_TRY
 {
 	if (!h) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL engine handle");
 	if (!h->configured || !h->has_state) return fail(CA3D_ERR_NOT_CONFIGURED, "no state to read: configure and upload first");
@@ -1033,6 +1098,7 @@ int ca3d_read_state(ca3d_t *h, uint32_t *words, size_t n_words)
 	HIP_TRY(hipStreamSynchronize(h->stream));
 	return CA3D_OK;
 }
+CA3D_API_CATCH
 
 } // extern "C"
 
@@ -1098,7 +1164,7 @@ static int submit_steps(ca3d_engine *h, uint32_t n_steps)
 extern "C"
 {
 
-int ca3d_step(ca3d_t *h, uint32_t n_steps)
+int ca3d_step(ca3d_t *h, uint32_t n_steps) CA3D_API_TRY
 {
 	int rc = check_ready(h);
 	if (rc) return rc;
@@ -1114,12 +1180,14 @@ int ca3d_step(ca3d_t *h, uint32_t n_steps)
 	}
 	return submit_steps(h, n_steps);
 }
+CA3D_API_CATCH
 
-int ca3d_flush(ca3d_t *h)
+int ca3d_flush(ca3d_t *h) CA3D_API_TRY
 {
 	if (!h) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL engine handle");
 	return flush_queued(h);
 }
+CA3D_API_CATCH
 
 // Slab batch of n sub-steps, whole or in two phases (include/ca3d.h). Array planes: ghost [0,K), owned [K,K+nz),
 // ghost [K+nz, L). Sub-step s (1..n) of the whole batch updates [s, L-s). The phased form splits that range:
@@ -1225,16 +1293,21 @@ int slab_batch(ca3d_engine *h, uint32_t n_steps, int phase)
 	return CA3D_OK;
 }
 
-int ca3d_slab_step(ca3d_t *h, uint32_t n_steps) { return slab_batch(h, n_steps, CA3D_SLAB_PHASE_ALL); }
+int ca3d_slab_step(ca3d_t *h, uint32_t n_steps) CA3D_API_TRY
+{
+	return slab_batch(h, n_steps, CA3D_SLAB_PHASE_ALL);
+}
+CA3D_API_CATCH
 
-int ca3d_slab_step_phase(ca3d_t *h, uint32_t n_steps, int phase)
+int ca3d_slab_step_phase(ca3d_t *h, uint32_t n_steps, int phase) CA3D_API_TRY
 {
 	if (phase != CA3D_SLAB_PHASE_ALL && phase != CA3D_SLAB_PHASE_EDGES && phase != CA3D_SLAB_PHASE_INTERIOR)
 		return fail(CA3D_ERR_INVALID_ARGUMENT, "unknown slab phase %d", phase);
 	return slab_batch(h, n_steps, phase);
 }
+CA3D_API_CATCH
 
-int ca3d_slab_region(ca3d_t *h, int region, void **device_ptr, size_t *n_bytes)
+int ca3d_slab_region(ca3d_t *h, int region, void **device_ptr, size_t *n_bytes) CA3D_API_TRY
 {
 	if (!h || !device_ptr || !n_bytes) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL argument");
 	if (!h->configured || !h->slab) return fail(CA3D_ERR_NOT_CONFIGURED, "engine is not configured as a slab");
@@ -1255,8 +1328,9 @@ int ca3d_slab_region(ca3d_t *h, int region, void **device_ptr, size_t *n_bytes)
 	*n_bytes = count * pw * sizeof(uint32_t);
 	return CA3D_OK;
 }
+CA3D_API_CATCH
 
-int ca3d_comm_unique_id(void *id)
+int ca3d_comm_unique_id(void *id) CA3D_API_TRY
 {
 	if (!id) return fail(CA3D_ERR_INVALID_ARGUMENT, "id is NULL");
 	Rccl &r = rccl();
@@ -1264,8 +1338,9 @@ int ca3d_comm_unique_id(void *id)
 	NCCL_TRY(r.GetUniqueId(id));
 	return CA3D_OK;
 }
+CA3D_API_CATCH
 
-int ca3d_slab_comm_init(ca3d_t *h, const void *id, int rank, int world)
+int ca3d_slab_comm_init(ca3d_t *h, const void *id, int rank, int world) CA3D_API_TRY
 {
 	if (!h || !id) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL argument");
 	if (world < 1 || rank < 0 || rank >= world) return fail(CA3D_ERR_INVALID_ARGUMENT, "rank %d of %d", rank, world);
@@ -1288,8 +1363,9 @@ int ca3d_slab_comm_init(ca3d_t *h, const void *id, int rank, int world)
 	h->ghosts_valid = false;
 	return CA3D_OK;
 }
+CA3D_API_CATCH
 
-int ca3d_slab_exchange(ca3d_t *h)
+int ca3d_slab_exchange(ca3d_t *h) CA3D_API_TRY
 {
 	int rc = check_ready(h);
 	if (rc) return rc;
@@ -1300,8 +1376,9 @@ int ca3d_slab_exchange(ca3d_t *h)
 	if (rc == CA3D_OK) h->ghosts_valid = true;
 	return rc;
 }
+CA3D_API_CATCH
 
-int ca3d_slab_run(ca3d_t *h, uint32_t n_steps, int overlap)
+int ca3d_slab_run(ca3d_t *h, uint32_t n_steps, int overlap) CA3D_API_TRY
 {
 	int rc = check_ready(h);
 	if (rc) return rc;
@@ -1364,8 +1441,9 @@ int ca3d_slab_run(ca3d_t *h, uint32_t n_steps, int overlap)
 	(void)first;
 	return CA3D_OK;
 }
+CA3D_API_CATCH
 
-int ca3d_slab_gather(ca3d_t *h, ca3d_t *full)
+int ca3d_slab_gather(ca3d_t *h, ca3d_t *full) CA3D_API_TRY
 {
 	if (!h || !full) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL argument");
 	if (!h->slab || !h->comm || !h->has_state) return fail(CA3D_ERR_NOT_CONFIGURED, "engine is not a slab with a communicator and a state");
@@ -1400,8 +1478,9 @@ int ca3d_slab_gather(ca3d_t *h, ca3d_t *full)
 	full->state_serial++;
 	return CA3D_OK;
 }
+CA3D_API_CATCH
 
-int ca3d_render_target(ca3d_t *h, int which, void **device_ptr, size_t *n_bytes)
+int ca3d_render_target(ca3d_t *h, int which, void **device_ptr, size_t *n_bytes) CA3D_API_TRY
 {
 	if (!h || !device_ptr || !n_bytes) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL argument");
 	if (!h->r_present) return fail(CA3D_ERR_NOT_CONFIGURED, "ca3d_render has not been called yet");
@@ -1415,8 +1494,9 @@ int ca3d_render_target(ca3d_t *h, int which, void **device_ptr, size_t *n_bytes)
 	}
 	return CA3D_OK;
 }
+CA3D_API_CATCH
 
-int ca3d_synchronize(ca3d_t *h)
+int ca3d_synchronize(ca3d_t *h) CA3D_API_TRY
 {
 	if (!h) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL engine handle");
 	FLUSH_QUEUED(h);
@@ -1425,8 +1505,9 @@ int ca3d_synchronize(ca3d_t *h)
 	HIP_TRY(hipStreamSynchronize(h->stream));
 	return check_resident(h);
 }
+CA3D_API_CATCH
 
-int ca3d_measure_copy(ca3d_t *h, size_t n_bytes, uint32_t reps, double *gb_per_s)
+int ca3d_measure_copy(ca3d_t *h, size_t n_bytes, uint32_t reps, double *gb_per_s) CA3D_API_TRY
 {
 	if (!h || !gb_per_s) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL argument");
 	if (n_bytes < (1u << 20) || n_bytes % 16u || reps == 0 || reps > 4096u) return fail(CA3D_ERR_INVALID_ARGUMENT, "n_bytes must be a multiple of 16 of at least 1 MiB, reps in [1, 4096]");
@@ -1454,15 +1535,17 @@ int ca3d_measure_copy(ca3d_t *h, size_t n_bytes, uint32_t reps, double *gb_per_s
 	*gb_per_s = ms > 0.f ? 2.0 * (double)n_bytes * reps / (ms * 1e-3) / 1e9 : 0.0; // bytes read + bytes written
 	return CA3D_OK;
 }
+CA3D_API_CATCH
 
-int ca3d_recovered_launches(ca3d_t *h, uint32_t *out_count)
+int ca3d_recovered_launches(ca3d_t *h, uint32_t *out_count) CA3D_API_TRY
 {
 	if (!h || !out_count) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL argument");
 	*out_count = h->res_recovered;
 	return CA3D_OK;
 }
+CA3D_API_CATCH
 
-int ca3d_set_stream(ca3d_t *h, void *hip_stream)
+int ca3d_set_stream(ca3d_t *h, void *hip_stream) CA3D_API_TRY
 {
 	if (!h) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL engine handle");
 	FLUSH_QUEUED(h);
@@ -1479,8 +1562,9 @@ int ca3d_set_stream(ca3d_t *h, void *hip_stream)
 	note_jit_failure(h);
 	return CA3D_OK;
 }
+CA3D_API_CATCH
 
-int ca3d_use_own_stream(ca3d_t *h)
+int ca3d_use_own_stream(ca3d_t *h) CA3D_API_TRY
 {
 	if (!h) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL engine handle");
 	FLUSH_QUEUED(h);
@@ -1497,8 +1581,9 @@ int ca3d_use_own_stream(ca3d_t *h)
 	note_jit_failure(h);
 	return CA3D_OK;
 }
+CA3D_API_CATCH
 
-int ca3d_device_buffer(ca3d_t *h, int which, void **device_ptr, size_t *n_bytes)
+int ca3d_device_buffer(ca3d_t *h, int which, void **device_ptr, size_t *n_bytes) CA3D_API_TRY
 {
 	if (!h || !device_ptr || !n_bytes) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL argument");
 	if (!h->configured) return fail(CA3D_ERR_NOT_CONFIGURED, "ca3d_configure has not been called");
@@ -1511,8 +1596,9 @@ int ca3d_device_buffer(ca3d_t *h, int which, void **device_ptr, size_t *n_bytes)
 	h->buffers_exposed = true; // and again before every frame while the pointer is valid (ca3d_render)
 	return CA3D_OK;
 }
+CA3D_API_CATCH
 
-int ca3d_get_info(ca3d_t *h, ca3d_info *out)
+int ca3d_get_info(ca3d_t *h, ca3d_info *out) CA3D_API_TRY
 {
 	if (!h || !out) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL argument");
 	FLUSH_QUEUED(h);
@@ -1547,8 +1633,9 @@ int ca3d_get_info(ca3d_t *h, ca3d_info *out)
 		snprintf(out->kernel_name, sizeof out->kernel_name, "%s%s", name, class_jit ? "(jit)" : "");
 	return CA3D_OK;
 }
+CA3D_API_CATCH
 
-int ca3d_get_jit_log(ca3d_t *h, char *buf, size_t n_bytes, size_t *needed)
+int ca3d_get_jit_log(ca3d_t *h, char *buf, size_t n_bytes, size_t *needed) CA3D_API_TRY
 {
 	if (!h) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL engine handle");
 	if (needed) *needed = h->jit_log.size() + 1;
@@ -1560,8 +1647,17 @@ int ca3d_get_jit_log(ca3d_t *h, char *buf, size_t n_bytes, size_t *needed)
 	}
 	return CA3D_OK;
 }
+CA3D_API_CATCH
 
-int ca3d_get_kernel_variant(ca3d_t *h, char *buf, size_t n_bytes, size_t *needed)
+int ca3d_get_jit_stats(ca3d_jit_stats *out) CA3D_API_TRY
+{
+	if (!out) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL argument");
+	jit_stats(out);
+	return CA3D_OK;
+}
+CA3D_API_CATCH
+
+int ca3d_get_kernel_variant(ca3d_t *h, char *buf, size_t n_bytes, size_t *needed) CA3D_API_TRY
 {
 	if (!h) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL engine handle");
 	ca3d_info info;
@@ -1594,8 +1690,9 @@ int ca3d_get_kernel_variant(ca3d_t *h, char *buf, size_t n_bytes, size_t *needed
 	}
 	return CA3D_OK;
 }
+CA3D_API_CATCH
 
-int ca3d_get_stats(ca3d_t *h, ca3d_stats *out)
+int ca3d_get_stats(ca3d_t *h, ca3d_stats *out) CA3D_API_TRY
 {
 	if (!h || !out) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL argument");
 	FLUSH_QUEUED(h);
@@ -1610,9 +1707,10 @@ int ca3d_get_stats(ca3d_t *h, ca3d_stats *out)
 	HIP_TRY(hipStreamSynchronize(h->stream));
 	return check_resident(h);
 }
+CA3D_API_CATCH
 
 int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t height, uint32_t spp,
-                uint8_t *presentation_rgba8, uint16_t *light_rgba16f, uint16_t *depth_rg16f)
+                uint8_t *presentation_rgba8, uint16_t *light_rgba16f, uint16_t *depth_rg16f) CA3D_API_TRY
 {
 	if (!h) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL engine handle");
 	if (!h->configured || !h->has_state) return fail(CA3D_ERR_NOT_CONFIGURED, "no state to render: configure and upload first");
@@ -1791,8 +1889,9 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 	h->r_swap ^= 1;
 	return CA3D_OK;
 }
+CA3D_API_CATCH
 
-int ca3d_get_render_stats(ca3d_t *h, ca3d_render_stats *out)
+int ca3d_get_render_stats(ca3d_t *h, ca3d_render_stats *out) CA3D_API_TRY
 {
 	if (!h || !out) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL argument");
 	if (!h->rev_valid) return fail(CA3D_ERR_NOT_CONFIGURED, "ca3d_render has not been called yet");
@@ -1810,8 +1909,9 @@ int ca3d_get_render_stats(ca3d_t *h, ca3d_render_stats *out)
 	*out = h->rstats;
 	return CA3D_OK;
 }
+CA3D_API_CATCH
 
-int ca3d_set_option(ca3d_t *h, const char *name, int64_t value)
+int ca3d_set_option(ca3d_t *h, const char *name, int64_t value) CA3D_API_TRY
 {
 	if (!h || !name) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL argument");
 	FLUSH_QUEUED(h); // options apply to the steps encoded after them
@@ -2042,6 +2142,7 @@ int ca3d_set_option(ca3d_t *h, const char *name, int64_t value)
 	}
 	return fail(CA3D_ERR_INVALID_ARGUMENT, "unknown option '%s'", name);
 }
+CA3D_API_CATCH
 
 } // extern "C"
 

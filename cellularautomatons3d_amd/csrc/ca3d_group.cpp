@@ -155,7 +155,7 @@ void band_rows(uint32_t height, int world, int rank, uint32_t *y0, uint32_t *y1)
 extern "C"
 {
 
-int ca3d_group_create(const int *device_ids, int n_devices, ca3d_group_t **out)
+int ca3d_group_create(const int *device_ids, int n_devices, ca3d_group_t **out) CA3D_API_TRY
 {
 	if (!out) return set_error(CA3D_ERR_INVALID_ARGUMENT, "out is NULL");
 	*out = nullptr;
@@ -193,8 +193,9 @@ int ca3d_group_create(const int *device_ids, int n_devices, ca3d_group_t **out)
 	*out = g;
 	return CA3D_OK;
 }
+CA3D_API_CATCH
 
-int ca3d_group_destroy(ca3d_group_t *g)
+int ca3d_group_destroy(ca3d_group_t *g) CA3D_API_TRY
 {
 	if (!g) return CA3D_OK;
 	destroy_full(g);
@@ -208,23 +209,26 @@ int ca3d_group_destroy(ca3d_group_t *g)
 	delete g;
 	return CA3D_OK;
 }
+CA3D_API_CATCH
 
-int ca3d_group_size(ca3d_group_t *g, int *out_n)
+int ca3d_group_size(ca3d_group_t *g, int *out_n) CA3D_API_TRY
 {
 	if (!g || !out_n) return set_error(CA3D_ERR_INVALID_ARGUMENT, "NULL argument");
 	*out_n = P(g);
 	return CA3D_OK;
 }
+CA3D_API_CATCH
 
-int ca3d_group_engine(ca3d_group_t *g, int rank, ca3d_t **out)
+int ca3d_group_engine(ca3d_group_t *g, int rank, ca3d_t **out) CA3D_API_TRY
 {
 	if (!g || !out) return set_error(CA3D_ERR_INVALID_ARGUMENT, "NULL argument");
 	if (rank < 0 || rank >= P(g)) return set_error(CA3D_ERR_INVALID_ARGUMENT, "rank %d of %d", rank, P(g));
 	*out = g->eng[(size_t)rank];
 	return CA3D_OK;
 }
+CA3D_API_CATCH
 
-int ca3d_group_configure(ca3d_group_t *g, uint32_t grid_size, int layout, uint32_t ghost)
+int ca3d_group_configure(ca3d_group_t *g, uint32_t grid_size, int layout, uint32_t ghost) CA3D_API_TRY
 {
 	if (!g) return set_error(CA3D_ERR_INVALID_ARGUMENT, "NULL group handle");
 	const uint32_t n = (uint32_t)P(g);
@@ -246,9 +250,10 @@ int ca3d_group_configure(ca3d_group_t *g, uint32_t grid_size, int layout, uint32
 			                     (uint32_t)g->r_corners.size(), g->r_survive, g->r_born));
 	return CA3D_OK;
 }
+CA3D_API_CATCH
 
 int ca3d_group_set_rules(ca3d_group_t *g, const int32_t *main_offsets, uint32_t n_main, const int32_t *edges_offsets, uint32_t n_edges,
-                         const int32_t *corners_offsets, uint32_t n_corners, const uint32_t survive[CA3D_LUT_LEN], const uint32_t born[CA3D_LUT_LEN])
+                         const int32_t *corners_offsets, uint32_t n_corners, const uint32_t survive[CA3D_LUT_LEN], const uint32_t born[CA3D_LUT_LEN]) CA3D_API_TRY
 {
 	if (!g) return set_error(CA3D_ERR_INVALID_ARGUMENT, "NULL group handle");
 	for (ca3d_t *e : g->eng) G_TRY(ca3d_set_rules(e, main_offsets, n_main, edges_offsets, n_edges, corners_offsets, n_corners, survive, born));
@@ -261,8 +266,9 @@ int ca3d_group_set_rules(ca3d_group_t *g, const int32_t *main_offsets, uint32_t 
 	g->has_rules = true;
 	return CA3D_OK;
 }
+CA3D_API_CATCH
 
-int ca3d_group_upload_state(ca3d_group_t *g, const uint32_t *words, size_t n_words)
+int ca3d_group_upload_state(ca3d_group_t *g, const uint32_t *words, size_t n_words) CA3D_API_TRY
 {
 	G_TRY(check_group(g, false));
 	if (!words) return set_error(CA3D_ERR_INVALID_ARGUMENT, "words is NULL");
@@ -277,8 +283,9 @@ int ca3d_group_upload_state(ca3d_group_t *g, const uint32_t *words, size_t n_wor
 	g->step = 0;
 	return CA3D_OK;
 }
+CA3D_API_CATCH
 
-int ca3d_group_read_state(ca3d_group_t *g, uint32_t *words, size_t n_words)
+int ca3d_group_read_state(ca3d_group_t *g, uint32_t *words, size_t n_words) CA3D_API_TRY
 {
 	G_TRY(check_group(g, false));
 	if (!g->has_state) return set_error(CA3D_ERR_NOT_CONFIGURED, "no state to read: upload first");
@@ -291,8 +298,9 @@ int ca3d_group_read_state(ca3d_group_t *g, uint32_t *words, size_t n_words)
 	for (size_t k = 0; k < n; k++) G_TRY(ca3d_read_state(g->eng[k], words + k * per, per));
 	return CA3D_OK;
 }
+CA3D_API_CATCH
 
-int ca3d_group_step(ca3d_group_t *g, uint32_t n_steps)
+int ca3d_group_step(ca3d_group_t *g, uint32_t n_steps) CA3D_API_TRY
 {
 	G_TRY(check_group(g, true));
 	if (n_steps == 0) return CA3D_OK;
@@ -308,16 +316,18 @@ int ca3d_group_step(ca3d_group_t *g, uint32_t n_steps)
 	g->step += n_steps;
 	return CA3D_OK;
 }
+CA3D_API_CATCH
 
-int ca3d_group_synchronize(ca3d_group_t *g)
+int ca3d_group_synchronize(ca3d_group_t *g) CA3D_API_TRY
 {
 	if (!g) return set_error(CA3D_ERR_INVALID_ARGUMENT, "NULL group handle");
 	for (ca3d_t *e : g->eng) G_TRY(ca3d_synchronize(e));
 	for (ca3d_t *f : g->full) G_TRY(ca3d_synchronize(f));
 	return CA3D_OK;
 }
+CA3D_API_CATCH
 
-int ca3d_group_set_option(ca3d_group_t *g, const char *name, int64_t value)
+int ca3d_group_set_option(ca3d_group_t *g, const char *name, int64_t value) CA3D_API_TRY
 {
 	if (!g || !name) return set_error(CA3D_ERR_INVALID_ARGUMENT, "NULL argument");
 	if (!strcmp(name, "transport"))
@@ -336,13 +346,14 @@ int ca3d_group_set_option(ca3d_group_t *g, const char *name, int64_t value)
 		for (ca3d_t *f : g->full) G_TRY(ca3d_set_option(f, name, value));
 	return CA3D_OK;
 }
+CA3D_API_CATCH
 
 // The frame of the whole grid, shared between the GPUs: shadow rays cross slabs, so every rank gets the full
 // packed volume (peer copies of every slab's owned planes into a full-grid engine per rank), renders its band of image rows
 // ("replicas over pixels") and the bands land in the caller's buffers. A band is bit-identical to the same rows of a
 // single-GPU frame.
 int ca3d_group_render(ca3d_group_t *g, const float uniforms[128], uint32_t width, uint32_t height, uint32_t spp, uint8_t *presentation_rgba8,
-                      uint16_t *light_rgba16f, uint16_t *depth_rg16f)
+                      uint16_t *light_rgba16f, uint16_t *depth_rg16f) CA3D_API_TRY
 {
 	G_TRY(check_group(g, true));
 	if (g->layout != CA3D_LAYOUT_PACKED32) return set_error(CA3D_ERR_UNSUPPORTED, "the shared frame takes the packed layout");
@@ -448,5 +459,6 @@ int ca3d_group_render(ca3d_group_t *g, const float uniforms[128], uint32_t width
 	g->rh = height;
 	return CA3D_OK;
 }
+CA3D_API_CATCH
 
 } // extern "C"

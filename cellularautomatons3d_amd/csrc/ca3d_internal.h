@@ -262,6 +262,18 @@ hipError_t launch_unpacked_step(const UnpackedLaunch &l, hipStream_t stream, con
 
 // ca3d_api.cpp internals used by ca3d_group.cpp
 int set_error(int code, const char *fmt, ...);
+// No C++ exception leaves an extern "C" entry point: each one is `int ca3d_x(...) CA3D_API_TRY { ... } CA3D_API_CATCH` — a
+// function-try-block whose handler maps what was thrown to a status code and a ca3d_last_error() message (ca3d_api.cpp;
+// tests/test_capi_cpu.py checks that every function include/ca3d.h declares is defined this way, and runs the handler on the CPU
+// through ca3d_selftest_exception)
+int exception_to_status() noexcept;
+void jit_stats(ca3d_jit_stats *out); // ca_jit.cpp
+#define CA3D_API_TRY try
+#define CA3D_API_CATCH                          \
+	catch (...)                                 \
+	{                                           \
+		return ca3d::exception_to_status();     \
+	}
 int engine_device(const ca3d_engine *h);
 hipStream_t engine_stream(const ca3d_engine *h);
 int engine_mark_state(ca3d_engine *h); // both buffers zeroed on the engine's stream, "has a state" — for engines whose state arrives by device copies

@@ -828,10 +828,30 @@ static napi_value js_abi_version(napi_env env, napi_callback_info info)
 	return v;
 }
 
+/* ca3d_get_jit_stats: what the run-time compiler did in this process (compiled / read from the on-disk cache / already loaded) */
+static napi_value js_jit_stats(napi_env env, napi_callback_info info)
+{
+	(void)info;
+	ca3d_jit_stats st;
+	int rc = ca3d_get_jit_stats(&st);
+	if (rc != CA3D_OK) return throw_ca3d(env, rc);
+	napi_value o, s;
+	napi_create_object(env, &o);
+	set_num(env, o, "programsCompiled", (double)st.programs_compiled);
+	set_num(env, o, "programsFromDisk", (double)st.programs_from_disk);
+	set_num(env, o, "programsFromMemory", (double)st.programs_from_memory);
+	set_num(env, o, "compileMs", st.compile_ms);
+	set_num(env, o, "diskReadMs", st.disk_read_ms);
+	set_num(env, o, "loadMs", st.load_ms);
+	napi_create_string_utf8(env, st.cache_dir, NAPI_AUTO_LENGTH, &s);
+	napi_set_named_property(env, o, "cacheDir", s);
+	return o;
+}
+
 static napi_value init(napi_env env, napi_value exports)
 {
 	static const struct { const char *name; napi_callback fn; } fns[] = {
-	    {"abiVersion", js_abi_version}, {"deviceCount", js_device_count}, {"create", js_create}, {"destroy", js_destroy},
+	    {"abiVersion", js_abi_version}, {"jitStats", js_jit_stats}, {"deviceCount", js_device_count}, {"create", js_create}, {"destroy", js_destroy},
 	    {"configure", js_configure}, {"configureSlab", js_configure_slab}, {"setRules", js_set_rules},
 	    {"uploadState", js_upload_state}, {"readState", js_read_state}, {"step", js_step}, {"flush", js_flush}, {"slabStep", js_slab_step}, {"slabStepPhase", js_slab_step_phase},
 	    {"synchronize", js_synchronize}, {"info", js_info}, {"stats", js_stats}, {"render", js_render},

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define CA3D_ABI_VERSION 5 /* 5: + ca3d_get_kernel_variant */
+#define CA3D_ABI_VERSION 6 /* 5: + ca3d_get_kernel_variant; 6: + ca3d_selftest_exception, the kernel cache (ca3d_get_jit_log reports it) */
 #define CA3D_LUT_LEN 81 /* 3 rule-sets x 27 slots (main_pathtraced.js:10, 155-159) */
 
 typedef struct ca3d_engine ca3d_t;
@@ -45,6 +45,12 @@ enum ca3d_layout
 
 int ca3d_abi_version(void);
 const char *ca3d_last_error(void);
+/* No C++ exception crosses this boundary: every entry point catches what the library's internals throw (host allocation
+ * failures above all) and returns CA3D_ERR_OUT_OF_MEMORY for std::bad_alloc, CA3D_ERR_DEVICE for anything else, with the
+ * message in ca3d_last_error(). Test hook for exactly that path, usable without a GPU: throws inside a guarded body —
+ * kind 0 std::bad_alloc, 1 std::runtime_error, 2 a non-std exception, 3 a real oversized host allocation — and returns
+ * the status the boundary mapped it to (any other kind: CA3D_OK). */
+int ca3d_selftest_exception(int kind);
 int ca3d_device_count(int *out_count);
 
 /* navigator.gpu.requestAdapter / requestDevice (main_pathtraced.js:222-225). */
@@ -253,6 +259,26 @@ int ca3d_get_info(ca3d_t *h, ca3d_info *out);
  * receives the size including the terminator; the text is truncated to n_bytes.
  */
 int ca3d_get_jit_log(ca3d_t *h, char *buf, size_t n_bytes, size_t *needed);
+
+/*
+ * The run-time compiler's bookkeeping for THIS PROCESS (all engines): how many programs were compiled, how many came
+ * from the on-disk cache of code objects ($CA3D_CACHE_DIR, else $XDG_CACHE_HOME/ca3d, else $HOME/.cache/ca3d;
+ * CA3D_JIT_CACHE=0 turns it off; files are keyed on architecture, compiler version, options and the full program
+ * text, so they never go stale) and how many were already loaded, with the milliseconds each kind cost. A process
+ * that finds its rules in the cache compiles nothing: programs_compiled == 0 — `_restartSim` (main_pathtraced.js:
+ * 624-637) stays cheap from the second start on. Needs no engine.
+ */
+typedef struct ca3d_jit_stats
+{
+	uint64_t programs_compiled;    /* hiprtc compiles */
+	uint64_t programs_from_disk;   /* code objects read from the cache directory */
+	uint64_t programs_from_memory; /* requests answered by a module this process had loaded already */
+	double compile_ms;             /* inside hiprtc */
+	double disk_read_ms;           /* reading + verifying cached objects */
+	double load_ms;                /* hipModuleLoadData (+ writing new objects to the cache) */
+	char cache_dir[256];           /* "" when the disk cache is off or its directory cannot be created */
+} ca3d_jit_stats;
+int ca3d_get_jit_stats(ca3d_jit_stats *out);
 
 /*
  * Diagnostics (no reference counterpart): everything that decides WHICH instruction stream the next step batch runs, as one

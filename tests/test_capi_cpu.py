@@ -27,7 +27,30 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_abi_version():
-    assert _capi.load().ca3d_abi_version() == 5
+    assert _capi.load().ca3d_abi_version() == 6
+
+
+def test_no_exception_crosses_the_c_abi():
+    """include/ca3d.h promises status codes: a C++ exception leaving an extern "C" function ends a Node.js / ctypes host.
+    (a) the boundary itself, run on the CPU through the test hook: std::bad_alloc -> CA3D_ERR_OUT_OF_MEMORY, anything else ->
+    CA3D_ERR_DEVICE, message in ca3d_last_error(), and the process is still here; (b) every function the header declares is DEFINED as
+    a function-try-block with that handler (CA3D_API_TRY ... CA3D_API_CATCH), the two trivial getters excepted."""
+    lib = _capi.load()
+    assert lib.ca3d_selftest_exception(0) == -4 and b"bad_alloc" in lib.ca3d_last_error()
+    assert lib.ca3d_selftest_exception(1) == -3 and b"selftest" in lib.ca3d_last_error()
+    assert lib.ca3d_selftest_exception(2) == -3 and b"unknown C++ exception" in lib.ca3d_last_error()
+    assert lib.ca3d_selftest_exception(3) in (-3, -4) and lib.ca3d_last_error()  # a real oversized allocation
+    assert lib.ca3d_selftest_exception(9) == 0
+    src = ""
+    for f in ("ca3d_api.cpp", "ca3d_group.cpp"):
+        src += open(os.path.join(ROOT, "cellularautomatons3d_amd", "csrc", f)).read()
+    trivial = {"ca3d_abi_version", "ca3d_last_error"}  # return a constant / a pointer to a static buffer: nothing to throw
+    for name in _declared_symbols():
+        if name in trivial:
+            continue
+        m = re.search(r"^int " + name + r"\([^;{]*?\) CA3D_API_TRY\n\{\n.*?\n\}\nCA3D_API_CATCH\n", src, flags=re.S | re.M)
+        assert m, f"{name} is not defined behind the exception boundary"
+        assert "CA3D_API_TRY" not in m.group(0)[m.group(0).index("CA3D_API_TRY") + 12:], name  # the match is ONE function
 
 
 def test_no_cpu_fallback_when_no_gpu():

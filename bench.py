@@ -750,7 +750,10 @@ def main():
 
             se.run(a.verify_steps)
             got = core.read_state()
-            want = ol.packed_run(G, full, ol.Rules.from_strings(**rule_kw), a.verify_steps, max(1, min(os.cpu_count() or 1, 128) // world))
+            verify_threads = max(1, min(os.cpu_count() or 1, 128) // world)
+            t_or = time.perf_counter()
+            want = ol.packed_run(G, full, ol.Rules.from_strings(**rule_kw), a.verify_steps, verify_threads)
+            verify_seconds = time.perf_counter() - t_or
             flag = torch.tensor([1 if np.array_equal(got, want[se.z0 * pw:(se.z0 + se.nz) * pw]) else 0], dtype=torch.int32,
                                 device="cuda" if a.backend == "nccl" else "cpu")
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -794,6 +797,22 @@ def main():
         schedules = {"overlap_on" if first else "overlap_off": rec(dt, reps), "overlap_off" if first else "overlap_on": rec(dt_o, reps_o),
                      "headline": "overlap_on" if first else "overlap_off",
                      "why_headline": ("BASELINE configs[4] names the overlapped schedule" if a.config == 5 else "--overlap / slab.py's automatic choice")}
+    rccl_evidence = None
+    if world > 1:
+        # What the run really ran on, from the engines and the communicator themselves — not from WORLD_SIZE: every rank's HIP device, PCI
+        # bus id and (native transport) ncclCommCount / ncclCommUserRank / ncclCommCuDevice of the engine's RCCL communicator, gathered to
+        # rank 0. N ranks are N GPUs only if the N bus ids differ.
+        mine = dict(core.comm_info(), rank=rank, local_rank=local_rank, pid=os.getpid())
+        if not getattr(se, "native", False) and a.backend == "nccl":
+            mine["torch_backend"] = dist.get_backend()
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+        if rank == 0:
+            ids = [e["pci_bus_id"] for e in everyone]
+            rccl_evidence = {"ranks": world, "distinct_devices": len(set(ids)), "devices": everyone,
+                             "communicator": ("the engine's own (ca3d_slab_comm_init): counts below are ncclCommCount / ncclCommUserRank / ncclCommCuDevice"
+                                              if getattr(se, "native", False) else f"torch.distributed process group, backend {a.backend}"),
+                             "comm_ranks_agree": all(e["comm_ranks"] in (-1, world) for e in everyone)}
     multi_render = None
     if world > 1 and a.multi_render:
         multi_render = render_leg_multi(se, G, a, world, rank, barrier)
@@ -824,6 +843,8 @@ def main():
             ceiling = copy_ceiling_gbs(eng)
             out["copy_ceiling"] = {"value": round(ceiling, 1), "unit": "GB/s",
                                    "how": "1 GiB float4-per-lane device-to-device copy, non-temporal stores (ca3d_measure_copy), bytes read + bytes written per second, measured in this run"}
+        if rccl_evidence is not None:
+            out["rccl"] = rccl_evidence
         if schedules is not None:
             out["schedules"] = schedules
         if ok is not None:
@@ -833,7 +854,7 @@ def main():
             if not single_verified["oracle_match"]:
                 ok = False
         if verified is not None:
-            out["verified"] = {"oracle_match": verified, "steps": a.verify_steps,
+            out["verified"] = {"oracle_match": verified, "steps": a.verify_steps, "oracle_seconds": round(verify_seconds, 2), "oracle_threads_per_rank": verify_threads,
                                "how": "every rank's slab after this many steps (past one halo exchange) against the CPU oracle's full grid, before the timed region"}
             if not verified:
                 ok = False

@@ -47,6 +47,11 @@ class RenderStats(C.Structure):
     ]
 
 
+class CommInfo(C.Structure):
+    _fields_ = [("device", C.c_int32), ("comm_ranks", C.c_int32), ("comm_rank", C.c_int32), ("comm_device", C.c_int32),
+                ("pci_bus_id", C.c_char * 32)]
+
+
 class JitStats(C.Structure):
     _fields_ = [
         ("programs_compiled", C.c_uint64), ("programs_from_disk", C.c_uint64), ("programs_from_memory", C.c_uint64),
@@ -89,6 +94,7 @@ SYMBOLS = [
     ("ca3d_slab_comm_init", C.c_int, [_H, C.c_void_p, C.c_int, C.c_int]),
     ("ca3d_slab_run", C.c_int, [_H, C.c_uint32, C.c_int]),
     ("ca3d_slab_exchange", C.c_int, [_H]),
+    ("ca3d_slab_comm_info", C.c_int, [_H, C.c_void_p]),
     ("ca3d_slab_gather", C.c_int, [_H, _H]),
     ("ca3d_group_create", C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(_H)]),
     ("ca3d_group_destroy", C.c_int, [_H]),

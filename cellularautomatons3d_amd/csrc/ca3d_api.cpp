@@ -165,9 +165,7 @@ struct ca3d_engine
 	uint32_t queue_max = 0;               // > 0: ca3d_step calls are encoded and submitted together (option "queue")
 	uint32_t queued = 0;                  // steps encoded, not yet submitted
 	uint64_t launches_total = 0;          // kernel launches the step calls issued since ca3d_create
-	bool res_deep = false;                // 256^3 von Neumann form: two steps per hand-off (option "resident_deep")
 	bool res_pair = true;                 // 512^3 von Neumann form: the row-pair kernel (option "resident_pair"; 2.48 against 2.52 us per step)
-	bool res_stagger = false;             // ... its staggered form: the two z groups of a tile half a step apart (option "resident_stagger"; 2.36 against 2.35: off)
 	uint32_t res_rows = 32;               // rows per tile of the von Neumann form (ca_resident_kernel.inc: 32 or 16)
 	uint32_t res_zsplit = 1;              // thread groups along z of the von Neumann form (option "resident_zsplit"; 2 = twice the threads, four waves per
 	                                      // SIMD: measured SLOWER with 32-row tiles — 2.61 vs 2.52 us per step at 512^3, 1.37 vs 1.26 at 256^3 — and faster
@@ -358,8 +356,7 @@ int enqueue_step(ca3d_engine *h, int src, uint32_t lo, uint32_t hi, hipStream_t 
 // whenever rules, grid or the relevant options change — never from the step path (the WebGPU analogue is pipeline
 // creation). A failed compile leaves the ahead-of-time kernels in charge.
 // the 512^3 von Neumann form runs as the row-pair kernel (32-row tiles, one z group: its own geometry)
-bool vn_deep(const ca3d_engine *h) { return h->res_deep && h->G == 256u; }
-int vn_pair(const ca3d_engine *h) { return h->res_pair && h->G == 512u && h->res_rows == 32u && h->res_zsplit == 1u ? (h->res_stagger ? 2 : 1) : 0; } // 2: the staggered form; // another geometry asked for: the general form
+int vn_pair(const ca3d_engine *h) { return h->res_pair && h->G == 512u && h->res_rows == 32u && h->res_zsplit == 1u ? 1 : 0; } // another geometry asked for: the general form
 
 void select_kernels(ca3d_engine *h)
 {
@@ -445,7 +442,7 @@ void select_kernels(ca3d_engine *h)
 		h->vn_jit = j;
 		h->kernel_name = "ca_packed_vn(jit)";
 	}
-	if (resident && jit_resident_kernel(h->device, ls, lb, h->G == 256u ? 256u : h->res_rows, h->res_zsplit, vn_pair(h), vn_deep(h), &h->res_jit_fn, &h->jit_log) == CA3D_OK) h->res_ready = true;
+	if (resident && jit_resident_kernel(h->device, ls, lb, h->G == 256u ? 256u : h->res_rows, h->res_zsplit, vn_pair(h), &h->res_jit_fn, &h->jit_log) == CA3D_OK) h->res_ready = true;
 }
 
 // A resident launch only completes when ALL its workgroups are on the chip at once (they wait for each other's faces). Ask the
@@ -462,7 +459,7 @@ void check_residency(ca3d_engine *h)
 	if (h->res_ready)
 	{
 		const uint32_t rows = (h->res_class || h->G == 256u || vn_pair(h)) ? 32u : h->res_rows;
-		if (resident_capacity(h->G, rows, h->res_class ? resident_class_zsplit(h->G) : h->res_zsplit, h->res_class ? 0 : vn_pair(h), !h->res_class && vn_deep(h), h->res_jit_fn, h->stream, &tiles, &cap) && cap < tiles)
+		if (resident_capacity(h->G, rows, h->res_class ? resident_class_zsplit(h->G) : h->res_zsplit, h->res_class ? 0 : vn_pair(h), h->res_jit_fn, h->stream, &tiles, &cap) && cap < tiles)
 		{
 			h->res_ready = false;
 			h->res_class = false;
@@ -618,6 +615,18 @@ int check_resident(ca3d_engine *h)
 	h->cur = p.cur_before;
 	h->step = p.step_before;
 	h->state_serial++; // whatever the renderer derived from the buffers of the failed launches is void
+	{
+		// ... and so is what frames drawn in the meantime left behind: ca3d_render without host pointers does not wait for a pending
+		// resident launch (the frame loop must not stall on it), so a frame may have been drawn from the unwritten output of the launch
+		// that has now turned out to have failed — wrong once on screen, but in the literal mode it was also blended into the history
+		// surfaces and would linger for several frames (EMA, alpha 0.1). A fresh canvas instead.
+		const size_t px = (size_t)h->rw * h->rh;
+		for (int i = 0; i < 2 && px && h->r_light[i] && h->r_depth[i]; i++)
+		{
+			HIP_TRY(hipMemsetAsync(h->r_light[i], 0, px * 8, h->stream));
+			HIP_TRY(hipMemsetAsync(h->r_depth[i], 0, px * 4, h->stream));
+		}
+	}
 	HIP_TRY(hipMemsetAsync(h->res_mail, 0, h->res_mail_bytes, h->stream));
 	HIP_TRY(hipMemsetAsync(h->res_status, 0, kResStatusBytes, h->stream));
 	h->res_status_host[0] = h->res_status_host[1] = 0;
@@ -731,7 +740,6 @@ int resident_steps(ca3d_engine *h, uint32_t n)
 	l.rows = (h->res_class || vn_pair(h)) ? 32u : h->res_rows;
 	l.zsplit = h->res_class ? resident_class_zsplit(h->G) : h->res_zsplit;
 	l.pair = h->res_class ? 0 : vn_pair(h);
-	l.deep = !h->res_class && vn_deep(h);
 	hipError_t e = launch_resident(l, h->stream);
 	if (e != hipSuccess) return fail(CA3D_ERR_DEVICE, "resident kernel launch failed: %s", hipGetErrorString(e));
 	h->res_pending.push_back({h->res_epoch, n, h->cur, h->step, in, other, h->spare});
@@ -773,6 +781,9 @@ struct Rccl
 	int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
 	int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
 	int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+	int (*CommCount)(void *, int *) = nullptr;
+	int (*CommUserRank)(void *, int *) = nullptr;
+	int (*CommCuDevice)(void *, int *) = nullptr;
 	const char *(*GetErrorString)(int) = nullptr;
 	std::string error;
 };
@@ -799,6 +810,9 @@ Rccl &rccl()
 	r.Recv = (decltype(r.Recv))sym("ncclRecv");
 	r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
 	r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+	r.CommCount = (decltype(r.CommCount))sym("ncclCommCount");
+	r.CommUserRank = (decltype(r.CommUserRank))sym("ncclCommUserRank");
+	r.CommCuDevice = (decltype(r.CommCuDevice))sym("ncclCommCuDevice");
 	return r;
 }
 
@@ -1365,6 +1379,26 @@ int ca3d_slab_comm_init(ca3d_t *h, const void *id, int rank, int world) CA3D_API
 }
 CA3D_API_CATCH
 
+int ca3d_slab_comm_info(ca3d_t *h, ca3d_comm_info *out) CA3D_API_TRY
+{
+	if (!h || !out) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL argument");
+	memset(out, 0, sizeof *out);
+	out->comm_ranks = out->comm_rank = out->comm_device = -1;
+	out->device = h->device;
+	int rc = bind_device(h);
+	if (rc) return rc;
+	HIP_TRY(hipDeviceGetPCIBusId(out->pci_bus_id, (int)sizeof out->pci_bus_id, h->device));
+	if (h->comm)
+	{
+		// what the COMMUNICATOR says, not what the caller passed to ca3d_slab_comm_init
+		NCCL_TRY(rccl().CommCount(h->comm, &out->comm_ranks));
+		NCCL_TRY(rccl().CommUserRank(h->comm, &out->comm_rank));
+		NCCL_TRY(rccl().CommCuDevice(h->comm, &out->comm_device));
+	}
+	return CA3D_OK;
+}
+CA3D_API_CATCH
+
 int ca3d_slab_exchange(ca3d_t *h) CA3D_API_TRY
 {
 	int rc = check_ready(h);
@@ -1675,9 +1709,9 @@ int ca3d_get_kernel_variant(ca3d_t *h, char *buf, size_t n_bytes, size_t *needed
 	char text[320];
 	const bool res = !strncmp(info.kernel_name, "ca_resident", 11);
 	if (res)
-		snprintf(text, sizeof text, "%s;G=%u;rule=%016llx;rows=%u;zsplit=%u;pair=%d;deep=%d;rc256zs=%s;src=%016llx", info.kernel_name, h->G, (unsigned long long)rh,
+		snprintf(text, sizeof text, "%s;G=%u;rule=%016llx;rows=%u;zsplit=%u;pair=%d;rc256zs=%s;src=%016llx", info.kernel_name, h->G, (unsigned long long)rh,
 		         (h->res_class || vn_pair(h)) ? 32u : h->res_rows, h->res_class ? resident_class_zsplit(h->G) : h->res_zsplit, h->res_class ? 0 : vn_pair(h),
-		         !h->res_class && vn_deep(h) ? 1 : 0, zs ? zs : "-", (unsigned long long)jit_sources_hash());
+		         zs ? zs : "-", (unsigned long long)jit_sources_hash());
 	else
 		snprintf(text, sizeof text, "%s;G=%u;rule=%016llx;variant=%d;src=%016llx", info.kernel_name, h->G, (unsigned long long)rh, h->variant, (unsigned long long)jit_sources_hash());
 	const size_t len = strlen(text);
@@ -1831,6 +1865,9 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 		}
 		l.stream_scratch = h->r_stream;
 		l.stream_check = h->render_stream_check != 0;
+		// the check below reads the passes' control words after the frame: zero them here, for a frame whose stream passes do not run
+		// (volume off screen or outside the band) would otherwise report an earlier frame's counts — or, on fresh scratch, noise
+		if (l.stream_check) HIP_TRY(hipMemsetAsync(h->r_stream, 0, 4096, h->stream));
 	}
 	if (h->render_frame_bricks && frame_bricks_applies(h->G) && (h->render_mode == 1 || l.stream_scratch))
 	{
@@ -2045,21 +2082,6 @@ int ca3d_set_option(ca3d_t *h, const char *name, int64_t value) CA3D_API_TRY
 		}
 		return CA3D_OK;
 	}
-	if (!strcmp(name, "resident_deep"))
-	{
-		if (value != 0 && value != 1) return fail(CA3D_ERR_INVALID_ARGUMENT, "resident_deep must be 0 or 1");
-		if ((value != 0) != h->res_deep)
-		{
-			int rc2 = bind_device(h);
-			if (rc2) return rc2;
-			HIP_TRY(hipStreamSynchronize(h->stream));
-			free_resident(h); // another mailbox layout: start from clean ones
-			h->res_deep = value != 0;
-			refresh_kernels(h);
-			note_jit_failure(h);
-		}
-		return CA3D_OK;
-	}
 	if (!strcmp(name, "resident_pair"))
 	{
 		if (value != 0 && value != 1) return fail(CA3D_ERR_INVALID_ARGUMENT, "resident_pair must be 0 or 1");
@@ -2070,21 +2092,6 @@ int ca3d_set_option(ca3d_t *h, const char *name, int64_t value) CA3D_API_TRY
 			HIP_TRY(hipStreamSynchronize(h->stream));
 			free_resident(h); // the tiling may change with it (32-row tiles): start from clean mailboxes
 			h->res_pair = value != 0;
-			refresh_kernels(h);
-			note_jit_failure(h);
-		}
-		return CA3D_OK;
-	}
-	if (!strcmp(name, "resident_stagger"))
-	{
-		if (value != 0 && value != 1) return fail(CA3D_ERR_INVALID_ARGUMENT, "resident_stagger must be 0 or 1");
-		if ((value != 0) != h->res_stagger)
-		{
-			int rc2 = bind_device(h);
-			if (rc2) return rc2;
-			HIP_TRY(hipStreamSynchronize(h->stream));
-			free_resident(h);
-			h->res_stagger = value != 0;
 			refresh_kernels(h);
 			note_jit_failure(h);
 		}

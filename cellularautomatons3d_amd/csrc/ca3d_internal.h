@@ -124,8 +124,7 @@ struct ResidentLaunch
 	uint32_t rows = 32;            // rows per tile: 32 (one 512-thread workgroup per CU) or 16 (two 256-thread workgroups per CU)
 	uint32_t fault_tile = 0;       // diagnostics: tile + 1 that leaves at once (a workgroup that never became resident), 0: none
 	uint32_t zsplit = 1;           // thread groups along z: 2 = twice the threads per tile, four waves per SIMD (ca_resident_kernel.inc, ZS)
-	bool deep = false;             // 256^3 von Neumann form: two steps per hand-off (resident_deep_run); 256 threads per tile
-	int pair = 0;                  // 512^3 von Neumann form: a thread owns two adjacent rows x 16 planes; rows = 32, zsplit = 1. 1: resident_pair_run, 2: its staggered form (resident_stagger_run)
+	int pair = 0;                  // 512^3 von Neumann form: a thread owns two adjacent rows x 16 planes; rows = 32, zsplit = 1 (resident_pair_run)
 };
 
 struct UnpackedLaunch
@@ -183,7 +182,7 @@ hipError_t launch_copy_f4(const void *in, void *out, size_t bytes, hipStream_t s
 hipError_t launch_render(const RenderLaunch &l, hipStream_t stream);
 // render_stream.hip: bytes of scratch a frame of this size needs at most (and where its three arrays start); the passes themselves
 // (`params`: render.hip's launch parameters with the volume's screen rectangle filled in)
-size_t stream_scratch_bytes(uint32_t W, uint32_t H, uint32_t spp, size_t *hit_off, size_t *occl_off, size_t *rays_off);
+size_t stream_scratch_bytes(uint32_t W, uint32_t H, uint32_t spp, size_t *hit_off, size_t *occl_off, size_t *rays_off, size_t *pool_off = nullptr);
 // render_frame.hip: the literal frame over a bricked copy of the volume (`frame_params`: render.hip's FrameParams)
 size_t frame_bricks_bytes(uint32_t G);
 bool frame_bricks_applies(uint32_t G);
@@ -230,9 +229,9 @@ hipError_t launch_resident(const ResidentLaunch &l, hipStream_t stream);
 // Workgroups a resident launch of this shape needs (`tiles`) and how many of them the device can hold at once on `stream`
 // (occupancy of the kernel per CU x the CUs the stream may use): the launch only completes when capacity >= tiles.
 // Returns false when the runtime cannot tell (the caller then relies on the kernel's bounded waits alone).
-bool resident_capacity(uint32_t G, uint32_t rows, uint32_t zsplit, int pair, bool deep, void *jit_fn, hipStream_t stream, uint32_t *tiles, uint32_t *capacity);
+bool resident_capacity(uint32_t G, uint32_t rows, uint32_t zsplit, int pair, void *jit_fn, hipStream_t stream, uint32_t *tiles, uint32_t *capacity);
 bool resident_slab_capacity(void *fn, hipStream_t stream, uint32_t *tiles, uint32_t *capacity);
-int jit_resident_kernel(int device, uint32_t lut_s, uint32_t lut_b, uint32_t rows, uint32_t zsplit, int pair, bool deep, void **fn, std::string *log);
+int jit_resident_kernel(int device, uint32_t lut_s, uint32_t lut_b, uint32_t rows, uint32_t zsplit, int pair, void **fn, std::string *log);
 // the resident kernel for rules with diagonal neighbour classes (ca_resident_class_kernel.inc; 512^3 and 256^3, run-time compiled)
 bool resident_class_applies(const CanonRules &r, uint32_t G, int variant);
 int jit_resident_class_kernel(int device, const CanonRules &r, uint32_t G, uint32_t zsplit, void **fn, std::string *log); // G: 512 (zsplit 1) or 256 (2 | 1)

@@ -97,7 +97,7 @@ uint32_t resident_class_zsplit(uint32_t G)
 
 size_t resident_mail_bytes(uint32_t G, uint32_t rows)
 {
-	if (G == 256u) return 2u * (size_t)256u * 4u * 512u * sizeof(unsigned long long); // 256 tiles, faces of up to 512 words (the two-deep faces of resident_deep_run)
+	if (G == 256u) return 2u * (size_t)256u * 4u * 512u * sizeof(unsigned long long); // 256 tiles, faces of up to 512 words (sized for the widest face any 256^3 form publishes)
 	const size_t tiles = (size_t)(G / rows) * (G / kResTileRows);
 	return 2u * tiles * 4u * kResFaceWords * sizeof(unsigned long long);
 }
@@ -135,7 +135,7 @@ uint32_t usable_cus(hipStream_t stream)
 }
 } // namespace
 
-bool resident_capacity(uint32_t G, uint32_t rows, uint32_t zsplit, int pair, bool deep, void *jit_fn, hipStream_t stream, uint32_t *tiles, uint32_t *capacity)
+bool resident_capacity(uint32_t G, uint32_t rows, uint32_t zsplit, int pair, void *jit_fn, hipStream_t stream, uint32_t *tiles, uint32_t *capacity)
 {
 
 	if (pair) { rows = 32u; zsplit = 1u; } // the row-pair form: the tiles and the 512 threads of the 32-row form
@@ -146,8 +146,7 @@ bool resident_capacity(uint32_t G, uint32_t rows, uint32_t zsplit, int pair, boo
 	int per_cu = 0;
 	hipError_t e;
 	if (jit_fn) e = hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (hipFunction_t)jit_fn, (int)threads, 0);
-	else if (deep) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, z2 ? (const void *)ca_resident_vn256_deep<kDefaultS, kDefaultB, 2> : (const void *)ca_resident_vn256_deep<kDefaultS, kDefaultB, 1>, (int)threads, 0);
-	else if (pair) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pair == 2 ? (const void *)ca_resident_vn_stagger<kDefaultS, kDefaultB> : (const void *)ca_resident_vn_pair<kDefaultS, kDefaultB>, (int)threads, 0);
+	else if (pair) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)ca_resident_vn_pair<kDefaultS, kDefaultB>, (int)threads, 0);
 	else if (G == 256u) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, z2 ? (const void *)ca_resident_vn256<kDefaultS, kDefaultB, 2> : (const void *)ca_resident_vn256<kDefaultS, kDefaultB, 1>, (int)threads, 0);
 	else if (rows == 16u) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, z2 ? (const void *)ca_resident_vn<kDefaultS, kDefaultB, 16, 2> : (const void *)ca_resident_vn<kDefaultS, kDefaultB, 16, 1>, (int)threads, 0);
 	else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, z2 ? (const void *)ca_resident_vn<kDefaultS, kDefaultB, 32, 2> : (const void *)ca_resident_vn<kDefaultS, kDefaultB, 32, 1>, (int)threads, 0);
@@ -202,20 +201,6 @@ hipError_t launch_resident(const ResidentLaunch &l, hipStream_t stream)
 	a.fault_tile = l.fault_tile;
 	const bool z2 = l.zsplit == 2u;
 	if (l.zsplit != 1u && l.zsplit != 2u && !(l.zsplit == 4u && l.G == 256u && l.jit_fn)) return hipErrorInvalidValue;
-	if (l.G == 256u && l.deep)
-	{
-		if (l.jit_fn)
-		{
-			void *args[] = {(void *)&a};
-			return chained_launch(stream, [&]() { return hipModuleLaunchKernel((hipFunction_t)l.jit_fn, 256, 1, 1, 256u * l.zsplit, 1, 1, 0, stream, args, nullptr); });
-		}
-		if (l.lut_s != (u32)kDefaultS || l.lut_b != (u32)kDefaultB) return hipErrorInvalidValue;
-		return chained_launch(stream, [&]() {
-			if (z2) hipLaunchKernelGGL((ca_resident_vn256_deep<kDefaultS, kDefaultB, 2>), dim3(256), dim3(512), 0, stream, a);
-			else hipLaunchKernelGGL((ca_resident_vn256_deep<kDefaultS, kDefaultB, 1>), dim3(256), dim3(256), 0, stream, a);
-			return hipGetLastError();
-		});
-	}
 	if (l.G == 256u)
 	{
 		// 8 x 32 tiles of 32 rows x 8 planes, 256 (x 2 with the z split) threads each (ca_resident_kernel.inc: CW = 8, PZ = 8)
@@ -242,8 +227,7 @@ hipError_t launch_resident(const ResidentLaunch &l, hipStream_t stream)
 		}
 		if (l.lut_s != (u32)kDefaultS || l.lut_b != (u32)kDefaultB) return hipErrorInvalidValue;
 		return chained_launch(stream, [&]() {
-			if (l.pair == 2) hipLaunchKernelGGL((ca_resident_vn_stagger<kDefaultS, kDefaultB>), dim3(256), dim3(512), 0, stream, a);
-			else hipLaunchKernelGGL((ca_resident_vn_pair<kDefaultS, kDefaultB>), dim3(256), dim3(512), 0, stream, a);
+			hipLaunchKernelGGL((ca_resident_vn_pair<kDefaultS, kDefaultB>), dim3(256), dim3(512), 0, stream, a);
 			return hipGetLastError();
 		});
 	}

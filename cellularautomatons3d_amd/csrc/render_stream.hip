@@ -60,6 +60,12 @@ struct StreamParams
 	const u32 *volume;   // what the walks read: R.cells, or the bricked copy of it
 	u32 lg, lc;          // log2 G, log2 cols (power-of-two grids)
 	u32 nb;              // bricks per edge, G / 8
+	u32 probe_mask;      // timing probes (kProbe*): 0
+	u32 *pool;           // ca_stream_walk2: walk states a wave of the first launch hands to the drain launch, kPoolWords words each, kPoolCap of them
+	u32 drain_wgs;       // workgroups of the drain launch
+	int dump_at;         // ... a wave that cannot refill any more hands its walks over when this many lanes or fewer still walk (0: never)
+	int flat;            // ca_stream_walk2: 1 = the branch-free cell step (walk_cell_flat), 0 = walk_cell (tuning: CA3D_STREAM_FLAT)
+	int refill2;         // ca_stream_walk2: idle lanes at which a wave leaves the stepping loop to pop prepared rays (tuning: CA3D_STREAM_POP)
 	int refill;          // lanes without a ray at which a wave leaves the stepping loop to take new jobs (tuning: CA3D_STREAM_REFILL)
 	u32 lb;              // log2 of a chunk's pixel-block edge; jobs per chunk = spp << (2 lb)
 	u32 qmap;            // 0: queue q owns a contiguous eighth of the chunks (a band of the image); 1: every eighth chunk
@@ -166,7 +172,10 @@ struct Walker
 // 2.32, bricks 0.80 / 1.98, bricks + a read per cell 0.785 / 1.94; a whole 8 x 8 z-slice per lane in two registers 0.805 / 2.11.
 // kBricksReadAny: the same over the bricks of a grid that is not a power of two (96, 160, ..., 992): G / 8 bricks per edge, the brick index by
 // two 24-bit multiply-adds (full rate) instead of shifts.
-enum { kRowsP2 = 0, kRowsAny = 1, kBricks = 2, kBricksRead = 3, kBricksReadAny = 4 };
+// kProbe*: timing probes of the stepping loop (CA3D_STREAM_PROBE=1..4; the frame is garbage: no cell is ever taken for live, every walk runs to
+// the end of the volume, so the four differ ONLY in what the read costs): no read at all / every lane reads word 0 (one cache line per
+// wave-level read) / word key & 1023 (a 4 KiB footprint, as many lines per read as the real walk) / the real word.
+enum { kRowsP2 = 0, kRowsAny = 1, kBricks = 2, kBricksRead = 3, kBricksReadAny = 4, kProbeNone = 5, kProbeSame = 6, kProbeSmall = 7, kProbeFull = 8 };
 
 template <int LAYOUT>
 __device__ __forceinline__ int word_key(const StreamParams &S, int ix, int iy, int iz)
@@ -176,7 +185,7 @@ __device__ __forceinline__ int word_key(const StreamParams &S, int ix, int iy, i
 		const u32 b = __umul24(__umul24((u32)iz >> 3, S.nb) + ((u32)iy >> 3), S.nb) + ((u32)ix >> 3); // nb <= 256: under 2^24
 		return (int)((b << 4) + (((u32)iz & 7u) << 1) + (((u32)iy & 7u) >> 2));
 	}
-	if (LAYOUT == kBricks || LAYOUT == kBricksRead)
+	if (LAYOUT == kBricks || LAYOUT == kBricksRead || LAYOUT >= kProbeNone)
 	{
 		const u32 lnb = S.lg - 3u;
 		const u32 b = (((((u32)iz >> 3) << lnb) + ((u32)iy >> 3)) << lnb) + ((u32)ix >> 3);
@@ -188,7 +197,7 @@ __device__ __forceinline__ int word_key(const StreamParams &S, int ix, int iy, i
 template <int LAYOUT>
 __device__ __forceinline__ u32 word_bit(int ix, int iy)
 {
-	return (LAYOUT == kBricks || LAYOUT == kBricksRead || LAYOUT == kBricksReadAny) ? (((u32)ix & 7u) | (((u32)iy & 3u) << 3)) : ((u32)ix & 31u);
+	return (LAYOUT == kBricks || LAYOUT == kBricksRead || LAYOUT == kBricksReadAny || LAYOUT >= kProbeNone) ? (((u32)ix & 7u) | (((u32)iy & 3u) << 3)) : ((u32)ix & 31u);
 }
 
 // walk_begin of render.hip / the head of walk(): first cell, boundary times, increments
@@ -251,7 +260,13 @@ __device__ __forceinline__ int walk_cell(const StreamParams &S, Walker &w, int k
 	const RenderParams &P = S.R;
 	// (a 32-bit byte offset from the scalar base: one shift instead of a sign extension and a 64-bit add per visit)
 	u32 cur;
-	if (LAYOUT == kBricksRead || LAYOUT == kBricksReadAny) cur = *reinterpret_cast<const u32 *>(reinterpret_cast<const char *>(S.volume) + ((u32)key << 2));
+	if (LAYOUT >= kProbeNone)
+	{
+		const u32 k2 = LAYOUT == kProbeSame ? 0u : (LAYOUT == kProbeSmall ? ((u32)key & 1023u) : (u32)key);
+		cur = LAYOUT == kProbeNone ? (u32)key : *reinterpret_cast<const u32 *>(reinterpret_cast<const char *>(S.volume) + (k2 << 2));
+		cur &= S.probe_mask; // 0 at run time: the compiler cannot drop the read, and no cell is live
+	}
+	else if (LAYOUT == kBricksRead || LAYOUT == kBricksReadAny) cur = *reinterpret_cast<const u32 *>(reinterpret_cast<const char *>(S.volume) + ((u32)key << 2));
 	else
 	{
 		if (LOAD && key != w.wkey) { w.word = *reinterpret_cast<const u32 *>(reinterpret_cast<const char *>(S.volume) + ((u32)key << 2)); w.wkey = key; }
@@ -296,6 +311,49 @@ __device__ __forceinline__ int walk_cell(const StreamParams &S, Walker &w, int k
 	// only: at G = 96 the cell (64, 32, z) reads as outside — a tenth of the pixels of a 96^3 frame were wrong until round 5 tested one)
 	const bool outside = max(max((u32)w.ix, (u32)w.iy), (u32)w.iz) >= P.G;
 	return (outside || t >= w.tmax) ? 2 : 0;
+}
+
+// One cell for EVERY lane of the wave, without a divergent branch (round 5, ca_stream_walk2). walk_cell compiles to a nest of exec-mask
+// regions — walking lanes / live cell / filter undecided / advance — each a v_cmp -> s_and_saveexec -> s_cbranch chain, eight branches
+// per cell; measured, a wave ALONE on a SIMD took ~2 000 cycles per cell with them (the drain launch: one wave per SIMD, 0.85 us per
+// iteration for ~70 instructions), which is what the tail of every walk launch runs at. Here every lane computes the filter and the
+// advance of its last state and selects keep what must not change: lanes that do not walk read word 0, take no hit and advance by
+// nothing (their axis masks are empty). Only the slab test of the filter's undecided band (1 % of live cells) stays behind a branch,
+// wave-uniform. The float operations of a walking lane are walk_cell's, in the same order.
+template <bool SHADOW, int LAYOUT>
+__device__ __forceinline__ void walk_cell_flat(const StreamParams &S, Walker &w, bool active, bool &exempt, int &term, v3 vhalf, float k0, float k1, float eps_a,
+                                               const float *ctx, int stride)
+{
+	const RenderParams &P = S.R;
+	const int key = active ? word_key<LAYOUT>(S, w.ix, w.iy, w.iz) : 0; // (a lane whose walk left the grid holds a cell outside it)
+	const u32 cur = *reinterpret_cast<const u32 *>(reinterpret_cast<const char *>(S.volume) + ((u32)key << 2));
+	const bool live = active && ((cur >> word_bit<LAYOUT>(w.ix, w.iy)) & 1u) && !exempt;
+	const float tn = fmaxf(fmaxf(__builtin_fmaf(-k1, w.dx, w.tx), __builtin_fmaf(-k1, w.dy, w.ty)), __builtin_fmaf(-k1, w.dz, w.tz));
+	const float tf = fminf(fminf(__builtin_fmaf(-k0, w.dx, w.tx), __builtin_fmaf(-k0, w.dy, w.ty)), __builtin_fmaf(-k0, w.dz, w.tz));
+	const float gap = tf - tn, lead = SHADOW ? tn : tf;
+	const float eps = __builtin_fmaf(__builtin_fmaf(eps_a, w.t, 3.814697265625e-6f), w.t, w.eps_b);
+	const bool yes = gap > eps && lead > eps, no = gap < -eps || lead < -eps;
+	bool hit = live && yes;
+	const bool undecided = live && !yes && !no;
+	if (__ballot(undecided) != 0ull)
+	{
+		float e;
+		if (undecided) hit = slab_test<SHADOW>(P, w, vhalf, ctx, stride, e);
+	}
+	const bool adv = active && !hit;
+	const float t = fminf(fminf(w.tx, w.ty), w.tz);
+	const bool ex = w.tx == t, ey = !ex && w.ty == t;
+	const bool mx = adv && ex, my = adv && ey, mz = adv && !ex && !ey;
+	w.t = adv ? t : w.t;
+	w.tx += mx ? w.dx : 0.0f;
+	w.ty += my ? w.dy : 0.0f;
+	w.tz += mz ? w.dz : 0.0f;
+	w.ix += mx ? w.sx : 0;
+	w.iy += my ? w.sy : 0;
+	w.iz += mz ? w.sz : 0;
+	exempt = exempt && !adv;
+	const bool over = max(max((u32)w.ix, (u32)w.iy), (u32)w.iz) >= P.G || t >= w.tmax;
+	term = hit ? 1 : ((adv && over) ? 2 : term);
 }
 
 // ---- the batched form of the stepping loop -----------------------------------------------------------------------------------
@@ -660,6 +718,420 @@ __global__ __launch_bounds__(kWalkThreads, kStreamWaves) void ca_stream_walk(Str
 	if (lane == 0 && visits) atomicAdd(&S.ctl[16 + 4 * ((blockIdx.x * (u32)kWalkWaves + (u32)wave) % kStatSlots) + (SHADOW ? 2 : 1)], visits);
 }
 
+// ---- second form of the walk passes (round 5): ray set-up at FULL lane occupancy, prepared rays queued in LDS ---------------------
+// What ca_stream_walk's time is made of was measured this round by taking the volume out of its stepping loop (CA3D_STREAM_PROBE: no
+// read / every lane the same word / a 4 KiB footprint / the real words — 2.34 / 1.91 / 2.40 / 2.39 ms for the same 967 M cell visits
+// with no cell ever live): the loop does not wait for memory at all, it is bound by instruction issue (~65 instructions per wave and
+// cell at 2.2 cycles each with eight waves on a SIMD) and runs at 0.42 visits per ns when its lanes are full. The real frame's
+// 123 M visits would take 0.29 ms at that rate; they take 0.69. The rest is what surrounds the loop: a refill round sets up
+// ~24 new rays with the other 40 lanes of the wave idle (~900 instructions, 25 divisions: 28 % of a wave's life), the loop runs
+// between refills with up to 24 lanes empty, and three of four tickets of the shadow pass are samples without a shadow ray. Here
+//   * a wave sets rays up 64 AT A TIME — every lane, walking or not, takes a job and forms its ray (the walkers in flight stay in
+//     their registers) — and the prepared walk states go into a 64-slot queue of the wave in LDS (16 words per ray);
+//   * a lane whose walk ends POPS a prepared state (16 LDS reads instead of the set-up), so the loop is left already when 8 lanes
+//     are idle instead of 24;
+//   * the shadow pass first gathers the ids of samples that HAVE a shadow ray (one 32-bit read of four flags per ticket, compacted
+//     into an id list in LDS) and only then sets 64 of them up, again on every lane.
+// Same job source (chunks -> workgroup ticket counter -> ring of chunk ids), same stepping loop, same arithmetic per ray and cell:
+// the frame is ca_stream_walk's bit for bit (tests/test_gpu_render.py compares plain kernel = in-wave kernel = both stream forms).
+constexpr int kW2Threads = 256, kW2Waves = kW2Threads / 64, kW2PerSimd = 5, kIdCap = 320, kRecWords = 17;
+// The drain. A ray that meets nothing crosses the whole volume — 120 to 200 cells where the average walk ends after 9 — and one ray in twelve
+// of the bench scene does. When the queues run dry every wave is left with a handful of them: it steps on for a hundred and more
+// iterations with 5 of its 64 lanes alive, and since the stepping loop is bound by instruction issue, eight such waves on a SIMD
+// cost what eight full ones cost: the launches spent 45 % of their time in that tail (tools/stream_trace.py: every wave alive for the
+// first 55 % of a launch, mean life 0.68 of it). A wave that can no longer refill and is down to `dump_at` walking lanes therefore
+// writes its walk states (the queue's record plus the walk's current time: kPoolWords words) to a pool in memory and ends; a second,
+// small launch of the same kernel (DRAIN) takes them 64 to a wave and walks them to their ends with full lanes.
+constexpr u32 kPoolWords = 20, kPoolCap = 1u << 19; // (80-byte records; 8 192 waves x 64 lanes would fit)
+constexpr u32 kPoolCtl = 8; // ctl words [kPoolCtl + 4 * pass + {0 records written, 1 records taken}]
+
+// walker_begin without the LDS writes: the walk state in `w`, what the slab test reads in c6
+__device__ __forceinline__ void walker_prepare(const RenderParams &P, Walker &w, bool &axis_parallel, float c6[6], v3 start, v3 dir, float t0, float tmax)
+{
+	const int G = (int)P.G;
+	const float cs = 1.0f / (float)P.G;
+	const v3 p = start + dir * t0;
+	int ix = (int)floorf(to_cells(P, p.x)), iy = (int)floorf(to_cells(P, p.y)), iz = (int)floorf(to_cells(P, p.z));
+	ix = min(max(ix, 0), G - 1);
+	iy = min(max(iy, 0), G - 1);
+	iz = min(max(iz, 0), G - 1);
+	const int sx = dir.x > 0.0f ? 1 : -1, sy = dir.y > 0.0f ? 1 : -1, sz = dir.z > 0.0f ? 1 : -1;
+	const float big = 3.0e38f;
+	w.tx = dir.x != 0.0f ? (((float)(ix + (sx > 0 ? 1 : 0)) * cs - kHalf) - start.x) / dir.x : big;
+	w.ty = dir.y != 0.0f ? (((float)(iy + (sy > 0 ? 1 : 0)) * cs - kHalf) - start.y) / dir.y : big;
+	w.tz = dir.z != 0.0f ? (((float)(iz + (sz > 0 ? 1 : 0)) * cs - kHalf) - start.z) / dir.z : big;
+	w.dx = dir.x != 0.0f ? cs / fabsf(dir.x) : big;
+	w.dy = dir.y != 0.0f ? cs / fabsf(dir.y) : big;
+	w.dz = dir.z != 0.0f ? cs / fabsf(dir.z) : big;
+	w.t = t0;
+	w.tmax = tmax;
+	w.ix = ix; w.iy = iy; w.iz = iz;
+	w.sx = sx; w.sy = sy; w.sz = sz;
+	w.word = 0;
+	w.wkey = -1;
+	axis_parallel = dir.x == 0.0f || dir.y == 0.0f || dir.z == 0.0f; // (walker_begin: the filter's bound is infinite then)
+	w.eps_b = 0.0f;
+	c6[0] = start.x; c6[1] = start.y; c6[2] = start.z;
+	c6[3] = 1.0f / dir.x; c6[4] = 1.0f / dir.y; c6[5] = 1.0f / dir.z;
+}
+
+template <bool SHADOW, int LAYOUT, bool CHECK, bool DRAIN>
+__global__ __launch_bounds__(kW2Threads, kW2PerSimd) void ca_stream_walk2(StreamParams S)
+{
+	const RenderParams &P = S.R;
+	if (occ_skip_enabled(P)) return; // a sparse volume: the skipping kernels of render.hip draw the frame
+	__shared__ float ctx_lds[6][kW2Threads];
+	__shared__ u32 rec_lds[kRecWords][kW2Threads]; // a wave's queue: rec_lds[field][64 * wave + slot]
+	__shared__ u32 ids_lds[kW2Waves][kIdCap];      // a wave's list of job ids waiting for their set-up
+	const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	float *ctx = &ctx_lds[0][tid];
+	constexpr int stride = kW2Threads;
+	u32 *rec = &rec_lds[0][wave * 64];
+	u32 *ids = ids_lds[wave];
+	const float cs = 1.0f / (float)P.G;
+	const float vis = cs * P.u[U_CELLSIZE] * 0.5f;
+	const v3 vhalf = V(vis, vis, vis);
+	const float k0 = 0.5f - 0.5f * fabsf(P.u[U_CELLSIZE]), k1 = 1.0f - k0;
+	const float eps_a = 4.76837158203125e-7f * (float)P.G;
+	const float eps_c = 9.5367431640625e-7f * ((float)P.G + 8.0f);
+	const u32 qown = blockIdx.x & 7u;
+	u32 qcur = qown, qtried = 0;
+	const u32 lper = 2u * S.lb + job_shift(P);   // log2 jobs of a chunk
+	constexpr u32 ltj = SHADOW ? 2u : 0u;        // log2 jobs of a ticket: the shadow pass reads the flags of four jobs at once
+	const u32 ltper = lper - ltj, tper = 1u << ltper; // tickets of a chunk (>= 64: the launcher has checked)
+	auto q_lo = [&](u32 q) { return S.qmap ? q : (u32)(((unsigned long long)S.chunks * q) >> 3); };
+	auto q_len = [&](u32 q) { return S.qmap ? (S.chunks + 7u - q) >> 3 : q_lo(q + 1u) - q_lo(q); };
+	auto q_chunk = [&](u32 q, u32 pos) { return S.qmap ? pos * 8u + q : q_lo(q) + pos; };
+	auto q_static = [&](u32 q) { return (gridDim.x + 7u - q) >> 3; };
+	u32 *const pool_ctl = S.ctl + kPoolCtl + (SHADOW ? 4u : 0u);
+	// Job source: tickets straight off eight GLOBAL counters (one per XCD: workgroups go to the XCDs round-robin, queue q owns every
+	// eighth chunk), 64 per draw, one per lane; ticket t of queue q is job (t mod tickets-per-chunk) of the queue's (t / tickets-per-
+	// chunk)-th chunk — arithmetic, no ring of chunk ids. ca_stream_walk hands whole chunks to workgroups and tickets to lanes through
+	// LDS: one global atomic per 256 jobs, but a workgroup that draws its last chunk just before the queues run dry ends a chunk's
+	// worth (12-25 us, a tenth of the launch) after one that did not, and chunks differ by a factor of three in cost: wave lives
+	// spread over the last 45 % of a launch. At one atomic per 64 tickets the eight counters take 16 draws per us each (they sustain
+	// ~88), and the granularity of the balance is a quarter of a chunk per WAVE. A wave's first draw is static (its index in its
+	// queue): thousands of first draws at once would queue behind the counters for microseconds.
+	bool first_draw = !DRAIN;
+	const u32 wave_in_queue = (blockIdx.x >> 3) * (u32)kW2Waves + (u32)wave; // this wave among those whose own queue is qown
+	// true: no queue has a ticket left (wave-uniform); else chunk / cand are this lane's
+	auto draw = [&](u32 &chunk, u32 &cand) -> bool {
+		for (;;)
+		{
+			if (qtried >= 8u) return true;
+			u32 *head = S.ctl + kQueueWords + 32u * ((SHADOW ? 8u : 0u) + qcur);
+			const u32 qtickets = q_len(qcur) << ltper;                    // (a multiple of 64: tickets per chunk >= 64)
+			const u32 nstatic = q_static(qcur) * (u32)kW2Waves * 64u;     // tickets handed out statically from this queue
+			u32 base = 0;
+			if (first_draw) base = wave_in_queue * 64u;
+			else
+			{
+				if (lane == 0) base = nstatic + atomicAdd(head, 64u);
+				base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+			}
+			first_draw = false;
+			if (base >= qtickets) { qcur = (qcur + 1u) & 7u; qtried++; continue; } // dry: the next XCD's queue
+			const u32 t = base + (u32)lane;
+			chunk = q_chunk(qcur, t >> ltper);
+			cand = t & (tper - 1u);
+			return false;
+		}
+	};
+	bool more = true;
+	int job = -1, term = 0;
+	bool exempt = false;
+	Walker w;
+	w.tx = w.ty = w.tz = w.dx = w.dy = w.dz = w.t = w.tmax = w.eps_b = 0.0f;
+	w.ix = w.iy = w.iz = 0; w.sx = w.sy = w.sz = 1; w.wkey = -1; w.word = 0;
+	u32 visits = 0;              // wave-uniform
+	u32 idcount = 0;             // wave-uniform: ids waiting in ids[]
+	u32 qhead = 0, qavail = 0;   // wave-uniform: prepared rays rec[.][qhead .. qhead + qavail)
+	bool pool_full = false;      // wave-uniform
+	const int pop_at = S.refill2; // idle lanes at which the stepping loop is left for a pop
+	const unsigned long long tr_t0 = S.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
+	unsigned long long tr_refill = 0;
+	u32 tr_rounds = 0, tr_jobs = 0;
+	for (;;)
+	{
+		// retire the lanes whose walk is over (ca_stream_walk's)
+		if (job >= 0 && term != 0)
+		{
+			if (SHADOW) S.occl[job] = term == 1 ? kOcclHit : kOcclNone;
+			else
+			{
+				u32 out = kNoHit;
+				if (term == 1)
+				{
+					float tn;
+					slab_test<false>(P, w, vhalf, ctx, stride, tn);
+					out = __float_as_uint(tn);
+				}
+				S.hit[job] = out;
+			}
+			job = -1;
+			term = 0;
+		}
+		if (!DRAIN && S.dump_at > 0 && !more && idcount == 0u && qavail == 0u)
+		{
+			// nothing left to refill from: few enough walkers -> hand them to the drain launch and end
+			const unsigned long long act = __ballot(job >= 0);
+			const u32 nact = (u32)__popcll(act);
+			if (nact <= (u32)S.dump_at)
+			{
+				if (nact)
+				{
+					u32 base = 0;
+					if (lane == 0) base = atomicAdd(&pool_ctl[0], nact);
+					base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+					const u32 rk = (u32)__builtin_amdgcn_mbcnt_hi((u32)(act >> 32), __builtin_amdgcn_mbcnt_lo((u32)act, 0u));
+					if (job >= 0 && base + rk < kPoolCap) // (the drain reads records [0, min(written, kPoolCap)): exactly those that are there)
+					{
+						uint4 *o = reinterpret_cast<uint4 *>(S.pool + (size_t)(base + rk) * kPoolWords);
+						const u32 c0 = (u32)w.ix | ((u32)w.iy << 16);
+						const u32 c1 = (u32)w.iz | (w.sx > 0 ? 1u << 16 : 0u) | (w.sy > 0 ? 1u << 17 : 0u) | (w.sz > 0 ? 1u << 18 : 0u) | (w.eps_b == __builtin_inff() ? 1u << 19 : 0u) | (exempt ? 1u << 20 : 0u);
+						o[0] = make_uint4(__float_as_uint(w.tx), __float_as_uint(w.ty), __float_as_uint(w.tz), __float_as_uint(w.dx));
+						o[1] = make_uint4(__float_as_uint(w.dy), __float_as_uint(w.dz), __float_as_uint(w.tmax), c0);
+						o[2] = make_uint4(c1, (u32)job, __float_as_uint(ctx[0 * stride]), __float_as_uint(ctx[1 * stride]));
+						o[3] = make_uint4(__float_as_uint(ctx[2 * stride]), __float_as_uint(ctx[3 * stride]), __float_as_uint(ctx[4 * stride]), __float_as_uint(ctx[5 * stride]));
+						o[4] = make_uint4(__float_as_uint(w.t), 0u, 0u, 0u);
+						job = -1;
+					}
+				}
+				if (__ballot(job >= 0) == 0ull) break;
+				pool_full = true; // the pool had no room for (all of) them: they are walked to their ends here
+			}
+		}
+		const unsigned long long tr_r0 = S.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
+		for (;;)
+		{
+			const unsigned long long idle = __ballot(job < 0);
+			const u32 nidle = (u32)__popcll(idle);
+			if (nidle == 0u) break;
+			if (qavail == 0u)
+			{
+				if (DRAIN)
+				{
+					// the pool's records, 64 at a time, into the queue (the first launch is over: the count is final)
+					if (!more) break;
+					u32 base = 0, total = 0;
+					if (lane == 0)
+					{
+						total = min(__hip_atomic_load(&pool_ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), kPoolCap);
+						base = atomicAdd(&pool_ctl[1], 64u);
+					}
+					base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+					total = (u32)__builtin_amdgcn_readfirstlane((int)total);
+					const u32 n = base < total ? min(64u, total - base) : 0u;
+					if (n == 0u) { more = false; break; }
+					tr_rounds++;
+					if ((u32)lane < n)
+					{
+						const uint4 *in = reinterpret_cast<const uint4 *>(S.pool + (size_t)(base + (u32)lane) * kPoolWords);
+						const uint4 a0 = in[0], a1 = in[1], a2 = in[2], a3 = in[3], a4 = in[4];
+						u32 *r = rec + lane;
+						r[0 * kW2Threads] = a0.x; r[1 * kW2Threads] = a0.y; r[2 * kW2Threads] = a0.z; r[3 * kW2Threads] = a0.w;
+						r[4 * kW2Threads] = a1.x; r[5 * kW2Threads] = a1.y; r[6 * kW2Threads] = a1.z; r[7 * kW2Threads] = a1.w;
+						r[8 * kW2Threads] = a2.x; r[9 * kW2Threads] = a2.y; r[10 * kW2Threads] = a2.z; r[11 * kW2Threads] = a2.w;
+						r[12 * kW2Threads] = a3.x; r[13 * kW2Threads] = a3.y; r[14 * kW2Threads] = a3.z; r[15 * kW2Threads] = a3.w;
+						r[16 * kW2Threads] = a4.x;
+					}
+					qavail = n;
+					qhead = 0u;
+				}
+				else
+				{
+				if (!more && idcount == 0u) break;
+				// ---- fill, stage A: ids of jobs that want a ray, until there are 64 of them (or the queues are dry)
+				while (idcount < 64u && more)
+				{
+					u32 chunk = 0, cand = 0;
+					const bool dry = draw(chunk, cand); // wave-uniform
+					if (dry) { more = false; break; }
+					if (!SHADOW)
+					{
+						const u32 j = (chunk << lper) + cand;
+						bool valid = false;
+						if (!dry)
+						{
+							u32 px, py, ks;
+							job_pixel(S, chunk, cand, px, py, ks);
+							valid = px < P.W && py < P.row1;
+						}
+						const unsigned long long m = __ballot(valid);
+						if (valid) ids[idcount + (u32)__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u))] = j;
+						idcount += (u32)__popcll(m);
+					}
+					else
+					{
+						const u32 j0 = (chunk << lper) + (cand << 2);
+						u32 flags = 0;
+						if (!dry) flags = *reinterpret_cast<const u32 *>(S.occl + j0);
+#pragma unroll
+						for (u32 q = 0; q < 4u; q++)
+						{
+							const bool valid = ((flags >> (8u * q)) & 0xFFu) == (u32)kOcclPending; // (kOcclPending != 0: a dry lane's zeros never match)
+							const unsigned long long m = __ballot(valid);
+							if (valid) ids[idcount + (u32)__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u))] = j0 + q;
+							idcount += (u32)__popcll(m);
+						}
+					}
+				}
+				if (idcount == 0u) break; // dry, and nothing was waiting
+				// ---- fill, stage B: the set-up of up to 64 of them, one per lane, every lane
+				tr_rounds++;
+				const u32 n = min(idcount, 64u);
+				bool pushed = false, ap = false, ex = false;
+				Walker nw;
+				float c6[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+				u32 nj = 0;
+				nw.tx = nw.ty = nw.tz = nw.dx = nw.dy = nw.dz = nw.t = nw.tmax = nw.eps_b = 0.0f;
+				nw.ix = nw.iy = nw.iz = 0; nw.sx = nw.sy = nw.sz = 1; nw.wkey = -1; nw.word = 0;
+				if ((u32)lane < n)
+				{
+					const u32 j = ids[lane];
+					nj = j;
+					if (!SHADOW)
+					{
+						u32 px, py, ks;
+						job_pixel(S, j >> lper, j & ((1u << lper) - 1u), px, py, ks);
+						float vu, vv;
+						sample_uv(P, px, py, ks, vu, vv);
+						CapturePrimary tr;
+						shade_sample_with(P, vu, vv, tr);
+						if (tr.wanted)
+						{
+							if (0.0f >= tr.len) S.hit[j] = kNoHit; // walk(): `if (t >= tmax) return false` before the first cell
+							else
+							{
+								walker_prepare(P, nw, ap, c6, tr.enter, tr.dir, 0.0f, tr.len);
+								pushed = true;
+							}
+						}
+					}
+					else
+					{
+						// shade_sample_with between the shading gate and the shadow walk
+						const float4 r = S.rays[j];
+						const v3 p = V(r.x, r.y, r.z);
+						const v3 light_pos = V(P.u[U_LIGHT], P.u[U_LIGHT + 1], P.u[U_LIGHT + 2]);
+						const v3 ldir = norm3(light_pos - p);
+						float vn, vf;
+						ray_cube(p, ldir, V(0.0f, 0.0f, 0.0f), V(kHalf, kHalf, kHalf), vn, vf);
+						const v3 vexit = p + ldir * vf;
+						const v3 sseg = vexit - p;
+						const float slen = len3(sseg);
+						if (0.0025f >= slen) S.occl[j] = kOcclNone;
+						else
+						{
+							walker_prepare(P, nw, ap, c6, p, norm3(sseg), 0.0025f, slen);
+							const int cx = (int)floorf(to_cells(P, p.x)), cy = (int)floorf(to_cells(P, p.y)), cz = (int)floorf(to_cells(P, p.z));
+							ex = nw.ix == cx && nw.iy == cy && nw.iz == cz; // any(cell != startCell) :664
+							pushed = true;
+						}
+					}
+				}
+				// the ids not taken move to the front of the list (at most 255 of them: four per lane; reads before writes)
+				if (idcount > 64u)
+				{
+					const u32 left = idcount - 64u;
+					u32 keep[4];
+#pragma unroll
+					for (u32 q = 0; q < 4u; q++) keep[q] = (u32)lane + 64u * q < left ? ids[64u + (u32)lane + 64u * q] : 0u;
+#pragma unroll
+					for (u32 q = 0; q < 4u; q++)
+						if ((u32)lane + 64u * q < left) ids[(u32)lane + 64u * q] = keep[q];
+				}
+				idcount -= n;
+				// prepared rays into the wave's queue, packed
+				{
+					const unsigned long long m = __ballot(pushed);
+					if (pushed)
+					{
+						const u32 slot = (u32)__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+						u32 *r = rec + slot;
+						r[0 * kW2Threads] = __float_as_uint(nw.tx); r[1 * kW2Threads] = __float_as_uint(nw.ty); r[2 * kW2Threads] = __float_as_uint(nw.tz);
+						r[3 * kW2Threads] = __float_as_uint(nw.dx); r[4 * kW2Threads] = __float_as_uint(nw.dy); r[5 * kW2Threads] = __float_as_uint(nw.dz);
+						r[6 * kW2Threads] = __float_as_uint(nw.tmax);
+						r[7 * kW2Threads] = (u32)nw.ix | ((u32)nw.iy << 16);
+						r[8 * kW2Threads] = (u32)nw.iz | (nw.sx > 0 ? 1u << 16 : 0u) | (nw.sy > 0 ? 1u << 17 : 0u) | (nw.sz > 0 ? 1u << 18 : 0u) | (ap ? 1u << 19 : 0u) | (ex ? 1u << 20 : 0u);
+						r[9 * kW2Threads] = nj;
+#pragma unroll
+						for (int q = 0; q < 6; q++) r[(10 + q) * kW2Threads] = __float_as_uint(c6[q]);
+					}
+					qavail = (u32)__popcll(m);
+					qhead = 0u;
+				}
+				if (qavail == 0u) continue; // none of the 64 needed a walk: the next 64
+				}
+			}
+			// ---- pop: the idle lanes take prepared rays
+			const u32 take = min(nidle, qavail);
+			if (job < 0)
+			{
+				const u32 rk = (u32)__builtin_amdgcn_mbcnt_hi((u32)(idle >> 32), __builtin_amdgcn_mbcnt_lo((u32)idle, 0u));
+				if (rk < take)
+				{
+					const u32 *r = rec + qhead + rk;
+					w.tx = __uint_as_float(r[0 * kW2Threads]); w.ty = __uint_as_float(r[1 * kW2Threads]); w.tz = __uint_as_float(r[2 * kW2Threads]);
+					w.dx = __uint_as_float(r[3 * kW2Threads]); w.dy = __uint_as_float(r[4 * kW2Threads]); w.dz = __uint_as_float(r[5 * kW2Threads]);
+					w.tmax = __uint_as_float(r[6 * kW2Threads]);
+					const u32 c0 = r[7 * kW2Threads], c1 = r[8 * kW2Threads];
+					w.ix = (int)(c0 & 0xFFFFu); w.iy = (int)(c0 >> 16); w.iz = (int)(c1 & 0xFFFFu);
+					w.sx = (c1 >> 16) & 1u ? 1 : -1; w.sy = (c1 >> 17) & 1u ? 1 : -1; w.sz = (c1 >> 18) & 1u ? 1 : -1;
+					w.eps_b = (c1 >> 19) & 1u ? __builtin_inff() : eps_c * (w.dx + w.dy + w.dz);
+					exempt = (c1 >> 20) & 1u;
+					w.t = DRAIN ? __uint_as_float(r[16 * kW2Threads]) : (SHADOW ? 0.0025f : 0.0f);
+					w.word = 0;
+					w.wkey = -1;
+					job = (int)r[9 * kW2Threads];
+					term = 0;
+#pragma unroll
+					for (int q = 0; q < 6; q++) ctx[q * stride] = __uint_as_float(r[(10 + q) * kW2Threads]);
+				}
+			}
+			qhead += take;
+			qavail -= take;
+			if (qavail != 0u || take == nidle) break; // every idle lane has a ray, or rays are left over: walk
+		}
+		int walking = __popcll(__ballot(job >= 0));
+		if (S.trace) { tr_refill += __builtin_amdgcn_s_memrealtime() - tr_r0; tr_jobs += (u32)walking; }
+		if (walking == 0)
+		{
+			if (!more && idcount == 0u && qavail == 0u) break;
+			continue;
+		}
+		const bool refillable = more || idcount != 0u || qavail != 0u;
+		// leave the loop for a pop when pop_at lanes are idle; with nothing left to pop, for the hand-over to the drain launch when
+		// dump_at lanes or fewer still walk (a wave the pool had no room for walks on to the end)
+		const int leave_at = __builtin_amdgcn_readfirstlane(refillable ? 64 - pop_at : ((!DRAIN && !pool_full && walking > S.dump_at) ? S.dump_at : 0));
+		if (CHECK || S.flat == 0)
+		{
+			do
+			{
+				const int key = word_key<LAYOUT>(S, w.ix, w.iy, w.iz);
+				visits += (u32)walking;
+				if (job >= 0 && term == 0) term = walk_cell<SHADOW, LAYOUT, CHECK, true>(S, w, key, exempt, vhalf, k0, k1, eps_a, ctx, stride);
+				walking = __builtin_amdgcn_readfirstlane(__popcll(__ballot(job >= 0 && term == 0)));
+			} while (walking > leave_at);
+		}
+		else
+		{
+			do
+			{
+				visits += (u32)walking;
+				walk_cell_flat<SHADOW, LAYOUT>(S, w, job >= 0 && term == 0, exempt, term, vhalf, k0, k1, eps_a, ctx, stride);
+				walking = __builtin_amdgcn_readfirstlane(__popcll(__ballot(job >= 0 && term == 0)));
+			} while (walking > leave_at);
+		}
+	}
+	if (S.trace && lane == 0 && !DRAIN)
+	{
+		unsigned long long *t = S.trace + 8ull * ((SHADOW ? gridDim.x * (u32)kW2Waves : 0u) + blockIdx.x * (u32)kW2Waves + (u32)wave);
+		t[0] = tr_t0; t[1] = __builtin_amdgcn_s_memrealtime(); t[2] = tr_rounds; t[3] = 0; t[4] = 0; t[5] = tr_refill; t[6] = tr_jobs; t[7] = 0;
+	}
+	if (lane == 0 && visits) atomicAdd(&S.ctl[16 + 4 * ((blockIdx.x * (u32)kW2Waves + (u32)wave) % kStatSlots) + (SHADOW ? 2 : 1)], visits);
+}
+
 // Second pass: every job of the rectangle, one lane each.
 __global__ __launch_bounds__(256) void ca_stream_shadow_rays(StreamParams S)
 {
@@ -752,6 +1224,17 @@ __global__ __launch_bounds__(256) void ca_stream_resolve(StreamParams S)
 	}
 }
 
+template <int P2, bool CHECK>
+void launch_walks2(const StreamParams &S, u32 wgs2, u32 job_blocks, hipStream_t stream)
+{
+	const u32 drain_wgs = S.drain_wgs; // one wave per SIMD takes what the first launch's waves left over
+	hipLaunchKernelGGL((ca_stream_walk2<false, P2, CHECK, false>), dim3(wgs2), dim3(kW2Threads), 0, stream, S);
+	if (S.dump_at > 0) hipLaunchKernelGGL((ca_stream_walk2<false, P2, CHECK, true>), dim3(drain_wgs), dim3(kW2Threads), 0, stream, S);
+	hipLaunchKernelGGL(ca_stream_shadow_rays, dim3(job_blocks), dim3(256), 0, stream, S);
+	hipLaunchKernelGGL((ca_stream_walk2<true, P2, CHECK, false>), dim3(wgs2), dim3(kW2Threads), 0, stream, S);
+	if (S.dump_at > 0) hipLaunchKernelGGL((ca_stream_walk2<true, P2, CHECK, true>), dim3(drain_wgs), dim3(kW2Threads), 0, stream, S);
+}
+
 template <int P2, bool CHECK, bool BATCHED = false>
 void launch_walks(const StreamParams &S, u32 wgs, u32 job_blocks, hipStream_t stream)
 {
@@ -762,7 +1245,7 @@ void launch_walks(const StreamParams &S, u32 wgs, u32 job_blocks, hipStream_t st
 
 } // namespace
 
-size_t stream_scratch_bytes(uint32_t W, uint32_t H, uint32_t spp, size_t *hit_off, size_t *occl_off, size_t *rays_off)
+size_t stream_scratch_bytes(uint32_t W, uint32_t H, uint32_t spp, size_t *hit_off, size_t *occl_off, size_t *rays_off, size_t *pool_off)
 {
 	// the rectangle is aligned to 32 x 16 pixels and clipped to the frame: at most the padded frame
 	const size_t jobs = (size_t)((W + 31u) / 32u * 32u) * ((H + 15u) / 16u * 16u) * spp;
@@ -770,6 +1253,8 @@ size_t stream_scratch_bytes(uint32_t W, uint32_t H, uint32_t spp, size_t *hit_of
 	*hit_off = off; off += jobs * 4u;
 	*occl_off = off; off += (jobs + 255u) / 256u * 256u;
 	*rays_off = off; off += jobs * 16u;
+	if (pool_off) *pool_off = off;
+	off += (size_t)kPoolCap * kPoolWords * 4u; // the drain's pool (40 MiB)
 	return off;
 }
 
@@ -780,8 +1265,8 @@ hipError_t launch_render_stream(const void *params, void *scratch, uint32_t W, u
 	StreamParams S;
 	S.R = *static_cast<const RenderParams *>(params);
 	const RenderParams &P = S.R;
-	size_t hit_off, occl_off, rays_off;
-	stream_scratch_bytes(W, H, P.spp, &hit_off, &occl_off, &rays_off);
+	size_t hit_off, occl_off, rays_off, pool_off;
+	stream_scratch_bytes(W, H, P.spp, &hit_off, &occl_off, &rays_off, &pool_off);
 	char *base = static_cast<char *>(scratch);
 	S.ctl = reinterpret_cast<u32 *>(base);
 	S.hit = reinterpret_cast<u32 *>(base + hit_off);
@@ -825,6 +1310,7 @@ hipError_t launch_render_stream(const void *params, void *scratch, uint32_t W, u
 	const u32 wgs = min(S.chunks, (u32)cus * (u32)kStreamWaves * 4u / (u32)kWalkWaves); // persistent: what the chip holds at kStreamWaves per SIMD
 	const u32 job_blocks = (S.chunks * per + 255u) / 256u;
 	static const int bricks_env = getenv("CA3D_STREAM_BRICKS") ? atoi(getenv("CA3D_STREAM_BRICKS")) : 1; // tuning: 0 rows, 1 default, 2 bricks with a cached word, 3 batched loop
+	unsigned long long trace_waves = (unsigned long long)wgs * (unsigned)kWalkWaves;
 	const bool bricked = bricks && bricks_env && frame_bricks_applies(P.G);
 	S.volume = bricked ? bricks : P.cells;
 	if (bricked)
@@ -835,7 +1321,32 @@ hipError_t launch_render_stream(const void *params, void *scratch, uint32_t W, u
 			if (eb != hipSuccess) return eb;
 			if (bricks_built) *bricks_built = true;
 		}
-		if (!p2) { if (check) launch_walks<kBricksReadAny, true>(S, wgs, job_blocks, stream); else launch_walks<kBricksReadAny, false>(S, wgs, job_blocks, stream); }
+		// which form of the walk passes: 2 (default) sets rays up 64 at a time and queues them in LDS (ca_stream_walk2); 1: round 4's form
+		static const int form_env = getenv("CA3D_STREAM_FORM") ? atoi(getenv("CA3D_STREAM_FORM")) : 1;
+		static const int pop_env = getenv("CA3D_STREAM_POP") ? atoi(getenv("CA3D_STREAM_POP")) : 0;
+		S.refill2 = pop_env >= 1 && pop_env <= 64 ? pop_env : 8;
+		static const int flat_env = getenv("CA3D_STREAM_FLAT") ? atoi(getenv("CA3D_STREAM_FLAT")) : 1;
+		S.flat = flat_env ? 1 : 0;
+		static const int dump_env = getenv("CA3D_STREAM_DUMP") ? atoi(getenv("CA3D_STREAM_DUMP")) : -1;
+		S.dump_at = dump_env >= 0 && dump_env <= 64 ? dump_env : 32;
+		static const int drain_env = getenv("CA3D_STREAM_DRAIN_WGS") ? atoi(getenv("CA3D_STREAM_DRAIN_WGS")) : 0;
+		S.drain_wgs = drain_env > 0 ? (u32)drain_env : (u32)cus;
+		S.pool = reinterpret_cast<u32 *>(base + pool_off);
+		const u32 wgs2 = min(S.chunks, (u32)cus * (u32)kW2PerSimd * 4u / (u32)kW2Waves);
+		const bool form2 = form_env == 2 && per >= 256u && bricks_env == 1; // (a chunk holds at least 64 tickets of four jobs)
+		if (form2) trace_waves = (unsigned long long)wgs2 * (unsigned)kW2Waves;
+		static const int probe_env = getenv("CA3D_STREAM_PROBE") ? atoi(getenv("CA3D_STREAM_PROBE")) : 0;
+		S.probe_mask = 0u;
+		if (probe_env >= 1 && probe_env <= 4 && p2)
+		{
+			if (probe_env == 1) launch_walks<kProbeNone, false>(S, wgs, job_blocks, stream);
+			else if (probe_env == 2) launch_walks<kProbeSame, false>(S, wgs, job_blocks, stream);
+			else if (probe_env == 3) launch_walks<kProbeSmall, false>(S, wgs, job_blocks, stream);
+			else launch_walks<kProbeFull, false>(S, wgs, job_blocks, stream);
+		}
+		else if (form2 && !p2) { if (check) launch_walks2<kBricksReadAny, true>(S, wgs2, job_blocks, stream); else launch_walks2<kBricksReadAny, false>(S, wgs2, job_blocks, stream); }
+		else if (form2) { if (check) launch_walks2<kBricksRead, true>(S, wgs2, job_blocks, stream); else launch_walks2<kBricksRead, false>(S, wgs2, job_blocks, stream); }
+		else if (!p2) { if (check) launch_walks<kBricksReadAny, true>(S, wgs, job_blocks, stream); else launch_walks<kBricksReadAny, false>(S, wgs, job_blocks, stream); }
 		else if (bricks_env == 3) { if (check) launch_walks<kBricks, true, true>(S, wgs, job_blocks, stream); else launch_walks<kBricks, false, true>(S, wgs, job_blocks, stream); }
 		else if (bricks_env == 2) { if (check) launch_walks<kBricks, true>(S, wgs, job_blocks, stream); else launch_walks<kBricks, false>(S, wgs, job_blocks, stream); }
 		else if (check) launch_walks<kBricksRead, true>(S, wgs, job_blocks, stream);
@@ -851,7 +1362,7 @@ hipError_t launch_render_stream(const void *params, void *scratch, uint32_t W, u
 		if (hipStreamSynchronize(stream) == hipSuccess && hipMemcpy(t.data(), S.trace, trace_words * 8u, hipMemcpyDeviceToHost) == hipSuccess)
 			if (FILE *f = fopen(trace_path, "wb"))
 			{
-				const unsigned long long n = (unsigned long long)wgs * (unsigned)kWalkWaves;
+				const unsigned long long n = trace_waves;
 				fwrite(&n, 8, 1, f);
 				fwrite(t.data(), 8, (size_t)n * 16u, f);
 				fclose(f);

@@ -157,6 +157,14 @@ class Engine:
     def slab_exchange(self) -> None:
         _capi.check(self._lib.ca3d_slab_exchange(self._h))
 
+    def comm_info(self) -> dict:
+        """Device ordinal + PCI bus id of this engine and, with an RCCL communicator (slab_comm_init), what the communicator itself
+        reports: rank count, rank, device (ca3d_slab_comm_info)."""
+        ci = _capi.CommInfo()
+        _capi.check(self._lib.ca3d_slab_comm_info(self._h, C.byref(ci)))
+        return {"device": int(ci.device), "pci_bus_id": ci.pci_bus_id.decode(), "comm_ranks": int(ci.comm_ranks),
+                "comm_rank": int(ci.comm_rank), "comm_device": int(ci.comm_device)}
+
     def slab_gather(self, full: "Engine") -> None:
         """ncclAllGather of every rank's owned planes into `full`'s current buffer (a full-grid engine, same device)."""
         _capi.check(self._lib.ca3d_slab_gather(self._h, full._h))

@@ -167,6 +167,19 @@ int ca3d_comm_unique_id(void *id_bytes);
 int ca3d_slab_comm_init(ca3d_t *h, const void *id_bytes, int rank, int world);
 int ca3d_slab_run(ca3d_t *h, uint32_t n_steps, int overlap);
 int ca3d_slab_exchange(ca3d_t *h);
+/* Evidence of what a multi-GPU run really ran on (bench.py prints it per rank): the engine's HIP device and its PCI bus id
+ * (hipDeviceGetPCIBusId), and — once ca3d_slab_comm_init has built the engine's RCCL communicator — what the COMMUNICATOR
+ * reports: ncclCommCount, ncclCommUserRank, ncclCommCuDevice (-1 each without one). Eight ranks are eight GPUs only if
+ * the eight bus ids differ. */
+typedef struct ca3d_comm_info
+{
+	int32_t device;       /* the engine's HIP device ordinal */
+	int32_t comm_ranks;   /* ncclCommCount */
+	int32_t comm_rank;    /* ncclCommUserRank */
+	int32_t comm_device;  /* ncclCommCuDevice */
+	char pci_bus_id[32];  /* "0000:05:00.0" */
+} ca3d_comm_info;
+int ca3d_slab_comm_info(ca3d_t *h, ca3d_comm_info *out);
 int ca3d_slab_gather(ca3d_t *h, ca3d_t *full);
 
 /*
@@ -317,6 +330,11 @@ int ca3d_get_stats(ca3d_t *h, ca3d_stats *out);
  * reference frame per call (jittered marches + history look-ups + temporal blend; spp must be 1; packed layout);
  * "render_reset_history" clears the history surfaces. An engine configured with CA3D_LAYOUT_UNPACKED renders
  * through the legacy shader model (shaders/pathtraced_fragment.wgsl).
+ *
+ * A call without output pointers only enqueues and does NOT wait for a pending resident multi-step launch to be
+ * verified (ca3d_recovered_launches): should that launch later turn out to have timed out, the frame was drawn from
+ * its unwritten output — wrong once; the engine then re-runs the steps and clears the history surfaces, so the
+ * literal mode does not keep blending that frame in. A call WITH an output pointer settles the launch first.
  */
 int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t height, uint32_t spp,
                 uint8_t *presentation_rgba8, uint16_t *light_rgba16f, uint16_t *depth_rg16f);
@@ -352,7 +370,7 @@ int ca3d_get_render_stats(ca3d_t *h, ca3d_render_stats *out);
  * "roll" 0/1 the rolling-window form of the run-time compiled class kernels (on by
  * default where it applies), "roll_tile" 0-3 which of its forms (0 every thread shifts its three rows, 1 workgroup tiles sharing the
  * shifted rows through LDS, 2 wave tiles, 3 two words per thread), "roll_z" 0/2/4/8/16/15/30 its planes per thread
- * (0: chosen per launch); "resident_zsplit" 1/2, "resident_rows" 32/16: tiling of the resident von Neumann kernels, "resident_deep" 0/1: at 256^3 two steps per hand-off with two-deep faces (measured slower: off); "resident_pair" 1/0: at 512^3 with the
+ * (0: chosen per launch); "resident_zsplit" 1/2, "resident_rows" 32/16: tiling of the resident von Neumann kernels, "resident_pair" 1/0: at 512^3 with the
  * default tiling a thread owns two adjacent rows x 16 planes instead of one row x 32 (less LDS traffic; default 1); "graph_min" n: batches shorter than n
  * steps are launched kernel by kernel instead of as a captured graph; "render_mode" 0/1; "render_row_begin" / "render_row_end":
  * ca3d_render then fills image rows [begin, end) only (begin a multiple of 16; 0 / 0 = the whole frame) — a rank's

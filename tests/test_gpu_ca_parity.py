@@ -129,8 +129,9 @@ def test_von_neumann_tables_through_every_branch_of_vn_next(eng, born, survive):
             np.testing.assert_array_equal(eng.read_state(), ol.packed_run(G, st, r, steps), err_msg=f"B{born}/S{survive} at {G} ({eng.info().kernel_name})")
 
 
-@pytest.mark.parametrize("G", [96, 160, 384, 768])
-@pytest.mark.parametrize("name", list(RULESETS))
+# every rule-set at 96 / 160 / 384; at 768 (3.5 s per case: the oracle) one rule per kernel form — von Neumann, clustered, a 2D rule, a wide
+# Moore table, an edges-only rule-set: the forms 768 selects are the ones 384 selects for the other rules (both are multiples of 128)
+@pytest.mark.parametrize("G,name", [(G, n) for G in (96, 160, 384) for n in RULESETS] + [(768, n) for n in ("default", "clustered", "life2d", "moore_wide", "vn_edges_only")])
 def test_rows_kernel_on_grids_that_are_not_powers_of_two(eng, G, name):
     """The grids the reference UI offers are the multiples of 32 up to 1024 (main_pathtraced.js:268-279, 675-693). Those that are not
     powers of two run the rows kernel (ca_packed_rows_kernel.inc, compiled for grid and rule at run time): against the oracle, and
@@ -454,8 +455,22 @@ def test_rolling_window_kernel_launcher_choice(eng, name, G):
     assert np.array_equal(eng.read_state(), ol.packed_run(G, st, r, 2))
 
 
-@pytest.mark.parametrize("tables,rows,zsplit", [("default", 32, 2), ("vn_b24_s135", 32, 2), ("default", 16, 2), ("default", 32, 1), ("vn_b24_s135", 16, 1),
-                                                ("default", "pair", 1), ("vn_b24_s135", "pair", 1), ("default", "stagger", 1), ("vn_b24_s135", "stagger", 1)])
+_ORACLE_MEMO = {}
+
+
+def _oracle_run(G, key, state, r, steps):
+    """ol.packed_run, remembered per (grid, name of the start state, rule tables) and continued from the furthest remembered state
+    at or before `steps`: the parametrised forms of one kernel family are compared with the same oracle states — a 512^3 x 1000-step
+    oracle run is ~22 s of the suite each time it is recomputed."""
+    memo = _ORACLE_MEMO.setdefault((G, key, tuple(r.survive), tuple(r.born)), {0: state})
+    if steps not in memo:
+        base = max(k for k in memo if k <= steps)
+        memo[steps] = ol.packed_run(G, memo[base], r, steps - base)
+    return memo[steps]
+
+
+@pytest.mark.parametrize("tables,rows,zsplit", [("default", "pair", 1), ("vn_b24_s135", "pair", 1), ("default", 32, 1), ("default", 32, 2), ("vn_b24_s135", 32, 2),
+                                                ("default", 16, 2), ("vn_b24_s135", 16, 1)])
 def test_resident_multi_step_kernel(eng, tables, rows, zsplit):
     """The resident kernel (ca_resident_kernel.inc): K steps of a 512^3 von Neumann rule in one launch, the state in
     registers, tile faces handed over through tagged granules. Batches of several lengths back to back (the state tags
@@ -464,10 +479,8 @@ def test_resident_multi_step_kernel(eng, tables, rows, zsplit):
     G = 512
     r = rules(tables)
     eng.configure(G)
-    stagger = rows == "stagger"  # the row-pair form with the two z groups of a tile half a step apart (resident_stagger_run)
-    pair = rows == "pair" or stagger  # the row-pair form: 32-row tiles, a thread owns two adjacent rows x 16 planes (resident_pair_run)
+    pair = rows == "pair"  # the row-pair form (the default): 32-row tiles, a thread owns two adjacent rows x 16 planes (resident_pair_run)
     eng.set_option("resident_pair", int(pair))
-    eng.set_option("resident_stagger", int(stagger))
     rows = 32 if pair else rows
     eng.set_option("resident_rows", rows)  # tiles of 32 rows (one workgroup per CU) or 16 rows (two per CU)
     eng.set_option("resident_zsplit", zsplit)  # 2: two threads per (row, word) column, half the planes each — four waves per SIMD
@@ -475,12 +488,11 @@ def test_resident_multi_step_kernel(eng, tables, rows, zsplit):
     assert eng.info().kernel_name.startswith(b"ca_resident_vn")
     st = host.random_fill(host.words_per_buffer(G), seed=88)
     eng.upload_state(st)
-    want = st
     total = 0
     for n in (8, 9, 20):
         eng.step(n)
-        prev = ol.packed_run(G, want, r, n - 1)
-        want = ol.packed_step(G, prev, r)
+        prev = _oracle_run(G, "fill88", st, r, total + n - 1)
+        want = _oracle_run(G, "fill88", st, r, total + n)
         total += n
         np.testing.assert_array_equal(eng.read_state(), want, err_msg=f"after a batch of {n}")
         assert eng.info().current_buffer == total % 2 and eng.info().step == total
@@ -498,41 +510,39 @@ def test_resident_multi_step_kernel(eng, tables, rows, zsplit):
     eng.upload_state(st2)
     eng.step(60)
     np.testing.assert_array_equal(got, eng.read_state())
-    np.testing.assert_array_equal(got, ol.packed_run(G, st2, r, 60))
-    # 1000 steps on a dense state in one launch against 1000 launches of the per-step kernel AND against the oracle
+    np.testing.assert_array_equal(got, _oracle_run(G, "seed", st2, r, 60))
+    # many steps on a dense state in one launch against as many launches of the per-step kernel — 1000 for the default form (the
+    # row-pair kernel) and, on the default rule, against the oracle's 1000 steps too; the forms that are off by default run 64
+    long = 1000 if pair else 64
     eng.upload_state(st)
-    eng.step(1000)
+    eng.step(long)
     per_step = eng.read_state()
     eng.set_option("resident", 1)
     eng.upload_state(st)
-    eng.step(1000)
+    eng.step(long)
     assert eng.info().kernel_name.startswith(b"ca_resident_vn")
     got = eng.read_state()
     np.testing.assert_array_equal(got, per_step)
-    if rows == 32 and zsplit == 1 and tables == "default":
-        np.testing.assert_array_equal(got, ol.packed_run(G, st, r, 1000), err_msg="1000 resident steps vs the oracle")
+    if pair and tables == "default":
+        np.testing.assert_array_equal(got, _oracle_run(G, "fill88", st, r, 1000), err_msg="1000 resident steps vs the oracle")
     assert eng.recovered_launches() == 0
     eng.set_option("resident_pair", 1)  # the defaults again
-    eng.set_option("resident_stagger", 0)
     eng.set_option("resident_rows", 32)
     eng.set_option("resident_zsplit", 1)
 
 
-@pytest.mark.parametrize("name,G,n,stagger", [("default", 512, 40, 0), ("default", 256, 33, 0), ("clustered", 512, 16, 0), ("clustered", 256, 20, 0),
-                                              ("default", 512, 40, 1)])
-def test_resident_launch_that_gives_up_is_recovered(name, G, n, stagger):
+@pytest.mark.parametrize("name,G,n", [("default", 512, 40), ("default", 256, 33), ("clustered", 512, 16), ("clustered", 256, 20)])
+def test_resident_launch_that_gives_up_is_recovered(name, G, n):
     """A resident launch only completes when all its workgroups are on the chip. Simulate one that is not (option
     "resident_fault_tile": that tile leaves at once, exactly what a workgroup stuck in the dispatcher's queue looks like to
     its neighbours) with a short timeout: the neighbours' waits expire, the launch and the resident launches queued behind
     it write nothing, and the engine re-runs their steps from the intact input through the per-step kernels — the call
-    sequence ends bit-exact with the oracle, the resident path is off afterwards and can be turned on again. (stagger: the form whose
-    two z groups run half a step apart — its waves meet the give-up word behind different barriers of their program.)"""
+    sequence ends bit-exact with the oracle, the resident path is off afterwards and can be turned on again."""
     from cellularautomatons3d_amd import Engine
 
     r = rules(name)
     with Engine(0) as e:
         e.configure(G)
-        e.set_option("resident_stagger", stagger)
         set_rules(e, r)
         assert e.info().kernel_name.startswith(b"ca_resident")
         st = host.random_fill(host.words_per_buffer(G), seed=404, and_rounds=1)
@@ -804,10 +814,7 @@ def test_checkpoint_resume(eng, tmp_path):
     np.testing.assert_array_equal(eng.read_state(), want)
 
 
-RESIDENT_DEEP_DEFAULT = 0  # the engine's default for option "resident_deep"
-
-
-@pytest.mark.parametrize("tables,zsplit", [("default", 2), ("vn_b24_s135", 2), ("default", 1), ("default", "deep"), ("vn_b24_s135", "deep2")])
+@pytest.mark.parametrize("tables,zsplit", [("default", 2), ("vn_b24_s135", 1), ("default", 1)])
 def test_resident_kernel_at_256(eng, tables, zsplit):
     """BASELINE configs[1] (256^3, 1000 steps) through the resident kernel's 256^3 form: 256 tiles of 8 words x 32 rows x 8
     planes (rows of 8 words: two grid rows per DPP row), y faces smaller than a tile's thread count. Batches of several
@@ -815,9 +822,6 @@ def test_resident_kernel_at_256(eng, tables, zsplit):
     G = 256
     r = rules(tables)
     eng.configure(G)
-    deep = zsplit in ("deep", "deep2")  # two steps per hand-off: faces two cells deep, the step in between on the tile plus a one-cell ring (resident_deep_run)
-    eng.set_option("resident_deep", int(deep))
-    zsplit = {"deep": 1, "deep2": 2}.get(zsplit, zsplit)
     eng.set_option("resident_zsplit", zsplit)
     set_rules(eng, r)
     assert eng.info().kernel_name.startswith(b"ca_resident_vn")
@@ -842,7 +846,7 @@ def test_resident_kernel_at_256(eng, tables, zsplit):
     eng.upload_state(st2)
     eng.step(100)
     np.testing.assert_array_equal(eng.read_state(), ol.packed_run(G, st2, r, 100))
-    # live cells hugging the dead -y / -z faces and the wrapping +y / +z faces, and both x ends (the deep form EVOLVES cells outside its tiles)
+    # live cells hugging the dead -y / -z faces and the wrapping +y / +z faces, and both x ends
     edge = np.zeros(host.words_per_buffer(G), dtype=np.uint32)
     e3 = edge.reshape(G, G, G // 32)
     e3[:3, :3, :] = host.random_fill(9 * (G // 32), seed=7).reshape(3, 3, G // 32)
@@ -867,7 +871,6 @@ def test_resident_kernel_at_256(eng, tables, zsplit):
     finally:
         eng.set_option("resident", 1)
         eng.set_option("resident_zsplit", 1)
-        eng.set_option("resident_deep", RESIDENT_DEEP_DEFAULT)
 
 
 def test_queued_submission(eng):

@@ -232,7 +232,11 @@ def test_native_rccl_transport_loopback(overlap, name, G, K, steps):
         se.engine.synchronize()
         want = ol.packed_run(G, full, r, steps + 1)
         assert np.array_equal(se.engine.read_state(), want)
+        ci = se.engine.comm_info()  # what the communicator itself reports (bench.py's "rccl" block on every N > 1 line)
+        assert ci["comm_ranks"] == 1 and ci["comm_rank"] == 0 and ci["comm_device"] == 0 and ci["device"] == 0
+        assert len(ci["pci_bus_id"].split(":")) == 3, ci
         with Engine(0) as vol:
+            assert vol.comm_info()["comm_ranks"] == -1 and vol.comm_info()["pci_bus_id"] == ci["pci_bus_id"]  # no communicator: the device only
             vol.configure(G)
             vol.set_rule_strings()
             vol.upload_state(np.zeros(host.words_per_buffer(G), dtype=np.uint32))
@@ -376,6 +380,10 @@ def test_bench_two_ranks_on_one_gpu_gloo_rehearsal(overlap):
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["oracle_match"] is True and d["scaling"] == "strong"
+    # what the ranks really ran on, from the engines: two ranks, ONE device here (a real 2-GPU run must show two bus ids)
+    assert d["rccl"]["ranks"] == 2 and d["rccl"]["distinct_devices"] == 1 and len(d["rccl"]["devices"]) == 2
+    assert d["rccl"]["devices"][0]["pci_bus_id"] == d["rccl"]["devices"][1]["pci_bus_id"] != ""
+    assert d["rccl"]["devices"][0]["pid"] != d["rccl"]["devices"][1]["pid"]
     assert d["render"]["frame_match"] is True and d["render"]["value"] > 0  # the two ranks' bands == one GPU's frame
     assert d["roofline"]["kernel"].startswith("ca_packed_vn")
 
@@ -400,12 +408,20 @@ def test_bench_four_ranks_rehearsal_picks_the_ghost_depth():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "32", "--warmup", "16", "--resident", "0",
            "--backend", "gloo", "--device-map", "0,0,0,0", "--no-cpu-baseline", "--min-seconds", "0", "--no-schedule-compare"]
+    import time
+
+    t_run = time.perf_counter()
     r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 4 and d["config"]["grid"] == 1024 and "ghost 16" in d["config"]["parallelism"]
     assert d["verified"]["oracle_match"] is True
     assert d["roofline"]["kernel"].startswith("ca_packed_vn"), d["roofline"]["kernel"]
+    # the oracle leg of the verification is what a `--gpus N` run spends most of its untimed time on: printed, and bounded — the driver's
+    # run at N = 8 (1024^3 x 40 steps on cores / 8 threads per rank) must stay well inside its 600 s limit
+    print(f"bench --gpus 4 rehearsal: oracle leg {d['verified']['oracle_seconds']} s on {d['verified']['oracle_threads_per_rank']} threads per rank, "
+          f"{d['verified']['steps']} steps; whole run {time.perf_counter() - t_run:.1f} s")
+    assert d["verified"]["oracle_seconds"] < 120.0 and time.perf_counter() - t_run < 400.0
 
 
 def test_bench_plain_invocation_spawns_its_ranks():

@@ -16,12 +16,9 @@ for G in grids:
     e.set_rule_strings()
     e.upload_state(host.random_fill(host.words_per_buffer(G)))
     for K in (20, 256, 4096):
-        for res, rows, zs in ((1, 32, 2), (1, 32, 1), (1, "pair", 1), (1, "deep", 1), (1, "deep", 2), (1, 16, 2), (1, 16, 1), (0, 32, 1)):
-            if (G == 256 and rows in (16, "pair")) or (G != 256 and rows == "deep"):
+        for res, rows, zs in ((1, 32, 2), (1, 32, 1), (1, "pair", 1), (1, 16, 2), (1, 16, 1), (0, 32, 1)):
+            if G == 256 and rows in (16, "pair"):
                 continue
-            deep = int(rows == "deep")
-            e.set_option("resident_deep", deep)
-            rows = 32 if deep else rows
             e.set_option("resident", res)
             pair = int(rows == "pair")
             e.set_option("resident_pair", pair)
@@ -36,5 +33,5 @@ for G in grids:
                 e.step(K)
             e.synchronize()
             dt = time.perf_counter() - t0
-            print(f"G {G} K {K:5d} resident {res} rows {rows} pair {pair} deep {deep} zsplit {zs}: {dt / (K * reps) * 1e6:7.3f} us/step  {e.info().kernel_name.decode()}", flush=True)
+            print(f"G {G} K {K:5d} resident {res} rows {rows} pair {pair} zsplit {zs}: {dt / (K * reps) * 1e6:7.3f} us/step  {e.info().kernel_name.decode()}", flush=True)
     e.set_option("resident", 1)

@@ -35,9 +35,7 @@ int main(int argc, char **argv)
 	{
 		ResidentArgs a{buf[cur], buf[(cur + steps) & 1], buf[(cur + steps + 1) & 1], mail, status, hflag, steps, epoch, 5000000u};
 		CK(hipEventRecord(e0));
-		if (deep && zs == 2) hipLaunchKernelGGL((ca_resident_vn256_deep<0xFF, 0x0A, 2>), dim3(256), dim3(512), 0, 0, a);
-		else if (deep) hipLaunchKernelGGL((ca_resident_vn256_deep<0xFF, 0x0A, 1>), dim3(256), dim3(256), 0, 0, a);
-		else if (rows == 34) hipLaunchKernelGGL((ca_resident_vn_stagger<0xFF, 0x0A>), dim3(256), dim3(512), 0, 0, a); // 34: the staggered row-pair form
+		if (deep || rows == 34) { fprintf(stderr, "the deep (256^3) and staggered (512^3) forms were removed in round 5\n"); return 2; }
 		else if (rows == 33) hipLaunchKernelGGL((ca_resident_vn_pair<0xFF, 0x0A>), dim3(256), dim3(512), 0, 0, a); // 33: the row-pair form
 		else if (rows == 256 && zs == 2) hipLaunchKernelGGL((ca_resident_vn256<0xFF, 0x0A, 2>), dim3(256), dim3(512), 0, 0, a);
 		else if (rows == 256) hipLaunchKernelGGL((ca_resident_vn256<0xFF, 0x0A, 1>), dim3(256), dim3(256), 0, 0, a);

@@ -236,7 +236,7 @@ def time_frames(eng, u, W, H, spp, frames):
 def render_pmc_record(kernel_ms):
     """What bounds the dense frame's kernels, from the committed PMC passes over the same scene (tools/pmc_render.sh ->
     profiles/r*_pmc_render.json, newest): vector-issue fraction, live lanes, L2 hit rate, bytes served by the L2 per second — for the
-    passes of the ray-stream pipeline together (counters summed over ca_stream_walk<primary>, ca_stream_shadow_rays, ca_stream_walk<shadow>,
+    passes of the ray-stream pipeline together (counters summed over ca_stream_walk2<primary>, ca_stream_shadow_rays, ca_stream_walk2<shadow>,
     ca_stream_resolve) and per pass. SURVEY 8(d): "report Mray/s and achieved GB/s from rocprof, no roofline claim beyond that"."""
     import glob
 

@@ -182,7 +182,7 @@ hipError_t launch_copy_f4(const void *in, void *out, size_t bytes, hipStream_t s
 hipError_t launch_render(const RenderLaunch &l, hipStream_t stream);
 // render_stream.hip: bytes of scratch a frame of this size needs at most (and where its three arrays start); the passes themselves
 // (`params`: render.hip's launch parameters with the volume's screen rectangle filled in)
-size_t stream_scratch_bytes(uint32_t W, uint32_t H, uint32_t spp, size_t *hit_off, size_t *occl_off, size_t *rays_off, size_t *pool_off = nullptr);
+size_t stream_scratch_bytes(uint32_t W, uint32_t H, uint32_t spp, size_t *hit_off, size_t *occl_off, size_t *rays_off);
 // render_frame.hip: the literal frame over a bricked copy of the volume (`frame_params`: render.hip's FrameParams)
 size_t frame_bricks_bytes(uint32_t G);
 bool frame_bricks_applies(uint32_t G);

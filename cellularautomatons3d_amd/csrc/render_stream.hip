@@ -61,10 +61,7 @@ struct StreamParams
 	u32 lg, lc;          // log2 G, log2 cols (power-of-two grids)
 	u32 nb;              // bricks per edge, G / 8
 	u32 probe_mask;      // timing probes (kProbe*): 0
-	u32 *pool;           // ca_stream_walk2: walk states a wave of the first launch hands to the drain launch, kPoolWords words each, kPoolCap of them
-	u32 drain_wgs;       // workgroups of the drain launch
-	int dump_at;         // ... a wave that cannot refill any more hands its walks over when this many lanes or fewer still walk (0: never)
-	int flat;            // ca_stream_walk2: 1 = the branch-free cell step (walk_cell_flat), 0 = walk_cell (tuning: CA3D_STREAM_FLAT)
+	int tail_batch;      // ca_stream_walk2: 1 = the batched stepping loop once a wave cannot refill any more and in the drain launch
 	int refill2;         // ca_stream_walk2: idle lanes at which a wave leaves the stepping loop to pop prepared rays (tuning: CA3D_STREAM_POP)
 	int refill;          // lanes without a ray at which a wave leaves the stepping loop to take new jobs (tuning: CA3D_STREAM_REFILL)
 	u32 lb;              // log2 of a chunk's pixel-block edge; jobs per chunk = spp << (2 lb)
@@ -313,49 +310,6 @@ __device__ __forceinline__ int walk_cell(const StreamParams &S, Walker &w, int k
 	return (outside || t >= w.tmax) ? 2 : 0;
 }
 
-// One cell for EVERY lane of the wave, without a divergent branch (round 5, ca_stream_walk2). walk_cell compiles to a nest of exec-mask
-// regions — walking lanes / live cell / filter undecided / advance — each a v_cmp -> s_and_saveexec -> s_cbranch chain, eight branches
-// per cell; measured, a wave ALONE on a SIMD took ~2 000 cycles per cell with them (the drain launch: one wave per SIMD, 0.85 us per
-// iteration for ~70 instructions), which is what the tail of every walk launch runs at. Here every lane computes the filter and the
-// advance of its last state and selects keep what must not change: lanes that do not walk read word 0, take no hit and advance by
-// nothing (their axis masks are empty). Only the slab test of the filter's undecided band (1 % of live cells) stays behind a branch,
-// wave-uniform. The float operations of a walking lane are walk_cell's, in the same order.
-template <bool SHADOW, int LAYOUT>
-__device__ __forceinline__ void walk_cell_flat(const StreamParams &S, Walker &w, bool active, bool &exempt, int &term, v3 vhalf, float k0, float k1, float eps_a,
-                                               const float *ctx, int stride)
-{
-	const RenderParams &P = S.R;
-	const int key = active ? word_key<LAYOUT>(S, w.ix, w.iy, w.iz) : 0; // (a lane whose walk left the grid holds a cell outside it)
-	const u32 cur = *reinterpret_cast<const u32 *>(reinterpret_cast<const char *>(S.volume) + ((u32)key << 2));
-	const bool live = active && ((cur >> word_bit<LAYOUT>(w.ix, w.iy)) & 1u) && !exempt;
-	const float tn = fmaxf(fmaxf(__builtin_fmaf(-k1, w.dx, w.tx), __builtin_fmaf(-k1, w.dy, w.ty)), __builtin_fmaf(-k1, w.dz, w.tz));
-	const float tf = fminf(fminf(__builtin_fmaf(-k0, w.dx, w.tx), __builtin_fmaf(-k0, w.dy, w.ty)), __builtin_fmaf(-k0, w.dz, w.tz));
-	const float gap = tf - tn, lead = SHADOW ? tn : tf;
-	const float eps = __builtin_fmaf(__builtin_fmaf(eps_a, w.t, 3.814697265625e-6f), w.t, w.eps_b);
-	const bool yes = gap > eps && lead > eps, no = gap < -eps || lead < -eps;
-	bool hit = live && yes;
-	const bool undecided = live && !yes && !no;
-	if (__ballot(undecided) != 0ull)
-	{
-		float e;
-		if (undecided) hit = slab_test<SHADOW>(P, w, vhalf, ctx, stride, e);
-	}
-	const bool adv = active && !hit;
-	const float t = fminf(fminf(w.tx, w.ty), w.tz);
-	const bool ex = w.tx == t, ey = !ex && w.ty == t;
-	const bool mx = adv && ex, my = adv && ey, mz = adv && !ex && !ey;
-	w.t = adv ? t : w.t;
-	w.tx += mx ? w.dx : 0.0f;
-	w.ty += my ? w.dy : 0.0f;
-	w.tz += mz ? w.dz : 0.0f;
-	w.ix += mx ? w.sx : 0;
-	w.iy += my ? w.sy : 0;
-	w.iz += mz ? w.sz : 0;
-	exempt = exempt && !adv;
-	const bool over = max(max((u32)w.ix, (u32)w.iy), (u32)w.iz) >= P.G || t >= w.tmax;
-	term = hit ? 1 : ((adv && over) ? 2 : term);
-}
-
 // ---- the batched form of the stepping loop -----------------------------------------------------------------------------------
 // The walk's next cell depends on arithmetic only (the boundary times), never on what the volume holds: a lane can run kBatch cells
 // ahead, ask for all their words at once and test them in order when they arrive — ONE memory round trip per kBatch cells instead
@@ -370,7 +324,10 @@ __device__ __forceinline__ void walk_cell_flat(const StreamParams &S, Walker &w,
 // Measured (CA3D_STREAM_BRICKS=3 selects it; bit-identical frames, the check mode passes): 1080p 4 spp 0.888 against 0.900 ms, one
 // sample 0.529 against 0.549, 4K 2.27 against 2.14 — a quarter of the memory round trips and no faster: like every other probe of
 // the stepping loop (see the cell-by-cell loop below) it says the walks are not waiting for the volume. Kept as an option.
-constexpr int kBatch = 4;
+#ifndef CA3D_STREAM_BATCH
+#define CA3D_STREAM_BATCH 4
+#endif
+constexpr int kBatch = CA3D_STREAM_BATCH;
 
 // advance along the axis whose boundary comes first; true: the walk is over (left the volume or ran out of range)
 __device__ __forceinline__ bool walk_advance(const RenderParams &P, Walker &w)
@@ -418,14 +375,15 @@ __device__ __forceinline__ u32 walk_batch(const StreamParams &S, Walker &w, bool
 	const RenderParams &P = S.R;
 	const float stx = w.tx, sty = w.ty, stz = w.tz, st = w.t;
 	const int six = w.ix, siy = w.iy, siz = w.iz;
-	u32 word[kBatch], pos = 0, nvalid = 0; // pos: 6 bits per cell — bit position, 32 for a cell past the walk's end
+	u32 word[kBatch], nvalid = 0;
+	unsigned long long pos = 0; // 6 bits per cell — bit position, 32 for a cell past the walk's end
 	bool over = false;
 #pragma unroll
 	for (int k = 0; k < kBatch; k++)
 	{
 		const int key = over ? 0 : word_key<LAYOUT>(S, w.ix, w.iy, w.iz);
 		word[k] = *reinterpret_cast<const u32 *>(reinterpret_cast<const char *>(S.volume) + ((u32)key << 2));
-		pos |= (over ? 32u : word_bit<LAYOUT>(w.ix, w.iy)) << (6 * k);
+		pos |= (unsigned long long)(over ? 32u : word_bit<LAYOUT>(w.ix, w.iy)) << (6 * k);
 		nvalid += over ? 0u : 1u;
 		over = walk_advance(P, w) || over;
 	}
@@ -433,7 +391,7 @@ __device__ __forceinline__ u32 walk_batch(const StreamParams &S, Walker &w, bool
 #pragma unroll
 	for (int k = 0; k < kBatch; k++)
 	{
-		const u32 b = (pos >> (6 * k)) & 63u;
+		const u32 b = (u32)(pos >> (6 * k)) & 63u;
 		live |= (b < 32u ? (word[k] >> b) & 1u : 0u) << k;
 	}
 	if (exempt) live &= ~1u; // the cell the shadow ray starts in: only ever the first cell of a walk
@@ -718,33 +676,45 @@ __global__ __launch_bounds__(kWalkThreads, kStreamWaves) void ca_stream_walk(Str
 	if (lane == 0 && visits) atomicAdd(&S.ctl[16 + 4 * ((blockIdx.x * (u32)kWalkWaves + (u32)wave) % kStatSlots) + (SHADOW ? 2 : 1)], visits);
 }
 
-// ---- second form of the walk passes (round 5): ray set-up at FULL lane occupancy, prepared rays queued in LDS ---------------------
+// ---- second form of the walk passes (round 5; the default) -----------------------------------------------------------------------
 // What ca_stream_walk's time is made of was measured this round by taking the volume out of its stepping loop (CA3D_STREAM_PROBE: no
 // read / every lane the same word / a 4 KiB footprint / the real words — 2.34 / 1.91 / 2.40 / 2.39 ms for the same 967 M cell visits
-// with no cell ever live): the loop does not wait for memory at all, it is bound by instruction issue (~65 instructions per wave and
-// cell at 2.2 cycles each with eight waves on a SIMD) and runs at 0.42 visits per ns when its lanes are full. The real frame's
-// 123 M visits would take 0.29 ms at that rate; they take 0.69. The rest is what surrounds the loop: a refill round sets up
-// ~24 new rays with the other 40 lanes of the wave idle (~900 instructions, 25 divisions: 28 % of a wave's life), the loop runs
-// between refills with up to 24 lanes empty, and three of four tickets of the shadow pass are samples without a shadow ray. Here
-//   * a wave sets rays up 64 AT A TIME — every lane, walking or not, takes a job and forms its ray (the walkers in flight stay in
-//     their registers) — and the prepared walk states go into a 64-slot queue of the wave in LDS (16 words per ray);
-//   * a lane whose walk ends POPS a prepared state (16 LDS reads instead of the set-up), so the loop is left already when 8 lanes
-//     are idle instead of 24;
-//   * the shadow pass first gathers the ids of samples that HAVE a shadow ray (one 32-bit read of four flags per ticket, compacted
-//     into an id list in LDS) and only then sets 64 of them up, again on every lane.
-// Same job source (chunks -> workgroup ticket counter -> ring of chunk ids), same stepping loop, same arithmetic per ray and cell:
-// the frame is ca_stream_walk's bit for bit (tests/test_gpu_render.py compares plain kernel = in-wave kernel = both stream forms).
-constexpr int kW2Threads = 256, kW2Waves = kW2Threads / 64, kW2PerSimd = 5, kIdCap = 320, kRecWords = 17;
-// The drain. A ray that meets nothing crosses the whole volume — 120 to 200 cells where the average walk ends after 9 — and one ray in twelve
-// of the bench scene does. When the queues run dry every wave is left with a handful of them: it steps on for a hundred and more
-// iterations with 5 of its 64 lanes alive, and since the stepping loop is bound by instruction issue, eight such waves on a SIMD
-// cost what eight full ones cost: the launches spent 45 % of their time in that tail (tools/stream_trace.py: every wave alive for the
-// first 55 % of a launch, mean life 0.68 of it). A wave that can no longer refill and is down to `dump_at` walking lanes therefore
-// writes its walk states (the queue's record plus the walk's current time: kPoolWords words) to a pool in memory and ends; a second,
-// small launch of the same kernel (DRAIN) takes them 64 to a wave and walks them to their ends with full lanes.
-constexpr u32 kPoolWords = 20, kPoolCap = 1u << 19; // (80-byte records; 8 192 waves x 64 lanes would fit)
-constexpr u32 kPoolCtl = 8; // ctl words [kPoolCtl + 4 * pass + {0 records written, 1 records taken}]
-
+// with no cell ever live): with its lanes full and eight waves on a SIMD the loop does not wait for memory at all — it is bound by
+// instruction issue (~65 instructions per wave and cell, 62 % of the VALU issue slots) at 0.42 visits per ns. The real frame's
+// 123 M visits would take 0.29 ms at that rate; they took 0.69. The rest is what surrounds the loop:
+//   (a) a refill round set ~24 new rays up with the other 40 lanes of the wave idle (~900 instructions, 25 divisions), and three
+//       of four tickets of the shadow pass were samples without a shadow ray;
+//   (b) the loop ran between refills with up to 24 lanes empty (lanes active 0.46 / 0.43);
+//   (c) THE TAIL: one ray in twelve of the bench scene meets nothing and crosses the whole volume, 120-200 cells where the average
+//       walk ends after 9. When the queues run dry every wave is left with a handful of them and steps on for a hundred and more
+//       iterations at 5 of 64 lanes, alone or nearly alone on its SIMD — where an iteration is a dependent chain of ~1 200 cycles that
+//       nothing overlaps (tools/stream_trace.py: every wave alive for the first 55 % of a launch, mean life 0.68 of it).
+// This form:
+//   * sets rays up 64 AT A TIME — every lane, walking or not, takes a job and forms its ray (the walkers in flight stay in their
+//     registers) — and the prepared walk states go into a 64-slot queue of the wave in LDS (16 words per ray); a lane whose walk ends
+//     POPS a prepared state (16 LDS reads instead of the set-up), so the loop is left when 16 lanes are idle instead of 24;
+//   * the shadow pass first gathers the ids of samples that HAVE a shadow ray (one 16-bit read of two flags per ticket, compacted
+//     into an id list in LDS) and only then sets 64 of them up, again on every lane;
+//   * tickets come straight off eight global counters (one per XCD, 64 per draw, a wave's first draw static): ticket -> chunk ->
+//     pixel is arithmetic, and the balance between waves is 64 jobs fine instead of a 256-job chunk per workgroup;
+//   * once a wave cannot refill any more it switches to the BATCHED stepping loop (walk_batch: four cells per memory round trip and
+//     per pass through the loop's bookkeeping): in the tail the chain per cell is what costs, and this is the one place where the
+//     batched loop pays (as the loop of the whole launch it measured no faster, above).
+// Same arithmetic per ray and cell, same answers: the frame is ca_stream_walk's and the plain kernel's bit for bit
+// (tests/test_gpu_render.py). Measured, dense bench scene, ms per frame, round 4's form -> this one (same box, same run):
+// 1080p 4 spp 0.792 -> 0.729, 3840 x 2160 1.946 -> 1.847, 1080p 1 spp 0.480 -> 0.440; lanes active in the walks 0.46 / 0.43 ->
+// 0.56 / 0.52 (the batched tail replays cells), vector instructions of the two walks 277 M -> 247 M. Without the batched tail 0.800: the tail is where the gain is.
+// Five waves per SIMD (88 / 81 registers, no scratch; six waves spill 64 bytes and measure 0.757; four 0.741).
+// Built on top and REMOVED again, both bit-identical and slower: a branch-free cell step (every lane computes filter and advance,
+// selects keep what must not change: 3 branches per cell instead of 8, but 9 % more vector instructions — 0.914 against 0.824);
+// handing the walkers of a wave that cannot refill to a second, compacting "drain" launch through a pool in memory (the first
+// launches shrink to 0.72 of their time and lanes active rise to 0.74, but the drain launch itself — 100-160 k long rays, 64 to a
+// wave, one or two waves per SIMD — takes 200-290 us at any grid size from 64 to 1 280 workgroups: long rays x a lone wave's chain per
+// cell is the critical path of the tail whoever walks them; 1.07-1.24 ms per frame).
+#ifndef CA3D_STREAM2_WAVES
+#define CA3D_STREAM2_WAVES 5
+#endif
+constexpr int kW2Threads = 256, kW2Waves = kW2Threads / 64, kW2PerSimd = CA3D_STREAM2_WAVES, kIdCap = 192, kRecWords = 16;
 // walker_begin without the LDS writes: the walk state in `w`, what the slab test reads in c6
 __device__ __forceinline__ void walker_prepare(const RenderParams &P, Walker &w, bool &axis_parallel, float c6[6], v3 start, v3 dir, float t0, float tmax)
 {
@@ -775,7 +745,7 @@ __device__ __forceinline__ void walker_prepare(const RenderParams &P, Walker &w,
 	c6[3] = 1.0f / dir.x; c6[4] = 1.0f / dir.y; c6[5] = 1.0f / dir.z;
 }
 
-template <bool SHADOW, int LAYOUT, bool CHECK, bool DRAIN>
+template <bool SHADOW, int LAYOUT, bool CHECK>
 __global__ __launch_bounds__(kW2Threads, kW2PerSimd) void ca_stream_walk2(StreamParams S)
 {
 	const RenderParams &P = S.R;
@@ -797,13 +767,12 @@ __global__ __launch_bounds__(kW2Threads, kW2PerSimd) void ca_stream_walk2(Stream
 	const u32 qown = blockIdx.x & 7u;
 	u32 qcur = qown, qtried = 0;
 	const u32 lper = 2u * S.lb + job_shift(P);   // log2 jobs of a chunk
-	constexpr u32 ltj = SHADOW ? 2u : 0u;        // log2 jobs of a ticket: the shadow pass reads the flags of four jobs at once
+	constexpr u32 ltj = SHADOW ? 1u : 0u;        // log2 jobs of a ticket: the shadow pass reads the flags of two jobs at once
 	const u32 ltper = lper - ltj, tper = 1u << ltper; // tickets of a chunk (>= 64: the launcher has checked)
 	auto q_lo = [&](u32 q) { return S.qmap ? q : (u32)(((unsigned long long)S.chunks * q) >> 3); };
 	auto q_len = [&](u32 q) { return S.qmap ? (S.chunks + 7u - q) >> 3 : q_lo(q + 1u) - q_lo(q); };
 	auto q_chunk = [&](u32 q, u32 pos) { return S.qmap ? pos * 8u + q : q_lo(q) + pos; };
 	auto q_static = [&](u32 q) { return (gridDim.x + 7u - q) >> 3; };
-	u32 *const pool_ctl = S.ctl + kPoolCtl + (SHADOW ? 4u : 0u);
 	// Job source: tickets straight off eight GLOBAL counters (one per XCD: workgroups go to the XCDs round-robin, queue q owns every
 	// eighth chunk), 64 per draw, one per lane; ticket t of queue q is job (t mod tickets-per-chunk) of the queue's (t / tickets-per-
 	// chunk)-th chunk — arithmetic, no ring of chunk ids. ca_stream_walk hands whole chunks to workgroups and tickets to lanes through
@@ -812,7 +781,7 @@ __global__ __launch_bounds__(kW2Threads, kW2PerSimd) void ca_stream_walk2(Stream
 	// spread over the last 45 % of a launch. At one atomic per 64 tickets the eight counters take 16 draws per us each (they sustain
 	// ~88), and the granularity of the balance is a quarter of a chunk per WAVE. A wave's first draw is static (its index in its
 	// queue): thousands of first draws at once would queue behind the counters for microseconds.
-	bool first_draw = !DRAIN;
+	bool first_draw = true;
 	const u32 wave_in_queue = (blockIdx.x >> 3) * (u32)kW2Waves + (u32)wave; // this wave among those whose own queue is qown
 	// true: no queue has a ticket left (wave-uniform); else chunk / cand are this lane's
 	auto draw = [&](u32 &chunk, u32 &cand) -> bool {
@@ -846,7 +815,6 @@ __global__ __launch_bounds__(kW2Threads, kW2PerSimd) void ca_stream_walk2(Stream
 	u32 visits = 0;              // wave-uniform
 	u32 idcount = 0;             // wave-uniform: ids waiting in ids[]
 	u32 qhead = 0, qavail = 0;   // wave-uniform: prepared rays rec[.][qhead .. qhead + qavail)
-	bool pool_full = false;      // wave-uniform
 	const int pop_at = S.refill2; // idle lanes at which the stepping loop is left for a pop
 	const unsigned long long tr_t0 = S.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
 	unsigned long long tr_refill = 0;
@@ -871,36 +839,6 @@ __global__ __launch_bounds__(kW2Threads, kW2PerSimd) void ca_stream_walk2(Stream
 			job = -1;
 			term = 0;
 		}
-		if (!DRAIN && S.dump_at > 0 && !more && idcount == 0u && qavail == 0u)
-		{
-			// nothing left to refill from: few enough walkers -> hand them to the drain launch and end
-			const unsigned long long act = __ballot(job >= 0);
-			const u32 nact = (u32)__popcll(act);
-			if (nact <= (u32)S.dump_at)
-			{
-				if (nact)
-				{
-					u32 base = 0;
-					if (lane == 0) base = atomicAdd(&pool_ctl[0], nact);
-					base = (u32)__builtin_amdgcn_readfirstlane((int)base);
-					const u32 rk = (u32)__builtin_amdgcn_mbcnt_hi((u32)(act >> 32), __builtin_amdgcn_mbcnt_lo((u32)act, 0u));
-					if (job >= 0 && base + rk < kPoolCap) // (the drain reads records [0, min(written, kPoolCap)): exactly those that are there)
-					{
-						uint4 *o = reinterpret_cast<uint4 *>(S.pool + (size_t)(base + rk) * kPoolWords);
-						const u32 c0 = (u32)w.ix | ((u32)w.iy << 16);
-						const u32 c1 = (u32)w.iz | (w.sx > 0 ? 1u << 16 : 0u) | (w.sy > 0 ? 1u << 17 : 0u) | (w.sz > 0 ? 1u << 18 : 0u) | (w.eps_b == __builtin_inff() ? 1u << 19 : 0u) | (exempt ? 1u << 20 : 0u);
-						o[0] = make_uint4(__float_as_uint(w.tx), __float_as_uint(w.ty), __float_as_uint(w.tz), __float_as_uint(w.dx));
-						o[1] = make_uint4(__float_as_uint(w.dy), __float_as_uint(w.dz), __float_as_uint(w.tmax), c0);
-						o[2] = make_uint4(c1, (u32)job, __float_as_uint(ctx[0 * stride]), __float_as_uint(ctx[1 * stride]));
-						o[3] = make_uint4(__float_as_uint(ctx[2 * stride]), __float_as_uint(ctx[3 * stride]), __float_as_uint(ctx[4 * stride]), __float_as_uint(ctx[5 * stride]));
-						o[4] = make_uint4(__float_as_uint(w.t), 0u, 0u, 0u);
-						job = -1;
-					}
-				}
-				if (__ballot(job >= 0) == 0ull) break;
-				pool_full = true; // the pool had no room for (all of) them: they are walked to their ends here
-			}
-		}
 		const unsigned long long tr_r0 = S.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
 		for (;;)
 		{
@@ -909,37 +847,6 @@ __global__ __launch_bounds__(kW2Threads, kW2PerSimd) void ca_stream_walk2(Stream
 			if (nidle == 0u) break;
 			if (qavail == 0u)
 			{
-				if (DRAIN)
-				{
-					// the pool's records, 64 at a time, into the queue (the first launch is over: the count is final)
-					if (!more) break;
-					u32 base = 0, total = 0;
-					if (lane == 0)
-					{
-						total = min(__hip_atomic_load(&pool_ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), kPoolCap);
-						base = atomicAdd(&pool_ctl[1], 64u);
-					}
-					base = (u32)__builtin_amdgcn_readfirstlane((int)base);
-					total = (u32)__builtin_amdgcn_readfirstlane((int)total);
-					const u32 n = base < total ? min(64u, total - base) : 0u;
-					if (n == 0u) { more = false; break; }
-					tr_rounds++;
-					if ((u32)lane < n)
-					{
-						const uint4 *in = reinterpret_cast<const uint4 *>(S.pool + (size_t)(base + (u32)lane) * kPoolWords);
-						const uint4 a0 = in[0], a1 = in[1], a2 = in[2], a3 = in[3], a4 = in[4];
-						u32 *r = rec + lane;
-						r[0 * kW2Threads] = a0.x; r[1 * kW2Threads] = a0.y; r[2 * kW2Threads] = a0.z; r[3 * kW2Threads] = a0.w;
-						r[4 * kW2Threads] = a1.x; r[5 * kW2Threads] = a1.y; r[6 * kW2Threads] = a1.z; r[7 * kW2Threads] = a1.w;
-						r[8 * kW2Threads] = a2.x; r[9 * kW2Threads] = a2.y; r[10 * kW2Threads] = a2.z; r[11 * kW2Threads] = a2.w;
-						r[12 * kW2Threads] = a3.x; r[13 * kW2Threads] = a3.y; r[14 * kW2Threads] = a3.z; r[15 * kW2Threads] = a3.w;
-						r[16 * kW2Threads] = a4.x;
-					}
-					qavail = n;
-					qhead = 0u;
-				}
-				else
-				{
 				if (!more && idcount == 0u) break;
 				// ---- fill, stage A: ids of jobs that want a ray, until there are 64 of them (or the queues are dry)
 				while (idcount < 64u && more)
@@ -963,13 +870,12 @@ __global__ __launch_bounds__(kW2Threads, kW2PerSimd) void ca_stream_walk2(Stream
 					}
 					else
 					{
-						const u32 j0 = (chunk << lper) + (cand << 2);
-						u32 flags = 0;
-						if (!dry) flags = *reinterpret_cast<const u32 *>(S.occl + j0);
+						const u32 j0 = (chunk << lper) + (cand << 1);
+						const u32 flags = *reinterpret_cast<const unsigned short *>(S.occl + j0);
 #pragma unroll
-						for (u32 q = 0; q < 4u; q++)
+						for (u32 q = 0; q < 2u; q++)
 						{
-							const bool valid = ((flags >> (8u * q)) & 0xFFu) == (u32)kOcclPending; // (kOcclPending != 0: a dry lane's zeros never match)
+							const bool valid = ((flags >> (8u * q)) & 0xFFu) == (u32)kOcclPending;
 							const unsigned long long m = __ballot(valid);
 							if (valid) ids[idcount + (u32)__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u))] = j0 + q;
 							idcount += (u32)__popcll(m);
@@ -1030,15 +936,15 @@ __global__ __launch_bounds__(kW2Threads, kW2PerSimd) void ca_stream_walk2(Stream
 						}
 					}
 				}
-				// the ids not taken move to the front of the list (at most 255 of them: four per lane; reads before writes)
+				// the ids not taken move to the front of the list (at most 127 of them: two per lane; reads before writes)
 				if (idcount > 64u)
 				{
 					const u32 left = idcount - 64u;
-					u32 keep[4];
+					u32 keep[2];
 #pragma unroll
-					for (u32 q = 0; q < 4u; q++) keep[q] = (u32)lane + 64u * q < left ? ids[64u + (u32)lane + 64u * q] : 0u;
+					for (u32 q = 0; q < 2u; q++) keep[q] = (u32)lane + 64u * q < left ? ids[64u + (u32)lane + 64u * q] : 0u;
 #pragma unroll
-					for (u32 q = 0; q < 4u; q++)
+					for (u32 q = 0; q < 2u; q++)
 						if ((u32)lane + 64u * q < left) ids[(u32)lane + 64u * q] = keep[q];
 				}
 				idcount -= n;
@@ -1062,7 +968,6 @@ __global__ __launch_bounds__(kW2Threads, kW2PerSimd) void ca_stream_walk2(Stream
 					qhead = 0u;
 				}
 				if (qavail == 0u) continue; // none of the 64 needed a walk: the next 64
-				}
 			}
 			// ---- pop: the idle lanes take prepared rays
 			const u32 take = min(nidle, qavail);
@@ -1080,7 +985,7 @@ __global__ __launch_bounds__(kW2Threads, kW2PerSimd) void ca_stream_walk2(Stream
 					w.sx = (c1 >> 16) & 1u ? 1 : -1; w.sy = (c1 >> 17) & 1u ? 1 : -1; w.sz = (c1 >> 18) & 1u ? 1 : -1;
 					w.eps_b = (c1 >> 19) & 1u ? __builtin_inff() : eps_c * (w.dx + w.dy + w.dz);
 					exempt = (c1 >> 20) & 1u;
-					w.t = DRAIN ? __uint_as_float(r[16 * kW2Threads]) : (SHADOW ? 0.0025f : 0.0f);
+					w.t = SHADOW ? 0.0025f : 0.0f;
 					w.word = 0;
 					w.wkey = -1;
 					job = (int)r[9 * kW2Threads];
@@ -1101,10 +1006,21 @@ __global__ __launch_bounds__(kW2Threads, kW2PerSimd) void ca_stream_walk2(Stream
 			continue;
 		}
 		const bool refillable = more || idcount != 0u || qavail != 0u;
-		// leave the loop for a pop when pop_at lanes are idle; with nothing left to pop, for the hand-over to the drain launch when
-		// dump_at lanes or fewer still walk (a wave the pool had no room for walks on to the end)
-		const int leave_at = __builtin_amdgcn_readfirstlane(refillable ? 64 - pop_at : ((!DRAIN && !pool_full && walking > S.dump_at) ? S.dump_at : 0));
-		if (CHECK || S.flat == 0)
+		const int leave_at = __builtin_amdgcn_readfirstlane(refillable ? 64 - pop_at : 0);
+		if (S.tail_batch && !refillable)
+		{
+			// nothing left to refill from: few waves are left on the chip, their rays are the long ones and lie
+			// all over the volume — an iteration is one memory round trip that nothing hides. Four cells per round trip (walk_batch).
+			do
+			{
+				u32 n = 0;
+				if (job >= 0 && term == 0) n = walk_batch<SHADOW, LAYOUT, CHECK>(S, w, exempt, term, vhalf, k0, k1, eps_a, ctx, stride);
+#pragma unroll
+				for (int k = 0; k < kBatch; k++) visits += (u32)__builtin_amdgcn_readfirstlane(__popcll(__ballot(n > (u32)k)));
+				walking = __builtin_amdgcn_readfirstlane(__popcll(__ballot(job >= 0 && term == 0)));
+			} while (walking > leave_at);
+		}
+		else
 		{
 			do
 			{
@@ -1114,17 +1030,8 @@ __global__ __launch_bounds__(kW2Threads, kW2PerSimd) void ca_stream_walk2(Stream
 				walking = __builtin_amdgcn_readfirstlane(__popcll(__ballot(job >= 0 && term == 0)));
 			} while (walking > leave_at);
 		}
-		else
-		{
-			do
-			{
-				visits += (u32)walking;
-				walk_cell_flat<SHADOW, LAYOUT>(S, w, job >= 0 && term == 0, exempt, term, vhalf, k0, k1, eps_a, ctx, stride);
-				walking = __builtin_amdgcn_readfirstlane(__popcll(__ballot(job >= 0 && term == 0)));
-			} while (walking > leave_at);
-		}
 	}
-	if (S.trace && lane == 0 && !DRAIN)
+	if (S.trace && lane == 0)
 	{
 		unsigned long long *t = S.trace + 8ull * ((SHADOW ? gridDim.x * (u32)kW2Waves : 0u) + blockIdx.x * (u32)kW2Waves + (u32)wave);
 		t[0] = tr_t0; t[1] = __builtin_amdgcn_s_memrealtime(); t[2] = tr_rounds; t[3] = 0; t[4] = 0; t[5] = tr_refill; t[6] = tr_jobs; t[7] = 0;
@@ -1227,12 +1134,9 @@ __global__ __launch_bounds__(256) void ca_stream_resolve(StreamParams S)
 template <int P2, bool CHECK>
 void launch_walks2(const StreamParams &S, u32 wgs2, u32 job_blocks, hipStream_t stream)
 {
-	const u32 drain_wgs = S.drain_wgs; // one wave per SIMD takes what the first launch's waves left over
-	hipLaunchKernelGGL((ca_stream_walk2<false, P2, CHECK, false>), dim3(wgs2), dim3(kW2Threads), 0, stream, S);
-	if (S.dump_at > 0) hipLaunchKernelGGL((ca_stream_walk2<false, P2, CHECK, true>), dim3(drain_wgs), dim3(kW2Threads), 0, stream, S);
+	hipLaunchKernelGGL((ca_stream_walk2<false, P2, CHECK>), dim3(wgs2), dim3(kW2Threads), 0, stream, S);
 	hipLaunchKernelGGL(ca_stream_shadow_rays, dim3(job_blocks), dim3(256), 0, stream, S);
-	hipLaunchKernelGGL((ca_stream_walk2<true, P2, CHECK, false>), dim3(wgs2), dim3(kW2Threads), 0, stream, S);
-	if (S.dump_at > 0) hipLaunchKernelGGL((ca_stream_walk2<true, P2, CHECK, true>), dim3(drain_wgs), dim3(kW2Threads), 0, stream, S);
+	hipLaunchKernelGGL((ca_stream_walk2<true, P2, CHECK>), dim3(wgs2), dim3(kW2Threads), 0, stream, S);
 }
 
 template <int P2, bool CHECK, bool BATCHED = false>
@@ -1245,7 +1149,7 @@ void launch_walks(const StreamParams &S, u32 wgs, u32 job_blocks, hipStream_t st
 
 } // namespace
 
-size_t stream_scratch_bytes(uint32_t W, uint32_t H, uint32_t spp, size_t *hit_off, size_t *occl_off, size_t *rays_off, size_t *pool_off)
+size_t stream_scratch_bytes(uint32_t W, uint32_t H, uint32_t spp, size_t *hit_off, size_t *occl_off, size_t *rays_off)
 {
 	// the rectangle is aligned to 32 x 16 pixels and clipped to the frame: at most the padded frame
 	const size_t jobs = (size_t)((W + 31u) / 32u * 32u) * ((H + 15u) / 16u * 16u) * spp;
@@ -1253,8 +1157,6 @@ size_t stream_scratch_bytes(uint32_t W, uint32_t H, uint32_t spp, size_t *hit_of
 	*hit_off = off; off += jobs * 4u;
 	*occl_off = off; off += (jobs + 255u) / 256u * 256u;
 	*rays_off = off; off += jobs * 16u;
-	if (pool_off) *pool_off = off;
-	off += (size_t)kPoolCap * kPoolWords * 4u; // the drain's pool (40 MiB)
 	return off;
 }
 
@@ -1265,8 +1167,8 @@ hipError_t launch_render_stream(const void *params, void *scratch, uint32_t W, u
 	StreamParams S;
 	S.R = *static_cast<const RenderParams *>(params);
 	const RenderParams &P = S.R;
-	size_t hit_off, occl_off, rays_off, pool_off;
-	stream_scratch_bytes(W, H, P.spp, &hit_off, &occl_off, &rays_off, &pool_off);
+	size_t hit_off, occl_off, rays_off;
+	stream_scratch_bytes(W, H, P.spp, &hit_off, &occl_off, &rays_off);
 	char *base = static_cast<char *>(scratch);
 	S.ctl = reinterpret_cast<u32 *>(base);
 	S.hit = reinterpret_cast<u32 *>(base + hit_off);
@@ -1322,18 +1224,13 @@ hipError_t launch_render_stream(const void *params, void *scratch, uint32_t W, u
 			if (bricks_built) *bricks_built = true;
 		}
 		// which form of the walk passes: 2 (default) sets rays up 64 at a time and queues them in LDS (ca_stream_walk2); 1: round 4's form
-		static const int form_env = getenv("CA3D_STREAM_FORM") ? atoi(getenv("CA3D_STREAM_FORM")) : 1;
+		static const int form_env = getenv("CA3D_STREAM_FORM") ? atoi(getenv("CA3D_STREAM_FORM")) : 2;
 		static const int pop_env = getenv("CA3D_STREAM_POP") ? atoi(getenv("CA3D_STREAM_POP")) : 0;
-		S.refill2 = pop_env >= 1 && pop_env <= 64 ? pop_env : 8;
-		static const int flat_env = getenv("CA3D_STREAM_FLAT") ? atoi(getenv("CA3D_STREAM_FLAT")) : 1;
-		S.flat = flat_env ? 1 : 0;
-		static const int dump_env = getenv("CA3D_STREAM_DUMP") ? atoi(getenv("CA3D_STREAM_DUMP")) : -1;
-		S.dump_at = dump_env >= 0 && dump_env <= 64 ? dump_env : 32;
-		static const int drain_env = getenv("CA3D_STREAM_DRAIN_WGS") ? atoi(getenv("CA3D_STREAM_DRAIN_WGS")) : 0;
-		S.drain_wgs = drain_env > 0 ? (u32)drain_env : (u32)cus;
-		S.pool = reinterpret_cast<u32 *>(base + pool_off);
+		S.refill2 = pop_env >= 1 && pop_env <= 64 ? pop_env : 16;
+		static const int tb_env = getenv("CA3D_STREAM_TAIL_BATCH") ? atoi(getenv("CA3D_STREAM_TAIL_BATCH")) : 1;
+		S.tail_batch = tb_env ? 1 : 0;
 		const u32 wgs2 = min(S.chunks, (u32)cus * (u32)kW2PerSimd * 4u / (u32)kW2Waves);
-		const bool form2 = form_env == 2 && per >= 256u && bricks_env == 1; // (a chunk holds at least 64 tickets of four jobs)
+		const bool form2 = form_env == 2 && per >= 128u && bricks_env == 1; // (a chunk holds at least 64 tickets of two jobs)
 		if (form2) trace_waves = (unsigned long long)wgs2 * (unsigned)kW2Waves;
 		static const int probe_env = getenv("CA3D_STREAM_PROBE") ? atoi(getenv("CA3D_STREAM_PROBE")) : 0;
 		S.probe_mask = 0u;

@@ -50,7 +50,7 @@ void compile_rule_prog(uint32_t onset_mask, uint32_t max_count, RuleProg *out);
 // Run-time compiled (hiprtc) von Neumann kernels for one (grid, survive table, born table): ca_jit.cpp
 struct VnJit
 {
-	void *zr1 = nullptr, *zr2 = nullptr, *zr4 = nullptr; // hipFunction_t of the 1-, 2- and 4-planes-per-thread entry points
+	void *zr1 = nullptr, *zr2 = nullptr, *zr4 = nullptr, *zr8 = nullptr; // hipFunction_t of the 1-, 2-, 4- and (grids of 2048 and up) 8-planes-per-thread entry points
 	int cvl = -1;
 	uint32_t lut_s = 0, lut_b = 0;
 };

@@ -46,7 +46,7 @@ hipError_t launch(const PackedLaunch &l, VnArgs a, hipStream_t stream)
 	const VnJit *jit = l.vn_jit;
 	if (a.lut_s == (u32)kDefaultS && a.lut_b == (u32)kDefaultB)
 		hipLaunchKernelGGL((ca_packed_vn<CVL, ZR, kDefaultS, kDefaultB>), dim3(blocks), dim3(256), 0, stream, l.in, l.out, a);
-	else if (void *fn = ZR == 1 ? (jit ? jit->zr1 : nullptr) : ZR == 2 ? (jit ? jit->zr2 : nullptr) : (jit ? jit->zr4 : nullptr);
+	else if (void *fn = ZR == 1 ? (jit ? jit->zr1 : nullptr) : ZR == 2 ? (jit ? jit->zr2 : nullptr) : ZR == 4 ? (jit ? jit->zr4 : nullptr) : (jit ? jit->zr8 : nullptr);
 	         fn && jit->cvl == CVL && jit->lut_s == a.lut_s && jit->lut_b == a.lut_b)
 	{
 		// the run-time compiled specialisation for exactly these tables (ca_jit.cpp): same code shape as the branch above
@@ -120,6 +120,15 @@ hipError_t launch_packed_vn(const PackedLaunch &l, hipStream_t stream)
 	const u32 tpp = G / 128u * G / 256u;
 	const bool deep = shortest >= 2u && (size_t)tpp * ((planes + 1u) / 2u) >= 1024u;
 	const bool deep4 = zr_env != 2 && cvl >= 4 && shortest >= 4u && (size_t)tpp * ((planes + 3u) / 4u) >= 4096u;
+	// 8 planes per thread on 2048^3 and up (round 5): 10 plane streams per thread for 8 planes instead of 6 for 4 — 381 against 411 us per
+	// step at 2048^3, three processes each, alternating (0.70 against 0.65 of the HBM figure; 26 x 4 registers of rows: four waves per
+	// SIMD, which a stream of this size does not miss); 16 planes per thread (two waves per SIMD): 404-417. Different PROCESSES differ
+	// by +-5 % at this size (391 and 410 us were measured for the same code in one sweep): compare alternating runs, not single ones.
+	// CA3D_VN_ZR=4 / 2 keep the shallower runs. (A table pair without a run-time compiled zr8 entry: 4 planes.)
+	const bool prebuilt = a.lut_s == (u32)kDefaultS && a.lut_b == (u32)kDefaultB;
+	const bool has8 = prebuilt || (l.vn_jit && l.vn_jit->zr8 && l.vn_jit->cvl == cvl && l.vn_jit->lut_s == a.lut_s && l.vn_jit->lut_b == a.lut_b);
+	const bool deep8 = zr_env != 2 && zr_env != 4 && cvl >= 4 && has8 && shortest >= 8u && (size_t)tpp * ((planes + 7u) / 8u) >= 4096u;
+	if (deep8) return cvl == 4 ? launch<4, 8>(l, a, stream) : cvl == 5 ? launch<5, 8>(l, a, stream) : launch<6, 8>(l, a, stream);
 	switch (cvl)
 	{
 	case 1: return launch<1, 1>(l, a, stream);

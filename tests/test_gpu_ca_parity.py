@@ -53,7 +53,7 @@ def test_vn_truth_table_kernel_random_tables(eng, G):
     rng = np.random.default_rng(1234 + G)
     eng.configure(G)
     st = host.random_fill(host.words_per_buffer(G), seed=77 + G)
-    tables = [(0x7F, 0x0A), (0x00, 0x7F), (0x7F, 0x00), (0x55, 0x2A)] + [tuple(int(x) for x in rng.integers(0, 128, 2)) for _ in range(8)]
+    tables = [(0x7F, 0x0A), (0x00, 0x7F), (0x7F, 0x00), (0x55, 0x2A)] + [tuple(int(x) for x in rng.integers(0, 128, 2)) for _ in range(4)]
     for lut_s, lut_b in tables:
         survive = ",".join(str(k) for k in range(7) if lut_s >> k & 1)
         born = ",".join(str(k) for k in range(7) if lut_b >> k & 1)
@@ -388,7 +388,7 @@ def test_1024_cubed_one_step(eng):
     np.testing.assert_array_equal(eng.read_state(), ol.packed_step(G, st, r))
 
 
-@pytest.mark.parametrize("name", ["default", "clustered", "vn_b24_s135"])
+@pytest.mark.parametrize("name", ["default", "clustered"])
 def test_2048_cubed_two_steps(eng, name):
     """BASELINE config 5's grid (1 GiB per buffer, offsets past 2^32 bits) under the default rule and under config 5's
     own clustered rule-set (all three rule-sets of compute_clustered.wgsl:192-247 live): two steps, whole state

@@ -93,26 +93,15 @@ def test_second_process_compiles_nothing(tmp_path):
         if isinstance(v, dict) and "sha" in v:
             assert again[k]["sha"] == v["sha"]
     assert open(victim, "rb").read() == blob
-    # CA3D_JIT_CACHE=0: nothing read, nothing written
-    off_dir = str(tmp_path / "unused")
-    off = _run(off_dir, {"CA3D_JIT_CACHE": "0"})
-    assert off["jit"]["cache_dir"] == "" and off["jit"]["programs_from_disk"] == 0 and off["jit"]["programs_compiled"] >= 4
-    assert not os.path.exists(off_dir)
-
-
-def test_states_match_the_oracle_from_cached_kernels(tmp_path):
-    """Kernels loaded from the cache are the kernels: parity against the oracle in a process that compiled nothing."""
-    from cellularautomatons3d_amd import Engine, _capi
-
-    # this process uses whatever cache directory it started with; the claim is about the loaded objects, so run the rules twice
-    # in children sharing a directory and compare the second child's state with the oracle here
-    cache = str(tmp_path / "c")
-    _run(cache)
-    warm = _run(cache)
-    assert warm["jit"]["programs_compiled"] == 0
+    # kernels loaded from the cache are the kernels: the states of the process that compiled nothing equal the oracle's
     import hashlib
 
     for name, G in (("clustered", 128), ("default", 96)):
         r = ol.Rules.from_strings(**RULESETS[name])
         want = ol.packed_run(G, host.random_fill(host.words_per_buffer(G), seed=3), r, 9)
         assert hashlib.sha256(want.tobytes()).hexdigest() == warm[f"{name}@{G}"]["sha"], (name, G)
+    # CA3D_JIT_CACHE=0: nothing read, nothing written
+    off_dir = str(tmp_path / "unused")
+    off = _run(off_dir, {"CA3D_JIT_CACHE": "0"})
+    assert off["jit"]["cache_dir"] == "" and off["jit"]["programs_from_disk"] == 0 and off["jit"]["programs_compiled"] >= 4
+    assert not os.path.exists(off_dir)

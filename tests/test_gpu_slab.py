@@ -212,8 +212,8 @@ def test_slab_engine_over_rccl_loopback(overlap):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("overlap", [True, False])
-@pytest.mark.parametrize("name,G,K,steps", [("default", 256, 4, 14), ("clustered", 256, 3, 7), ("default", 1024, 16, 33)])
+@pytest.mark.parametrize("overlap,name,G,K,steps", [(True, "default", 256, 4, 14), (False, "default", 256, 4, 14), (True, "clustered", 256, 3, 7), (False, "clustered", 256, 3, 7),
+                                                     (True, "default", 1024, 16, 33)])
 def test_native_rccl_transport_loopback(overlap, name, G, K, steps):
     """The halo exchange inside the engine (ca3d_slab_comm_init / ca3d_slab_run: libca3d.so loads librccl and issues the
     grouped ncclSend / ncclRecv itself) on a one-rank communicator: the wrap message (rank 0's first planes -> its own high

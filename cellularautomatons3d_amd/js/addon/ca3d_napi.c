@@ -780,6 +780,14 @@ static napi_value js_group_info(napi_env env, napi_callback_info info)
 	set_num(env, o, "launchesTotal", (double)i.launches_total);
 	napi_create_string_utf8(env, i.kernel_name, NAPI_AUTO_LENGTH, &s);
 	napi_set_named_property(env, o, "kernelName", s);
+	/* what the slab really runs on (ca3d_slab_comm_info): the PCI bus id tells two GPUs from one GPU listed twice */
+	ca3d_comm_info ci;
+	if (ca3d_slab_comm_info(e, &ci) == CA3D_OK)
+	{
+		napi_create_string_utf8(env, ci.pci_bus_id, NAPI_AUTO_LENGTH, &s);
+		napi_set_named_property(env, o, "pciBusId", s);
+		set_num(env, o, "commRanks", ci.comm_ranks);
+	}
 	return o;
 }
 

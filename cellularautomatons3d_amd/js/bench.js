@@ -68,6 +68,9 @@ function runGroup()
 		n_gpus: new Set(devices).size, slabs: devices.length, devices, steps: stepsM, reps: repsM, warmup: warm, ms_per_step: +(dt * 1e3 / total).toFixed(6),
 		kernel: grp.info(0).kernelName, ghost, transport: transport ? "rccl (ncclCommInitAll, grouped send/recv)" : "peer copies ordered by events", node: process.version
 	};
+	// what the slabs really ran on, from the engines themselves (ca3d_slab_comm_info): N slabs are N GPUs only if N bus ids differ
+	const ranks = devices.map((_, k) => { const i = grp.info(k); return { rank: k, device: i.device, pci_bus_id: i.pciBusId, z0: i.z0, nz: i.nz }; });
+	out.devices_seen = { slabs: ranks.length, distinct_devices: new Set(ranks.map((r) => r.pci_bus_id)).size, ranks };
 	if (verified !== null) { out.verified = { steps: check, state_matches_single_grid: verified }; }
 	console.log(JSON.stringify(out));
 	grp.close();

@@ -80,6 +80,10 @@ def test_node_bench_drives_several_slabs_from_one_thread():
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["slabs"] == 4 and d["n_gpus"] == 1 and d["verified"]["state_matches_single_grid"] is True and d["value"] > 10
+    # what the slabs ran on, from the engines: four slabs, ONE bus id here (a real 4-GPU run must show four)
+    seen = d["devices_seen"]
+    assert seen["slabs"] == 4 and seen["distinct_devices"] == 1 and len(seen["ranks"][0]["pci_bus_id"].split(":")) == 3
+    assert [r["z0"] for r in seen["ranks"]] == [0, 128, 256, 384]
 
 
 def test_facade_runs_the_unmodified_reference_host_with_a_mock_engine():

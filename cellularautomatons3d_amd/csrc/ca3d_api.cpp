@@ -406,6 +406,13 @@ void select_kernels(ca3d_engine *h)
 		if (hipSetDevice(h->device) != hipSuccess) return;
 		RowsJit rj;
 		if (jit_rows_kernels(h->device, h->rules, h->G, &rj, &h->jit_log) == CA3D_OK) { h->rows_jit = rj; h->kernel_name = "ca_packed_rows(jit)"; }
+		if (h->G == 64u && !h->res_ready && h->use_resident && !h->slab && resident_kernel_applies(h->rules, h->G, h->variant))
+		{
+			// 64^3, a von Neumann table pair other than the start-up rule's: the one-workgroup resident kernel compiled for the tables
+			uint32_t ls64 = 0, lb64 = 0;
+			vn_tables(h->rules, &ls64, &lb64);
+			if (jit_resident_kernel(h->device, ls64, lb64, 64u, 1u, 0, &h->res_jit_fn, &h->jit_log) == CA3D_OK) h->res_ready = true;
+		}
 		return;
 	}
 	if (!vn_kernel_applies(h->rules, h->G, h->variant))

@@ -194,6 +194,7 @@ hipError_t launch_render_stream(const void *params, void *scratch, uint32_t W, u
 hipError_t launch_packed_step(const PackedLaunch &l, hipStream_t stream, const char **kernel_name);
 const char *packed_kernel_name(const CanonRules &r, uint32_t G, int variant);
 // ca_packed_vn.hip: the specialised von Neumann kernel (truth-table rules, power-of-two grids)
+bool vn_rule_applies(const CanonRules &r, int variant); // main list von Neumann, edges / corners rule-sets without effect
 bool vn_kernel_applies(const CanonRules &r, uint32_t G, int variant);
 hipError_t launch_packed_vn(const PackedLaunch &l, hipStream_t stream);
 // Canonical truth tables of the von Neumann kernel for these rules (entry 7 is a don't-care: see ca_packed_vn.hip)

@@ -70,8 +70,8 @@ int log2_exact(u32 x)
 
 } // namespace
 
-// The rule reduces to two truth tables over the von Neumann count and the grid is a power of two in [256, 8192].
-bool vn_kernel_applies(const CanonRules &r, uint32_t G, int variant)
+// The rule reduces to two truth tables over the von Neumann count ...
+bool vn_rule_applies(const CanonRules &r, int variant)
 {
 	if (variant == 1 || !r.fast || r.main != MAIN_VN) return false;
 	for (int s = 1; s < 3; s++)
@@ -79,6 +79,13 @@ bool vn_kernel_applies(const CanonRules &r, uint32_t G, int variant)
 		const uint32_t reachable = (2u << r.lists.n[s]) - 1u;
 		if ((r.onset_born[s] | r.onset_survive[s]) & reachable) return false;
 	}
+	return true;
+}
+
+// ... and the grid is a power of two in [256, 8192].
+bool vn_kernel_applies(const CanonRules &r, uint32_t G, int variant)
+{
+	if (!vn_rule_applies(r, variant)) return false;
 	const int cvl = log2_exact(G / 128u);
 	return G % 128u == 0 && cvl >= 1 && cvl <= 6;
 }

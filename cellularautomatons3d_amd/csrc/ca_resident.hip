@@ -78,7 +78,11 @@ void resident_stream_retired(hipStream_t stream)
 
 // The rule is a pair of truth tables over the von Neumann count (as ca_packed_vn) and the grid is the one the tile
 // geometry is built for.
-bool resident_kernel_applies(const CanonRules &r, uint32_t G, int variant) { return (G == 512u || G == 256u) && vn_kernel_applies(r, G, variant); }
+bool resident_kernel_applies(const CanonRules &r, uint32_t G, int variant)
+{
+	if (G == 64u) return vn_rule_applies(r, variant); // the one-workgroup form (ca_resident_kernel.inc, resident64_run): the per-step kernel there is the rows kernel
+	return (G == 512u || G == 256u) && vn_kernel_applies(r, G, variant);
+}
 
 bool resident_class_applies(const CanonRules &r, uint32_t G, int variant)
 {
@@ -138,6 +142,7 @@ uint32_t usable_cus(hipStream_t stream)
 bool resident_capacity(uint32_t G, uint32_t rows, uint32_t zsplit, int pair, void *jit_fn, hipStream_t stream, uint32_t *tiles, uint32_t *capacity)
 {
 
+	if (G == 64u) { *tiles = 1u; *capacity = usable_cus(stream) ? 1u : 0u; return *capacity != 0u; } // one workgroup: it waits for nobody
 	if (pair) { rows = 32u; zsplit = 1u; } // the row-pair form: the tiles and the 512 threads of the 32-row form
 	const uint32_t threads = (G == 256u ? 256u : 16u * rows) * zsplit;
 	const bool z2 = zsplit == 2u;
@@ -201,6 +206,20 @@ hipError_t launch_resident(const ResidentLaunch &l, hipStream_t stream)
 	a.fault_tile = l.fault_tile;
 	const bool z2 = l.zsplit == 2u;
 	if (l.zsplit != 1u && l.zsplit != 2u && !(l.zsplit == 4u && l.G == 256u && l.jit_fn)) return hipErrorInvalidValue;
+	if (l.G == 64u)
+	{
+		// the whole grid in one workgroup of 1024 threads
+		if (l.jit_fn)
+		{
+			void *args[] = {(void *)&a};
+			return chained_launch(stream, [&]() { return hipModuleLaunchKernel((hipFunction_t)l.jit_fn, 1, 1, 1, 1024, 1, 1, 0, stream, args, nullptr); });
+		}
+		if (l.lut_s != (u32)kDefaultS || l.lut_b != (u32)kDefaultB) return hipErrorInvalidValue;
+		return chained_launch(stream, [&]() {
+			hipLaunchKernelGGL((ca_resident_vn64<kDefaultS, kDefaultB, 4>), dim3(1), dim3(1024), 0, stream, a);
+			return hipGetLastError();
+		});
+	}
 	if (l.G == 256u)
 	{
 		// 8 x 32 tiles of 32 rows x 8 planes, 256 (x 2 with the z split) threads each (ca_resident_kernel.inc: CW = 8, PZ = 8)

@@ -361,8 +361,9 @@ int ca3d_get_render_stats(ca3d_t *h, ca3d_render_stats *out);
  * (bit-exact, off by default); "variant" 1 forces the generic / literal kernels; "jit" 0/1 run-time (hiprtc) specialisation of the step
  * kernel for the current rule, compiled inside ca3d_set_rules / ca3d_configure (on by default; a failed compile
  * keeps the pre-built kernels and is reported through ca3d_get_jit_log); "resident" 0/1: batches of "resident_min" (default 8) steps and more run as ONE launch of
- * the resident multi-step kernel where one exists (512^3, von Neumann rule tables: the state stays in registers and only
- * tile faces cross the chip; a resident kernel is only selected when the runtime says all its workgroups fit on the CUs the
+ * the resident multi-step kernel where one exists (512^3 and 256^3 — von Neumann rule tables, and rule-sets with diagonal classes
+ * compiled at run time: the state stays in registers and only tile faces cross the chip; 64^3, von Neumann rule tables: the
+ * whole grid in one workgroup; a resident kernel is only selected when the runtime says all its workgroups fit on the CUs the
  * engine's stream may use; every in-kernel wait is bounded by "resident_timeout_us", default 200 000 — after a timeout the
  * engine re-runs the affected steps through the per-step kernels at the next call that looks at the state and turns the
  * path off: ca3d_recovered_launches; "resident_fault_tile" t: diagnostics, tile t - 1 of the next resident launch leaves at

@@ -873,6 +873,73 @@ def test_resident_kernel_at_256(eng, tables, zsplit):
         eng.set_option("resident_zsplit", 1)
 
 
+@pytest.mark.parametrize("tables", ["default", "vn_b24_s135", "B2,4,5/S0,3,6"])
+def test_resident_kernel_at_64(eng, tables):
+    """The reference UI's start-up grid, 64^3 (main_pathtraced.js:101), through the one-workgroup resident kernel (resident64_run: the
+    whole state in the registers of one CU, lane = row, a wave = four planes, y neighbours by wave-wide DPP, plane exchange between
+    waves through LDS): batches of several lengths incl. one and two steps, the other ping-pong buffer, the single seed, live cells
+    hugging every face (dead -x / -y / -z, wrapping +x / +y / +z — here the wraps are lane 63 -> lane 0 and wave 15 -> wave 0), and
+    1000 steps in one launch against the oracle and against the per-step kernels."""
+    G = 64
+    if tables in RULESETS:
+        r = rules(tables)
+    else:
+        b, s_ = tables[1:].split("/S")
+        r = ol.Rules.from_strings(neighbourhood="von neumann", born=b, survive=s_)
+    eng.configure(G)
+    set_rules(eng, r)
+    assert eng.info().kernel_name.startswith(b"ca_resident_vn"), eng.info().kernel_name
+    st = host.random_fill(host.words_per_buffer(G), seed=64)
+    eng.upload_state(st)
+    want = st
+    total = 0
+    from cellularautomatons3d_amd import slab
+    try:
+        for n in (8, 9, 21, 1, 2):
+            if n < 8:
+                eng.set_option("resident_min", 1)
+            eng.step(n)
+            prev = ol.packed_run(G, want, r, n - 1)
+            want = ol.packed_step(G, prev, r)
+            total += n
+            np.testing.assert_array_equal(eng.read_state(), want, err_msg=f"after a batch of {n}")
+            assert eng.info().current_buffer == total % 2 and eng.info().step == total
+            other = slab.device_tensor(*eng.device_buffer(1 - total % 2), 0).cpu().numpy().view(np.uint32)
+            np.testing.assert_array_equal(other, prev, err_msg="the other buffer holds the state one step earlier")
+    finally:
+        eng.set_option("resident_min", 8)
+    st2 = host.initial_state(G)
+    eng.upload_state(st2)
+    eng.step(100)
+    np.testing.assert_array_equal(eng.read_state(), ol.packed_run(G, st2, r, 100))
+    edge = np.zeros(host.words_per_buffer(G), dtype=np.uint32)
+    e3 = edge.reshape(G, G, G // 32)
+    e3[:3, :3, :] = host.random_fill(9 * (G // 32), seed=7).reshape(3, 3, G // 32)
+    e3[-3:, -3:, :] = host.random_fill(9 * (G // 32), seed=8).reshape(3, 3, G // 32)
+    e3[:3, -3:, :] = host.random_fill(9 * (G // 32), seed=9).reshape(3, 3, G // 32)
+    e3[-3:, :3, :] = host.random_fill(9 * (G // 32), seed=10).reshape(3, 3, G // 32)
+    e3[20:40, 20:40, 0] |= 1           # cells at x == 0
+    e3[20:40, 20:40, 1] |= 0x80000000  # and at x == 63
+    eng.upload_state(edge)
+    for n in (9, 12):
+        eng.step(n)
+    np.testing.assert_array_equal(eng.read_state(), ol.packed_run(G, edge, r, 21), err_msg="faces, 21 steps")
+    eng.upload_state(st)
+    eng.step(1000)
+    assert eng.info().kernel_name.startswith(b"ca_resident_vn")
+    got = eng.read_state()
+    np.testing.assert_array_equal(got, ol.packed_run(G, st, r, 1000))
+    eng.set_option("resident", 0)
+    try:
+        assert eng.info().kernel_name.startswith(b"ca_packed_rows"), eng.info().kernel_name
+        eng.upload_state(st)
+        eng.step(1000)
+        np.testing.assert_array_equal(eng.read_state(), got)
+    finally:
+        eng.set_option("resident", 1)
+    assert eng.recovered_launches() == 0
+
+
 def test_queued_submission(eng):
     """Option "queue": ca3d_step only encodes, the steps of consecutive calls are submitted together (ca3d_flush, any call
     that looks at the state, or once `queue` steps wait) — the reference's commandEncoder + queue.submit

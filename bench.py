@@ -25,7 +25,7 @@ algorithmic bytes per launch / launch duration (HIP events on the engine's strea
 wave-instructions per second (count per wave and step from the committed rocprofv3 SQ pass of this command, profiles/) against
 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction — with the algorithmic-byte rate beside it as `hbm_equivalent`.
 The N = 1 line also carries: `per_step_kernels` (the same grid with every step through memory: the HBM-path fraction),
-`per_call` (every K-step call its own submission), `grid_256` (BASELINE configs[1]'s grid), `render` / `render_4k`,
+`per_call` (every K-step call its own submission), `grid_256` (BASELINE configs[1]'s grid), `grid_64` (the UI's start-up grid), `render` / `render_4k`,
 `scaling_base` (1024^3 on one GPU).
 """
 import argparse
@@ -922,6 +922,25 @@ def main():
             if k1.startswith("ca_resident") and not a.no_per_step_leg:
                 out["grid_256"]["per_step_kernels"] = per_step_leg(e1, 256, 2 << 20)
             eng = e1
+            # the reference UI's start-up grid (main_pathtraced.js:101): 64^3 — one workgroup holds the whole state (resident64_run)
+            eng.close()
+            e0, _, dt0, reps0, ev0, cal0, l0 = single_gpu_leg(local_rank, 64, "default", a.steps, a.warmup, min(a.min_seconds, 0.2), 0, a.resident, a.queue if a.submit == "queued" else 0,
+                                                              a.verify_steps)
+            k0 = e0.info().kernel_name.decode()
+            out["grid_64"] = {"grid": 64, "rule": "default", "value": round(64.0 ** 3 * a.steps * reps0 / dt0 / 1e9, 3), "unit": "Gcells/s",
+                              "ms_per_step": round(dt0 * 1e3 / (a.steps * reps0), 6), "steps": a.steps, "reps": reps0, "kernel": k0,
+                              "what": "the reference UI's start-up grid; batches through the one-workgroup resident kernel (the whole state in one CU's registers)"}
+            if e0.verified is not None:
+                out["grid_64"]["verified"] = e0.verified
+                if not e0.verified["oracle_match"]:
+                    ok = False
+            if k0.startswith("ca_resident") and not a.no_per_step_leg:
+                e0.set_option("queue", 0)
+                e0.set_option("resident", 0)
+                dtp, repsp, _, _, _ = timed_region(e0.step, e0.bench_stream, 256, 64, min(a.min_seconds, 0.2), barrier, 1, "nccl")
+                out["grid_64"]["per_step_kernels"] = {"ms_per_step": round(dtp * 1e3 / (256 * repsp), 6), "kernel": e0.info().kernel_name.decode()}
+                e0.set_option("resident", a.resident)
+            eng = e0
         if world == 1 and a.config == 3 and G == 512 and not a.no_scaling_base:
             # the single-GPU point of the multi-GPU curve, on the multi-GPU grid, in the same run (N > 1 runs 1024^3)
             eng.close()

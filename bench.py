@@ -831,6 +831,9 @@ def main():
                                    f"hashed fill seed 0xCA3D0001 density {2.0 ** -(1 + a.density_rounds):g}, one CA step per bench step, "
                                    f"{reps} batches of {a.steps} steps timed",
                        "baseline_config": a.config, "grid": G, "layout": "packed32", "rule": a.rule,
+                       "state_note": ("under this rule (S0-6: a live cell never dies) a density-0.5 fill reaches a fixed point within a few steps; the kernels are "
+                                      "bit-sliced with no data-dependent path, so the rate does not depend on what the cells do (`--rule vn_b24_s135` keeps "
+                                      "changing: same kernel, same time; tests/test_gpu_ca_parity.py runs both for 1000 steps against the oracle)") if a.rule == "default" else None,
                        "parallelism": "1 GPU" if world == 1 else f"z-slab x{world}, ghost {a.ghost} planes, RCCL send/recv every {a.ghost} steps"
                                       + (" overlapped with the interior phase" if se.overlap else "")
                                       + (", exchange issued by the engine (ca3d_slab_run)" if getattr(se, "native", False) else ", exchange through torch.distributed")},

@@ -87,6 +87,36 @@ def test_grids_that_are_not_a_power_of_two(eng, G, W, H, spp):
     assert eng.info().grid_size == G
 
 
+@pytest.mark.parametrize("G,steps", [(96, 12), (160, 30), (288, 40)])
+def test_sparse_scenes_on_grids_that_are_not_a_power_of_two(eng, G, steps):
+    """The UI's start-up seed a few steps on, on grids that are not a power of two: the sparse-volume kernels (occupancy bits over 32 x 8 x 8
+    blocks, the box of the live blocks, block jumps, the spread kernel; no second occupancy level off multiples of 128) against the
+    oracle, converged frame at one and four samples and the literal frame's two forms against each other."""
+    cells = ol.packed_run(G, host.initial_state(G), rules("default"), steps)
+    W, H = 320, 180
+    for pose in (host.camera_matrix(), host.orbit_camera(1.2, (1.0, 0.3, 0.0), 0.8)):
+        for spp in (1, 4):
+            _compare(eng, cells, G, host.uniform_block(W, H, pose), W, H, spp)
+    eng.set_render_mode(True)
+    try:
+        got = {}
+        vm = host.orbit_camera(1.2, (1.0, 0.3, 0.0), 0.8)
+        for bricks in (0, 1):
+            eng.set_option("render_frame_bricks", bricks)
+            eng.reset_render_history()
+            got[bricks] = [eng.render(host.uniform_block(W, H, vm, elapsed_time=0.1 + 0.07 * f, prev_view_mat=vm if f else None), W, H, 1) for f in range(3)]
+        for a, b in zip(got[0], got[1]):
+            for x, y in zip(a, b):
+                np.testing.assert_array_equal(x.view(np.uint8), y.view(np.uint8))
+        u = host.uniform_block(W, H, vm, elapsed_time=0.1, prev_view_mat=None)
+        ol_light, ol_depth, _ = ol.render_frame(cells, G, u, W, H, None, None)
+        ok = np.abs(got[1][0][1].astype(np.float32)[..., :3] - ol_light.astype(np.float16).astype(np.float32)[..., :3]).max(-1) <= 2e-3
+        assert ok.mean() >= 0.999, ok.mean()
+    finally:
+        eng.set_option("render_frame_bricks", 1)
+        eng.set_render_mode(False)
+
+
 def test_evolved_seed_volume(eng):
     # state after 30 steps of the default rule from the single seed (SURVEY 8(d) render input)
     G, W, H = 128, 480, 270

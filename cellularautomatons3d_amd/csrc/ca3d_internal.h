@@ -82,6 +82,7 @@ struct RollJit
 {
 	void *z[3] = {nullptr, nullptr, nullptr}; // hipFunction_t for Z = 2, 4, 8
 	void *tile[4] = {nullptr, nullptr, nullptr, nullptr}; // the tile form (x-shifted rows shared through LDS) for Z = 2, 4, 8, 16
+	void *tile_x = nullptr; int zx = 0; // tuning (CA3D_ROLL_ZX=<planes>): one more depth of the tile form
 	void *loop[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; // looped forms [tile][Z = 15, 30]: the plane loop rolled up in groups of three
 	void *w2[2] = {nullptr, nullptr};    // two words per thread (five waves per SIMD) for Z = 8, 16; null on rows of 32 uint4 and more
 	void *wtile[2] = {nullptr, nullptr}; // wave tiles (one wave per workgroup, LDS exchange without a barrier) for Z = 8, 16; null on rows of 64 uint4

@@ -408,6 +408,18 @@ hipError_t launch_class(const PackedLaunch &l, hipStream_t stream)
 			void *args[] = {(void *)&in, (void *)&out, (void *)&a};
 			return hipModuleLaunchKernel((hipFunction_t)fn, g.tiles_per_plane * nruns, 1, 1, 256, 1, 1, 0, stream, args, nullptr);
 		}
+		if (rj->tile_x && l.roll_tile == 1 && l.roll_z == 0 && shortest >= (u32)rj->zx)
+		{
+			const u32 Z = (u32)rj->zx;
+			const u32 runs1 = (planes1 + Z - 1u) / Z, nruns = runs1 + (planes2 + Z - 1u) / Z;
+			RollArgs a;
+			a.lo = l.pr.lo; a.hi = l.pr.hi; a.nplanes = l.pr.nplanes; a.wrap_full = l.pr.wrap_full; a.zbase = l.pr.zbase;
+			a.lo2 = l.pr.lo2; a.hi2 = two ? l.pr.hi2 : l.pr.lo2; a.runs1 = runs1;
+			const u32 *in = l.in;
+			u32 *out = l.out;
+			void *args[] = {(void *)&in, (void *)&out, (void *)&a};
+			return hipModuleLaunchKernel((hipFunction_t)rj->tile_x, g.tiles_per_plane * nruns, 1, 1, 256, 1, 1, 0, stream, args, nullptr);
+		}
 		for (int zi = l.roll_tile == 1 ? 3 : 2; zi >= 0; zi--)
 		{
 			const u32 Z = 2u << zi;

@@ -60,6 +60,7 @@ struct StreamParams
 	const u32 *volume;   // what the walks read: R.cells, or the bricked copy of it
 	u32 lg, lc;          // log2 G, log2 cols (power-of-two grids)
 	u32 nb;              // bricks per edge, G / 8
+	u32 lnbp;            // packed cell positions (kBricksPacked): bits of a brick coordinate, log2 nb
 	u32 probe_mask;      // timing probes (kProbe*): 0
 	int tail_batch;      // ca_stream_walk2: 1 = the batched stepping loop once a wave cannot refill any more and in the drain launch
 	int refill2;         // ca_stream_walk2: idle lanes at which a wave leaves the stepping loop to pop prepared rays (tuning: CA3D_STREAM_POP)
@@ -156,6 +157,7 @@ struct Walker
 	int wkey;
 	u32 word;
 	float eps_b; // constant term of the filter's error bound (below); +inf: always ask the slab test
+	u32 pos, neg, edge; // kBricksPacked: the cell as ONE word (PackGeom below) instead of ix .. sz
 };
 
 // Where the walk reads the volume: the packed state itself (row-major words of 32 x-cells; power-of-two grids index it by shifts) or a
@@ -172,7 +174,7 @@ struct Walker
 // kProbe*: timing probes of the stepping loop (CA3D_STREAM_PROBE=1..4; the frame is garbage: no cell is ever taken for live, every walk runs to
 // the end of the volume, so the four differ ONLY in what the read costs): no read at all / every lane reads word 0 (one cache line per
 // wave-level read) / word key & 1023 (a 4 KiB footprint, as many lines per read as the real walk) / the real word.
-enum { kRowsP2 = 0, kRowsAny = 1, kBricks = 2, kBricksRead = 3, kBricksReadAny = 4, kProbeNone = 5, kProbeSame = 6, kProbeSmall = 7, kProbeFull = 8 };
+enum { kRowsP2 = 0, kRowsAny = 1, kBricks = 2, kBricksRead = 3, kBricksReadAny = 4, kProbeNone = 5, kProbeSame = 6, kProbeSmall = 7, kProbeFull = 8, kBricksPacked = 9 };
 
 template <int LAYOUT>
 __device__ __forceinline__ int word_key(const StreamParams &S, int ix, int iy, int iz)
@@ -237,13 +239,18 @@ __device__ __forceinline__ void walker_begin(const RenderParams &P, Walker &w, v
 
 // the reference's slab test of the cube in the walker's cell (ray_cube_inv: bit-identical to ray_cube)
 template <bool SHADOW>
-__device__ __forceinline__ bool slab_test(const RenderParams &P, const Walker &w, v3 vhalf, const float *ctx, int stride, float &tn)
+__device__ __forceinline__ bool slab_test_at(const RenderParams &P, int ix, int iy, int iz, v3 vhalf, const float *ctx, int stride, float &tn)
 {
 	const v3 start = V(ctx[0 * stride], ctx[1 * stride], ctx[2 * stride]);
 	const v3 inv = V(ctx[3 * stride], ctx[4 * stride], ctx[5 * stride]);
 	float tf;
-	ray_cube_inv(start, inv, cell_origin(1.0f / (float)P.G, w.ix, w.iy, w.iz), vhalf, tn, tf);
+	ray_cube_inv(start, inv, cell_origin(1.0f / (float)P.G, ix, iy, iz), vhalf, tn, tf);
 	return SHADOW ? (tn <= tf && tn >= 0.0f) /* :668 */ : (tf >= 0.0f && tn <= tf) /* :722-729 */;
+}
+template <bool SHADOW>
+__device__ __forceinline__ bool slab_test(const RenderParams &P, const Walker &w, v3 vhalf, const float *ctx, int stride, float &tn)
+{
+	return slab_test_at<SHADOW>(P, w.ix, w.iy, w.iz, vhalf, ctx, stride, tn);
 }
 
 // One cell of the walk. Returns 0 keep walking, 1 hit, 2 the ray left the volume or ran out of range.
@@ -411,6 +418,155 @@ __device__ __forceinline__ u32 walk_batch(const StreamParams &S, Walker &w, bool
 					if (walk_hit_test<SHADOW, CHECK>(S, w, vhalf, k0, k1, eps_a, ctx, stride)) { hit = true; visited = (u32)k + 1u; }
 				}
 				if (!hit) walk_advance(P, w);
+			}
+		}
+	}
+	term = hit ? 1 : (over ? 2 : 0);
+	return visited;
+}
+
+// ---- packed cell positions (kBricksPacked; round 5, late) ------------------------------------------------------------------------
+// The ledger of the stepping loop (profiles/r5_render_walk_ledger.txt) prices an empty cell at 44 VALU: 10 for the bricked word's key,
+// 6 for the bit, 23 for the advance (three cell coordinates and three signs next to the three boundary times). Here a walker carries
+// its cell as ONE word laid out like the bricked volume's address, pos = (word key << 5) | bit in the word:
+//     bits 0-2 x & 7 | 3-5 y & 7 | 6-8 z & 7 | then x >> 3, y >> 3, z >> 3 in lnb bits each        (9 + 3 lnb <= 30 bits: G <= 1024)
+// so the key is pos >> 5 and the bit pos & 31 — no arithmetic — and a step of +-1 along one axis is an add on that axis's scattered
+// bits ("dilated integer" add): with m the axis's mask, (pos | ~m) fills the gaps with ones so that a carry runs through them,
+// + (m & neg) adds the dilated +1 (the mask's lowest bit) or -1 (the whole mask), and v_bfi puts the axis back among the others.
+// `neg` = the masks of the axes the ray descends along | 0x49 (the three lowest bits of the masks), `edge` = the last coordinate inside
+// the grid along each axis in the ray's direction (G - 1 ascending, 0 descending), dilated: the walk leaves the grid exactly when the
+// moving axis stands on its edge before the step. Boundary times, the order of the float operations and the interval filter are
+// walk_cell's: the cells visited and the answers are the same, bit for bit (the coordinates are unpacked for the slab test).
+struct PackGeom
+{
+	u32 mx, my, mz; // the axes' masks
+	u32 ex, ey, ez; // dilated G - 1 per axis
+	u32 lnb;
+};
+__device__ __forceinline__ PackGeom pack_geom(const StreamParams &S)
+{
+	PackGeom g;
+	g.lnb = S.lnbp;
+	const u32 nbm = (1u << g.lnb) - 1u, top = S.nb - 1u;
+	g.mx = 7u | (nbm << 9);
+	g.my = (7u << 3) | (nbm << (9u + g.lnb));
+	g.mz = (7u << 6) | (nbm << (9u + 2u * g.lnb));
+	g.ex = 7u | (top << 9);
+	g.ey = (7u << 3) | (top << (9u + g.lnb));
+	g.ez = (7u << 6) | (top << (9u + 2u * g.lnb));
+	// (opaque scalars: left as fields of a struct the compiler turns `mx ? g.mx : my ? g.my : g.mz` into an indexed read of the struct —
+	// a scratch load per cell)
+	// (in vector registers: v_cndmask takes one scalar operand, the select of the moving axis's mask would pay a v_mov per scalar)
+	asm volatile("" : "+v"(g.mx), "+v"(g.my), "+v"(g.mz));
+	return g;
+}
+__device__ __forceinline__ u32 pack_cell(const PackGeom &g, int ix, int iy, int iz)
+{
+	return ((u32)ix & 7u) | (((u32)iy & 7u) << 3) | (((u32)iz & 7u) << 6) | (((u32)ix >> 3) << 9) | (((u32)iy >> 3) << (9u + g.lnb)) | (((u32)iz >> 3) << (9u + 2u * g.lnb));
+}
+__device__ __forceinline__ void unpack_cell(const PackGeom &g, u32 p, int &ix, int &iy, int &iz)
+{
+	const u32 nbm = (1u << g.lnb) - 1u;
+	ix = (int)((p & 7u) | (((p >> 9) & nbm) << 3));
+	iy = (int)(((p >> 3) & 7u) | (((p >> (9u + g.lnb)) & nbm) << 3));
+	iz = (int)(((p >> 6) & 7u) | (((p >> (9u + 2u * g.lnb)) & nbm) << 3));
+}
+// walk_advance on a packed position
+__device__ __forceinline__ bool walk_advance_p(const PackGeom &g, Walker &w)
+{
+	const float t = fminf(fminf(w.tx, w.ty), w.tz);
+	const bool mx = w.tx == t, my = !mx && w.ty == t, mz = !mx && !my;
+	w.t = t;
+	w.tx += mx ? w.dx : 0.0f;
+	w.ty += my ? w.dy : 0.0f;
+	w.tz += mz ? w.dz : 0.0f;
+	const u32 gmx = g.mx, gmy = g.my, gmz = g.mz;
+	const u32 m = mx ? gmx : (my ? gmy : gmz);
+	const bool leaving = ((w.pos ^ w.edge) & m) == 0u; // the moving axis stands on the last cell inside the grid
+	const u32 q = (w.pos | ~m) + (m & w.neg);
+	w.pos = (q & m) | (w.pos & ~m);
+	return leaving || t >= w.tmax;
+}
+// walk_hit_test on a packed position
+template <bool SHADOW, bool CHECK>
+__device__ __forceinline__ bool walk_hit_test_p(const StreamParams &S, const PackGeom &g, const Walker &w, v3 vhalf, float k0, float k1, float eps_a, const float *ctx, int stride)
+{
+	const RenderParams &P = S.R;
+	const float tn = fmaxf(fmaxf(__builtin_fmaf(-k1, w.dx, w.tx), __builtin_fmaf(-k1, w.dy, w.ty)), __builtin_fmaf(-k1, w.dz, w.tz));
+	const float tf = fminf(fminf(__builtin_fmaf(-k0, w.dx, w.tx), __builtin_fmaf(-k0, w.dy, w.ty)), __builtin_fmaf(-k0, w.dz, w.tz));
+	const float gap = tf - tn, lead = SHADOW ? tn : tf;
+	const float eps = __builtin_fmaf(__builtin_fmaf(eps_a, w.t, 3.814697265625e-6f), w.t, w.eps_b);
+	const bool yes = gap > eps && lead > eps, no = gap < -eps || lead < -eps;
+	float e;
+	if (CHECK)
+	{
+		int ix, iy, iz;
+		unpack_cell(g, w.pos, ix, iy, iz);
+		const bool truth = slab_test_at<SHADOW>(P, ix, iy, iz, vhalf, ctx, stride, e);
+		if ((yes && !truth) || (no && truth)) atomicAdd(&S.ctl[2], 1u);
+		return truth;
+	}
+	if (yes) return true;
+	if (no) return false;
+	int ix, iy, iz;
+	unpack_cell(g, w.pos, ix, iy, iz);
+	return slab_test_at<SHADOW>(P, ix, iy, iz, vhalf, ctx, stride, e);
+}
+// walk_cell on a packed position (the word is read at every cell, as kBricksRead)
+template <bool SHADOW, bool CHECK>
+__device__ __forceinline__ int walk_cell_p(const StreamParams &S, const PackGeom &g, Walker &w, bool &exempt, v3 vhalf, float k0, float k1, float eps_a, const float *ctx, int stride)
+{
+	const u32 cur = *reinterpret_cast<const u32 *>(reinterpret_cast<const char *>(S.volume) + ((w.pos >> 3) & ~3u));
+	if (__builtin_amdgcn_ubfe(cur, w.pos, 1u) != 0u && !exempt) // (the shift takes bits 0-4 of pos: the bit in the word)
+	{
+		if (walk_hit_test_p<SHADOW, CHECK>(S, g, w, vhalf, k0, k1, eps_a, ctx, stride)) return 1;
+	}
+	exempt = false;
+	return walk_advance_p(g, w) ? 2 : 0;
+}
+// walk_batch on a packed position
+template <bool SHADOW, bool CHECK>
+__device__ __forceinline__ u32 walk_batch_p(const StreamParams &S, const PackGeom &g, Walker &w, bool &exempt, int &term, v3 vhalf, float k0, float k1, float eps_a,
+                                            const float *ctx, int stride)
+{
+	const float stx = w.tx, sty = w.ty, stz = w.tz, st = w.t;
+	const u32 spos = w.pos;
+	u32 word[kBatch], nvalid = 0;
+	unsigned long long pos = 0; // 6 bits per cell — bit position, 32 for a cell past the walk's end
+	bool over = false;
+#pragma unroll
+	for (int k = 0; k < kBatch; k++)
+	{
+		const u32 off = over ? 0u : ((w.pos >> 3) & ~3u);
+		word[k] = *reinterpret_cast<const u32 *>(reinterpret_cast<const char *>(S.volume) + off);
+		pos |= (unsigned long long)(over ? 32u : (w.pos & 31u)) << (6 * k);
+		nvalid += over ? 0u : 1u;
+		over = walk_advance_p(g, w) || over;
+	}
+	u32 live = 0;
+#pragma unroll
+	for (int k = 0; k < kBatch; k++)
+	{
+		const u32 b = (u32)(pos >> (6 * k)) & 63u;
+		live |= (b < 32u ? (word[k] >> b) & 1u : 0u) << k;
+	}
+	if (exempt) live &= ~1u;
+	exempt = false;
+	u32 visited = nvalid;
+	bool hit = false;
+	if (live)
+	{
+		w.tx = stx; w.ty = sty; w.tz = stz; w.t = st; w.pos = spos;
+#pragma unroll
+		for (int k = 0; k < kBatch; k++)
+		{
+			if (!hit)
+			{
+				if ((live >> k) & 1u)
+				{
+					if (walk_hit_test_p<SHADOW, CHECK>(S, g, w, vhalf, k0, k1, eps_a, ctx, stride)) { hit = true; visited = (u32)k + 1u; }
+				}
+				if (!hit) walk_advance_p(g, w);
 			}
 		}
 	}
@@ -764,6 +920,8 @@ __global__ __launch_bounds__(kW2Threads, kW2PerSimd) void ca_stream_walk2(Stream
 	const float k0 = 0.5f - 0.5f * fabsf(P.u[U_CELLSIZE]), k1 = 1.0f - k0;
 	const float eps_a = 4.76837158203125e-7f * (float)P.G;
 	const float eps_c = 9.5367431640625e-7f * ((float)P.G + 8.0f);
+	constexpr bool PACKED = LAYOUT == kBricksPacked;
+	const PackGeom pg = pack_geom(S);
 	const u32 qown = blockIdx.x & 7u;
 	u32 qcur = qown, qtried = 0;
 	const u32 lper = 2u * S.lb + job_shift(P);   // log2 jobs of a chunk
@@ -812,6 +970,7 @@ __global__ __launch_bounds__(kW2Threads, kW2PerSimd) void ca_stream_walk2(Stream
 	Walker w;
 	w.tx = w.ty = w.tz = w.dx = w.dy = w.dz = w.t = w.tmax = w.eps_b = 0.0f;
 	w.ix = w.iy = w.iz = 0; w.sx = w.sy = w.sz = 1; w.wkey = -1; w.word = 0;
+	w.pos = 0u; w.neg = 0x49u; w.edge = 0u;
 	u32 visits = 0;              // wave-uniform
 	u32 idcount = 0;             // wave-uniform: ids waiting in ids[]
 	u32 qhead = 0, qavail = 0;   // wave-uniform: prepared rays rec[.][qhead .. qhead + qavail)
@@ -831,7 +990,9 @@ __global__ __launch_bounds__(kW2Threads, kW2PerSimd) void ca_stream_walk2(Stream
 				if (term == 1)
 				{
 					float tn;
-					slab_test<false>(P, w, vhalf, ctx, stride, tn);
+					int hx = w.ix, hy = w.iy, hz = w.iz;
+					if (PACKED) unpack_cell(pg, w.pos, hx, hy, hz);
+					slab_test_at<false>(P, hx, hy, hz, vhalf, ctx, stride, tn);
 					out = __float_as_uint(tn);
 				}
 				S.hit[job] = out;
@@ -958,7 +1119,7 @@ __global__ __launch_bounds__(kW2Threads, kW2PerSimd) void ca_stream_walk2(Stream
 						r[0 * kW2Threads] = __float_as_uint(nw.tx); r[1 * kW2Threads] = __float_as_uint(nw.ty); r[2 * kW2Threads] = __float_as_uint(nw.tz);
 						r[3 * kW2Threads] = __float_as_uint(nw.dx); r[4 * kW2Threads] = __float_as_uint(nw.dy); r[5 * kW2Threads] = __float_as_uint(nw.dz);
 						r[6 * kW2Threads] = __float_as_uint(nw.tmax);
-						r[7 * kW2Threads] = (u32)nw.ix | ((u32)nw.iy << 16);
+						r[7 * kW2Threads] = PACKED ? pack_cell(pg, nw.ix, nw.iy, nw.iz) : ((u32)nw.ix | ((u32)nw.iy << 16));
 						r[8 * kW2Threads] = (u32)nw.iz | (nw.sx > 0 ? 1u << 16 : 0u) | (nw.sy > 0 ? 1u << 17 : 0u) | (nw.sz > 0 ? 1u << 18 : 0u) | (ap ? 1u << 19 : 0u) | (ex ? 1u << 20 : 0u);
 						r[9 * kW2Threads] = nj;
 #pragma unroll
@@ -981,8 +1142,18 @@ __global__ __launch_bounds__(kW2Threads, kW2PerSimd) void ca_stream_walk2(Stream
 					w.dx = __uint_as_float(r[3 * kW2Threads]); w.dy = __uint_as_float(r[4 * kW2Threads]); w.dz = __uint_as_float(r[5 * kW2Threads]);
 					w.tmax = __uint_as_float(r[6 * kW2Threads]);
 					const u32 c0 = r[7 * kW2Threads], c1 = r[8 * kW2Threads];
-					w.ix = (int)(c0 & 0xFFFFu); w.iy = (int)(c0 >> 16); w.iz = (int)(c1 & 0xFFFFu);
-					w.sx = (c1 >> 16) & 1u ? 1 : -1; w.sy = (c1 >> 17) & 1u ? 1 : -1; w.sz = (c1 >> 18) & 1u ? 1 : -1;
+					if (PACKED)
+					{
+						const bool ux = (c1 >> 16) & 1u, uy = (c1 >> 17) & 1u, uz = (c1 >> 18) & 1u; // the ray ascends along x / y / z
+						w.pos = c0;
+						w.neg = (ux ? 0u : pg.mx) | (uy ? 0u : pg.my) | (uz ? 0u : pg.mz) | 0x49u;
+						w.edge = (ux ? pg.ex : 0u) | (uy ? pg.ey : 0u) | (uz ? pg.ez : 0u);
+					}
+					else
+					{
+						w.ix = (int)(c0 & 0xFFFFu); w.iy = (int)(c0 >> 16); w.iz = (int)(c1 & 0xFFFFu);
+						w.sx = (c1 >> 16) & 1u ? 1 : -1; w.sy = (c1 >> 17) & 1u ? 1 : -1; w.sz = (c1 >> 18) & 1u ? 1 : -1;
+					}
 					w.eps_b = (c1 >> 19) & 1u ? __builtin_inff() : eps_c * (w.dx + w.dy + w.dz);
 					exempt = (c1 >> 20) & 1u;
 					w.t = SHADOW ? 0.0025f : 0.0f;
@@ -1014,11 +1185,28 @@ __global__ __launch_bounds__(kW2Threads, kW2PerSimd) void ca_stream_walk2(Stream
 			do
 			{
 				u32 n = 0;
-				if (job >= 0 && term == 0) n = walk_batch<SHADOW, LAYOUT, CHECK>(S, w, exempt, term, vhalf, k0, k1, eps_a, ctx, stride);
+				if (job >= 0 && term == 0)
+				{
+					if (PACKED) n = walk_batch_p<SHADOW, CHECK>(S, pg, w, exempt, term, vhalf, k0, k1, eps_a, ctx, stride);
+					else n = walk_batch<SHADOW, LAYOUT, CHECK>(S, w, exempt, term, vhalf, k0, k1, eps_a, ctx, stride);
+				}
 #pragma unroll
 				for (int k = 0; k < kBatch; k++) visits += (u32)__builtin_amdgcn_readfirstlane(__popcll(__ballot(n > (u32)k)));
 				walking = __builtin_amdgcn_readfirstlane(__popcll(__ballot(job >= 0 && term == 0)));
 			} while (walking > leave_at);
+		}
+		else if (PACKED)
+		{
+			// (one state word per lane — 0 walking, 1 hit, 2 over, 3 no ray — so that "who still walks" is ONE compare whose mask is both the
+			// loop body's exec mask and the count the loop ends on)
+			int st = (job >= 0 && term == 0) ? 0 : 3;
+			do
+			{
+				visits += (u32)walking;
+				if (st == 0) st = walk_cell_p<SHADOW, CHECK>(S, pg, w, exempt, vhalf, k0, k1, eps_a, ctx, stride);
+				walking = __builtin_popcountll(__builtin_amdgcn_ballot_w64(st == 0));
+			} while (walking > leave_at);
+			if (st != 3) term = st;
 		}
 		else
 		{
@@ -1185,6 +1373,8 @@ hipError_t launch_render_stream(const void *params, void *scratch, uint32_t W, u
 	const bool p2 = (P.G & (P.G - 1u)) == 0u;
 	S.lg = S.lc = 0;
 	S.nb = P.G >> 3;
+	S.lnbp = 0;
+	while ((1u << S.lnbp) < S.nb) S.lnbp++;
 	if (p2)
 	{
 		while ((1u << S.lg) < P.G) S.lg++;
@@ -1233,6 +1423,7 @@ hipError_t launch_render_stream(const void *params, void *scratch, uint32_t W, u
 		const bool form2 = form_env == 2 && per >= 128u && bricks_env == 1; // (a chunk holds at least 64 tickets of two jobs)
 		if (form2) trace_waves = (unsigned long long)wgs2 * (unsigned)kW2Waves;
 		static const int probe_env = getenv("CA3D_STREAM_PROBE") ? atoi(getenv("CA3D_STREAM_PROBE")) : 0;
+		static const int packed_env = getenv("CA3D_STREAM_PACKED") ? atoi(getenv("CA3D_STREAM_PACKED")) : 1; // tuning: 0 = cell coordinates as three integers (kBricksRead)
 		S.probe_mask = 0u;
 		if (probe_env >= 1 && probe_env <= 4 && p2)
 		{
@@ -1241,6 +1432,7 @@ hipError_t launch_render_stream(const void *params, void *scratch, uint32_t W, u
 			else if (probe_env == 3) launch_walks<kProbeSmall, false>(S, wgs, job_blocks, stream);
 			else launch_walks<kProbeFull, false>(S, wgs, job_blocks, stream);
 		}
+		else if (form2 && p2 && packed_env && P.G <= 1024u) { if (check) launch_walks2<kBricksPacked, true>(S, wgs2, job_blocks, stream); else launch_walks2<kBricksPacked, false>(S, wgs2, job_blocks, stream); }
 		else if (form2 && !p2) { if (check) launch_walks2<kBricksReadAny, true>(S, wgs2, job_blocks, stream); else launch_walks2<kBricksReadAny, false>(S, wgs2, job_blocks, stream); }
 		else if (form2) { if (check) launch_walks2<kBricksRead, true>(S, wgs2, job_blocks, stream); else launch_walks2<kBricksRead, false>(S, wgs2, job_blocks, stream); }
 		else if (!p2) { if (check) launch_walks<kBricksReadAny, true>(S, wgs, job_blocks, stream); else launch_walks<kBricksReadAny, false>(S, wgs, job_blocks, stream); }

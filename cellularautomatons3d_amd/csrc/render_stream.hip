@@ -512,21 +512,9 @@ __device__ __forceinline__ bool walk_hit_test_p(const StreamParams &S, const Pac
 	unpack_cell(g, w.pos, ix, iy, iz);
 	return slab_test_at<SHADOW>(P, ix, iy, iz, vhalf, ctx, stride, e);
 }
-// walk_cell on a packed position (the word is read at every cell, as kBricksRead)
+// walk_batch on a packed position (no exempt cell: a shadow ray that starts in its own cell is advanced past it when it is set up)
 template <bool SHADOW, bool CHECK>
-__device__ __forceinline__ int walk_cell_p(const StreamParams &S, const PackGeom &g, Walker &w, bool &exempt, v3 vhalf, float k0, float k1, float eps_a, const float *ctx, int stride)
-{
-	const u32 cur = *reinterpret_cast<const u32 *>(reinterpret_cast<const char *>(S.volume) + ((w.pos >> 3) & ~3u));
-	if (__builtin_amdgcn_ubfe(cur, w.pos, 1u) != 0u && !exempt) // (the shift takes bits 0-4 of pos: the bit in the word)
-	{
-		if (walk_hit_test_p<SHADOW, CHECK>(S, g, w, vhalf, k0, k1, eps_a, ctx, stride)) return 1;
-	}
-	exempt = false;
-	return walk_advance_p(g, w) ? 2 : 0;
-}
-// walk_batch on a packed position
-template <bool SHADOW, bool CHECK>
-__device__ __forceinline__ u32 walk_batch_p(const StreamParams &S, const PackGeom &g, Walker &w, bool &exempt, int &term, v3 vhalf, float k0, float k1, float eps_a,
+__device__ __forceinline__ u32 walk_batch_p(const StreamParams &S, const PackGeom &g, Walker &w, int &term, v3 vhalf, float k0, float k1, float eps_a,
                                             const float *ctx, int stride)
 {
 	const float stx = w.tx, sty = w.ty, stz = w.tz, st = w.t;
@@ -550,8 +538,6 @@ __device__ __forceinline__ u32 walk_batch_p(const StreamParams &S, const PackGeo
 		const u32 b = (u32)(pos >> (6 * k)) & 63u;
 		live |= (b < 32u ? (word[k] >> b) & 1u : 0u) << k;
 	}
-	if (exempt) live &= ~1u;
-	exempt = false;
 	u32 visited = nvalid;
 	bool hit = false;
 	if (live)
@@ -971,6 +957,7 @@ __global__ __launch_bounds__(kW2Threads, kW2PerSimd) void ca_stream_walk2(Stream
 	w.tx = w.ty = w.tz = w.dx = w.dy = w.dz = w.t = w.tmax = w.eps_b = 0.0f;
 	w.ix = w.iy = w.iz = 0; w.sx = w.sy = w.sz = 1; w.wkey = -1; w.word = 0;
 	w.pos = 0u; w.neg = 0x49u; w.edge = 0u;
+	u32 hpos = 0u;               // kBricksPacked: the cell a walk ended its hit on
 	u32 visits = 0;              // wave-uniform
 	u32 idcount = 0;             // wave-uniform: ids waiting in ids[]
 	u32 qhead = 0, qavail = 0;   // wave-uniform: prepared rays rec[.][qhead .. qhead + qavail)
@@ -991,7 +978,7 @@ __global__ __launch_bounds__(kW2Threads, kW2PerSimd) void ca_stream_walk2(Stream
 				{
 					float tn;
 					int hx = w.ix, hy = w.iy, hz = w.iz;
-					if (PACKED) unpack_cell(pg, w.pos, hx, hy, hz);
+					if (PACKED) unpack_cell(pg, hpos, hx, hy, hz);
 					slab_test_at<false>(P, hx, hy, hz, vhalf, ctx, stride, tn);
 					out = __float_as_uint(tn);
 				}
@@ -1109,6 +1096,31 @@ __global__ __launch_bounds__(kW2Threads, kW2PerSimd) void ca_stream_walk2(Stream
 						if ((u32)lane + 64u * q < left) ids[(u32)lane + 64u * q] = keep[q];
 				}
 				idcount -= n;
+				u32 ppos = 0u, pflags = 0u;
+				if (PACKED)
+				{
+					ppos = pack_cell(pg, nw.ix, nw.iy, nw.iz);
+					pflags = (nw.sx > 0 ? 1u : 0u) | (nw.sy > 0 ? 2u : 0u) | (nw.sz > 0 ? 4u : 0u) | (ap ? 8u : 0u);
+					if (SHADOW)
+					{
+						// The cell a shadow ray starts in is visited and never tested (any(cell != startCell), :664): walk past it HERE, on every
+						// lane at once, instead of carrying an "exempt" flag through every pass of the stepping loop.
+						const bool first = pushed && ex;
+						if (first)
+						{
+							nw.pos = ppos;
+							nw.neg = ((pflags & 1u) ? 0u : pg.mx) | ((pflags & 2u) ? 0u : pg.my) | ((pflags & 4u) ? 0u : pg.mz) | 0x49u;
+							nw.edge = ((pflags & 1u) ? pg.ex : 0u) | ((pflags & 2u) ? pg.ey : 0u) | ((pflags & 4u) ? pg.ez : 0u);
+							if (walk_advance_p(pg, nw))
+							{
+								S.occl[nj] = kOcclNone; // the walk ended on its first cell
+								pushed = false;
+							}
+							ppos = nw.pos;
+						}
+						visits += (u32)__popcll(__ballot(first));
+					}
+				}
 				// prepared rays into the wave's queue, packed
 				{
 					const unsigned long long m = __ballot(pushed);
@@ -1119,9 +1131,18 @@ __global__ __launch_bounds__(kW2Threads, kW2PerSimd) void ca_stream_walk2(Stream
 						r[0 * kW2Threads] = __float_as_uint(nw.tx); r[1 * kW2Threads] = __float_as_uint(nw.ty); r[2 * kW2Threads] = __float_as_uint(nw.tz);
 						r[3 * kW2Threads] = __float_as_uint(nw.dx); r[4 * kW2Threads] = __float_as_uint(nw.dy); r[5 * kW2Threads] = __float_as_uint(nw.dz);
 						r[6 * kW2Threads] = __float_as_uint(nw.tmax);
-						r[7 * kW2Threads] = PACKED ? pack_cell(pg, nw.ix, nw.iy, nw.iz) : ((u32)nw.ix | ((u32)nw.iy << 16));
-						r[8 * kW2Threads] = (u32)nw.iz | (nw.sx > 0 ? 1u << 16 : 0u) | (nw.sy > 0 ? 1u << 17 : 0u) | (nw.sz > 0 ? 1u << 18 : 0u) | (ap ? 1u << 19 : 0u) | (ex ? 1u << 20 : 0u);
-						r[9 * kW2Threads] = nj;
+						if (PACKED)
+						{
+							r[7 * kW2Threads] = ppos;
+							r[8 * kW2Threads] = __float_as_uint(nw.t);
+							r[9 * kW2Threads] = nj | (pflags << 28); // (job ids stay below 2^28: the launcher has checked)
+						}
+						else
+						{
+							r[7 * kW2Threads] = (u32)nw.ix | ((u32)nw.iy << 16);
+							r[8 * kW2Threads] = (u32)nw.iz | (nw.sx > 0 ? 1u << 16 : 0u) | (nw.sy > 0 ? 1u << 17 : 0u) | (nw.sz > 0 ? 1u << 18 : 0u) | (ap ? 1u << 19 : 0u) | (ex ? 1u << 20 : 0u);
+							r[9 * kW2Threads] = nj;
+						}
 #pragma unroll
 						for (int q = 0; q < 6; q++) r[(10 + q) * kW2Threads] = __float_as_uint(c6[q]);
 					}
@@ -1141,25 +1162,29 @@ __global__ __launch_bounds__(kW2Threads, kW2PerSimd) void ca_stream_walk2(Stream
 					w.tx = __uint_as_float(r[0 * kW2Threads]); w.ty = __uint_as_float(r[1 * kW2Threads]); w.tz = __uint_as_float(r[2 * kW2Threads]);
 					w.dx = __uint_as_float(r[3 * kW2Threads]); w.dy = __uint_as_float(r[4 * kW2Threads]); w.dz = __uint_as_float(r[5 * kW2Threads]);
 					w.tmax = __uint_as_float(r[6 * kW2Threads]);
-					const u32 c0 = r[7 * kW2Threads], c1 = r[8 * kW2Threads];
+					const u32 c0 = r[7 * kW2Threads], c1 = r[8 * kW2Threads], c2 = r[9 * kW2Threads];
 					if (PACKED)
 					{
-						const bool ux = (c1 >> 16) & 1u, uy = (c1 >> 17) & 1u, uz = (c1 >> 18) & 1u; // the ray ascends along x / y / z
+						const bool ux = (c2 >> 28) & 1u, uy = (c2 >> 29) & 1u, uz = (c2 >> 30) & 1u; // the ray ascends along x / y / z
 						w.pos = c0;
 						w.neg = (ux ? 0u : pg.mx) | (uy ? 0u : pg.my) | (uz ? 0u : pg.mz) | 0x49u;
 						w.edge = (ux ? pg.ex : 0u) | (uy ? pg.ey : 0u) | (uz ? pg.ez : 0u);
+						w.eps_b = (c2 >> 31) ? __builtin_inff() : eps_c * (w.dx + w.dy + w.dz);
+						w.t = __uint_as_float(c1);
+						exempt = false;
+						job = (int)(c2 & 0x0FFFFFFFu);
 					}
 					else
 					{
 						w.ix = (int)(c0 & 0xFFFFu); w.iy = (int)(c0 >> 16); w.iz = (int)(c1 & 0xFFFFu);
 						w.sx = (c1 >> 16) & 1u ? 1 : -1; w.sy = (c1 >> 17) & 1u ? 1 : -1; w.sz = (c1 >> 18) & 1u ? 1 : -1;
+						w.eps_b = (c1 >> 19) & 1u ? __builtin_inff() : eps_c * (w.dx + w.dy + w.dz);
+						exempt = (c1 >> 20) & 1u;
+						w.t = SHADOW ? 0.0025f : 0.0f;
+						job = (int)c2;
 					}
-					w.eps_b = (c1 >> 19) & 1u ? __builtin_inff() : eps_c * (w.dx + w.dy + w.dz);
-					exempt = (c1 >> 20) & 1u;
-					w.t = SHADOW ? 0.0025f : 0.0f;
 					w.word = 0;
 					w.wkey = -1;
-					job = (int)r[9 * kW2Threads];
 					term = 0;
 #pragma unroll
 					for (int q = 0; q < 6; q++) ctx[q * stride] = __uint_as_float(r[(10 + q) * kW2Threads]);
@@ -1187,7 +1212,11 @@ __global__ __launch_bounds__(kW2Threads, kW2PerSimd) void ca_stream_walk2(Stream
 				u32 n = 0;
 				if (job >= 0 && term == 0)
 				{
-					if (PACKED) n = walk_batch_p<SHADOW, CHECK>(S, pg, w, exempt, term, vhalf, k0, k1, eps_a, ctx, stride);
+					if (PACKED)
+					{
+						n = walk_batch_p<SHADOW, CHECK>(S, pg, w, term, vhalf, k0, k1, eps_a, ctx, stride);
+						if (term == 1) hpos = w.pos;
+					}
 					else n = walk_batch<SHADOW, LAYOUT, CHECK>(S, w, exempt, term, vhalf, k0, k1, eps_a, ctx, stride);
 				}
 #pragma unroll
@@ -1199,11 +1228,23 @@ __global__ __launch_bounds__(kW2Threads, kW2PerSimd) void ca_stream_walk2(Stream
 		{
 			// (one state word per lane — 0 walking, 1 hit, 2 over, 3 no ray — so that "who still walks" is ONE compare whose mask is both the
 			// loop body's exec mask and the count the loop ends on)
+			// A lane that finds its hit advances like the others (its walk state is not needed again; the hit cell is kept in hpos): the
+			// body has ONE nested exec region, the live cells' filter, instead of a second one around the advance.
 			int st = (job >= 0 && term == 0) ? 0 : 3;
 			do
 			{
 				visits += (u32)walking;
-				if (st == 0) st = walk_cell_p<SHADOW, CHECK>(S, pg, w, exempt, vhalf, k0, k1, eps_a, ctx, stride);
+				if (st == 0)
+				{
+					const u32 cur = *reinterpret_cast<const u32 *>(reinterpret_cast<const char *>(S.volume) + ((w.pos >> 3) & ~3u));
+					bool hit = false;
+					if (__builtin_amdgcn_ubfe(cur, w.pos, 1u) != 0u) // (the shift takes bits 0-4 of pos: the bit in the word)
+					{
+						if (walk_hit_test_p<SHADOW, CHECK>(S, pg, w, vhalf, k0, k1, eps_a, ctx, stride)) { hit = true; hpos = w.pos; }
+					}
+					const bool over = walk_advance_p(pg, w);
+					st = hit ? 1 : (over ? 2 : 0);
+				}
 				walking = __builtin_popcountll(__builtin_amdgcn_ballot_w64(st == 0));
 			} while (walking > leave_at);
 			if (st != 3) term = st;
@@ -1432,7 +1473,7 @@ hipError_t launch_render_stream(const void *params, void *scratch, uint32_t W, u
 			else if (probe_env == 3) launch_walks<kProbeSmall, false>(S, wgs, job_blocks, stream);
 			else launch_walks<kProbeFull, false>(S, wgs, job_blocks, stream);
 		}
-		else if (form2 && p2 && packed_env && P.G <= 1024u) { if (check) launch_walks2<kBricksPacked, true>(S, wgs2, job_blocks, stream); else launch_walks2<kBricksPacked, false>(S, wgs2, job_blocks, stream); }
+		else if (form2 && p2 && packed_env && P.G <= 1024u && (unsigned long long)S.chunks * per < (1ull << 28)) { if (check) launch_walks2<kBricksPacked, true>(S, wgs2, job_blocks, stream); else launch_walks2<kBricksPacked, false>(S, wgs2, job_blocks, stream); }
 		else if (form2 && !p2) { if (check) launch_walks2<kBricksReadAny, true>(S, wgs2, job_blocks, stream); else launch_walks2<kBricksReadAny, false>(S, wgs2, job_blocks, stream); }
 		else if (form2) { if (check) launch_walks2<kBricksRead, true>(S, wgs2, job_blocks, stream); else launch_walks2<kBricksRead, false>(S, wgs2, job_blocks, stream); }
 		else if (!p2) { if (check) launch_walks<kBricksReadAny, true>(S, wgs, job_blocks, stream); else launch_walks<kBricksReadAny, false>(S, wgs, job_blocks, stream); }

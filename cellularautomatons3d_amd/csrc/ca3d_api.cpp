@@ -226,6 +226,28 @@ struct ca3d_engine
 	hipEvent_t r_fork = nullptr, r_join = nullptr;
 	bool rev_valid = false;
 	ca3d_render_stats rstats{};
+	// Two converged frames in flight (option "render_pipeline", default 1). A frame's two persistent walk launches each end in a tail with
+	// most of the chip idle (render_stream.hip: a third to a half of a 1080p launch) and its passes depend on each other — but not on
+	// the frame before: a converged frame has no history. Frames that stay on the device (no host pointers) and are drawn by the stream
+	// passes alternate between two LANES — a stream, a side stream, scratch, counters and events each — so that the next frame's walks
+	// fill the tails of this one's. A lane waits for the engine's stream at the moment of the call (steps, uploads before the frame);
+	// the engine's stream waits for the lanes LAZILY: the next call that touches the state, a target or the stream joins them
+	// (bind_device). The presentation surface is shared: a frame's pixel-writing kernels wait for the frame before (RenderLaunch::after).
+	// Only on the engine's own stream: a caller who set a stream of their own expects every frame ordered on it.
+	struct FrameLane
+	{
+		hipStream_t s = nullptr, aux = nullptr;
+		hipEvent_t fork = nullptr, join = nullptr, start = nullptr, stop = nullptr, done = nullptr;
+		void *scratch = nullptr;
+		size_t scratch_bytes = 0;
+		unsigned long long *counters = nullptr;
+		bool pending = false; // frames on this lane the engine's stream has not been made to wait for
+		bool used = false;    // `done` has been recorded at least once
+	} lanes[2];
+	hipEvent_t ev_state = nullptr; // "everything the engine's stream held when the frame was asked for"
+	int render_pipeline = 1;
+	int lane_next = 0;
+	int last_lane = -1; // the lane of the last frame (-1: it went down the engine's stream) — whose events and counters ca3d_get_render_stats reads
 
 	size_t buffer_words() const { return plane_words * nplanes; }
 	size_t state_words() const { return plane_words * (slab ? nz : G); }
@@ -293,9 +315,22 @@ void free_buffers(ca3d_engine *h)
 	h->ghosts_valid = false;
 }
 
-int bind_device(ca3d_engine *h)
+// the engine's stream waits for the frames in flight on the lanes (nothing is waited for on the host)
+int join_frames(ca3d_engine *h)
+{
+	for (auto &L : h->lanes)
+		if (L.pending)
+		{
+			HIP_TRY(hipStreamWaitEvent(h->stream, L.done, 0));
+			L.pending = false;
+		}
+	return CA3D_OK;
+}
+
+int bind_device(ca3d_engine *h, bool join = true)
 {
 	HIP_TRY(hipSetDevice(h->device));
+	if (join && (h->lanes[0].pending || h->lanes[1].pending)) return join_frames(h);
 	return CA3D_OK;
 }
 
@@ -953,6 +988,8 @@ int ca3d_destroy(ca3d_t *h) CA3D_API_TRY
 	hipSetDevice(h->device);
 	h->queued = 0; // never submitted: the state goes away with the engine
 	if (h->stream || h->own_stream) hipStreamSynchronize(h->stream);
+	for (auto &L : h->lanes)
+		if (L.s) hipStreamSynchronize(L.s); // frames in flight read the state
 	resident_stream_retired(h->stream);
 	free_buffers(h);
 	free_render_targets(h);
@@ -965,6 +1002,16 @@ int ca3d_destroy(ca3d_t *h) CA3D_API_TRY
 	if (h->r_occ) hipFree(h->r_occ);
 	if (h->r_stream) hipFree(h->r_stream);
 	if (h->r_bricks) hipFree(h->r_bricks);
+	for (auto &L : h->lanes)
+	{
+		if (L.s) { hipStreamSynchronize(L.s); hipStreamDestroy(L.s); }
+		if (L.aux) hipStreamDestroy(L.aux);
+		for (hipEvent_t e : {L.fork, L.join, L.start, L.stop, L.done})
+			if (e) hipEventDestroy(e);
+		if (L.scratch) hipFree(L.scratch);
+		if (L.counters) hipFree(L.counters);
+	}
+	if (h->ev_state) hipEventDestroy(h->ev_state);
 	if (h->r_aux) hipStreamDestroy(h->r_aux);
 	if (h->r_fork) hipEventDestroy(h->r_fork);
 	if (h->r_join) hipEventDestroy(h->r_join);
@@ -1525,6 +1572,7 @@ int ca3d_render_target(ca3d_t *h, int which, void **device_ptr, size_t *n_bytes)
 {
 	if (!h || !device_ptr || !n_bytes) return fail(CA3D_ERR_INVALID_ARGUMENT, "NULL argument");
 	if (!h->r_present) return fail(CA3D_ERR_NOT_CONFIGURED, "ca3d_render has not been called yet");
+	if (int rcb = bind_device(h)) return rcb; // (whoever reads the target after the engine's stream also reads it after the frames in flight)
 	const size_t px = (size_t)h->rw * h->rh;
 	switch (which)
 	{
@@ -1762,7 +1810,13 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 	if (width == 0 || height == 0 || width > 16384u || height > 16384u) return fail(CA3D_ERR_INVALID_ARGUMENT, "bad target size %ux%u", width, height);
 	if (spp != 1 && spp != 4) return fail(CA3D_ERR_INVALID_ARGUMENT, "spp must be 1 or 4");
 	if (h->render_mode == 1 && spp != 1) return fail(CA3D_ERR_INVALID_ARGUMENT, "the literal frame mode takes one jittered sample per pixel (spp = 1)");
-	int rc = bind_device(h);
+	// two frames in flight (FrameLane): converged frames of a packed volume that stay on the device and go down the stream passes
+	static const char *trace_path = getenv("CA3D_RENDER_TRACE");
+	static const bool aux_off = getenv("CA3D_RENDER_AUX") && atoi(getenv("CA3D_RENDER_AUX")) == 0; // tuning: everything on one stream
+	const bool pipelined = h->render_pipeline && h->render_mode == 0 && !presentation_rgba8 && !light_rgba16f && !depth_rg16f && h->stream == h->own_stream &&
+	                       h->layout == CA3D_LAYOUT_PACKED32 && h->render_stream && h->render_sched && !h->render_indirect && !h->render_stream_check && !trace_path &&
+	                       !aux_off && !h->render_row0 && !h->render_row1 && width == h->rw && height == h->rh;
+	int rc = bind_device(h, !pipelined);
 	if (rc) return rc;
 	// The frame shows a state the engine has verified — when the caller gets the frame back on the host. A frame that stays on the
 	// device (no host pointers: the reference's render pass, which only enqueues) does not block on the step batch in front of it: a
@@ -1775,7 +1829,7 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 	if (width != h->rw || height != h->rh)
 	{
 		// _createResolutionDependentAssests (main_pathtraced.js:729-779)
-		HIP_TRY(hipStreamSynchronize(h->stream));
+		HIP_TRY(hipStreamSynchronize(h->stream)); // (a frame of a new size is never pipelined: the lanes were joined above)
 		free_render_targets(h);
 		HIP_TRY(hipMalloc((void **)&h->r_present, px * 4));
 		for (int i = 0; i < 2; i++)
@@ -1791,7 +1845,6 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 	}
 	// diagnostics: CA3D_RENDER_TRACE=<file> makes every wave of the scheduled kernel record when and where it ran
 	// (tools/render_trace.py draws the occupancy timeline from the file)
-	static const char *trace_path = getenv("CA3D_RENDER_TRACE");
 	const size_t trace_waves = trace_path ? ((size_t)(width + 31u) / 32u * 2u) * ((height + 15u) / 16u * 4u) : 0u; // wave tiles of 16 x 4 pixels
 	const size_t counter_words = 8u + 4u * trace_waves;
 	if (h->r_counters && h->r_counter_words < counter_words) { HIP_TRY(hipFree(h->r_counters)); h->r_counters = nullptr; }
@@ -1800,7 +1853,31 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 		HIP_TRY(hipMalloc((void **)&h->r_counters, counter_words * sizeof(unsigned long long)));
 		h->r_counter_words = counter_words;
 	}
-	HIP_TRY(hipMemsetAsync(h->r_counters, 0, (trace_path ? counter_words : 8u) * sizeof(unsigned long long), h->stream)); // [3]: the tile queue's head
+	// where this frame runs: the engine's stream, or the next lane
+	ca3d_engine::FrameLane *L = nullptr;
+	hipStream_t rs = h->stream;
+	unsigned long long *counters = h->r_counters;
+	if (pipelined)
+	{
+		L = &h->lanes[h->lane_next];
+		if (!L->s)
+		{
+			HIP_TRY(hipStreamCreateWithFlags(&L->s, hipStreamNonBlocking));
+			HIP_TRY(hipStreamCreateWithFlags(&L->aux, hipStreamNonBlocking));
+			HIP_TRY(hipEventCreateWithFlags(&L->fork, hipEventDisableTiming));
+			HIP_TRY(hipEventCreateWithFlags(&L->join, hipEventDisableTiming));
+			HIP_TRY(hipEventCreateWithFlags(&L->done, hipEventDisableTiming));
+			HIP_TRY(hipEventCreate(&L->start));
+			HIP_TRY(hipEventCreate(&L->stop));
+			HIP_TRY(hipMalloc((void **)&L->counters, 8u * sizeof(unsigned long long)));
+		}
+		if (!h->ev_state) HIP_TRY(hipEventCreateWithFlags(&h->ev_state, hipEventDisableTiming));
+		HIP_TRY(hipEventRecord(h->ev_state, h->stream)); // the steps and uploads in front of this frame
+		HIP_TRY(hipStreamWaitEvent(L->s, h->ev_state, 0));
+		rs = L->s;
+		counters = L->counters;
+	}
+	HIP_TRY(hipMemsetAsync(counters, 0, (trace_path ? counter_words : 8u) * sizeof(unsigned long long), rs)); // [3]: the tile queue's head
 	RenderLaunch l;
 	l.trace = trace_path != nullptr;
 	l.cells = h->buf[h->cur];
@@ -1812,7 +1889,7 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 	l.presentation = h->r_present;
 	l.light = h->r_light[h->r_swap];
 	l.depth = h->r_depth[h->r_swap];
-	l.counters = h->r_counters;
+	l.counters = counters;
 	if (h->buffers_exposed) h->state_serial++; // a caller holds a pointer to the state and may have written it since the last frame
 	const uint64_t state_key[3] = {h->state_serial, h->step, (uint64_t)(uintptr_t)l.cells}; // what the occupancy bits / the bricks were built from
 	bool occ_built = false, bricks_built = false;
@@ -1823,6 +1900,8 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 		if (words != h->r_occ_words)
 		{
 			h->r_occ_key[0] = 0;
+			for (auto &fl : h->lanes)
+				if (fl.s) HIP_TRY(hipStreamSynchronize(fl.s));
 			if (h->r_occ) HIP_TRY(hipFree(h->r_occ));
 			h->r_occ = nullptr;
 			h->r_occ_words = 0;
@@ -1844,8 +1923,13 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 	l.legacy = h->layout == CA3D_LAYOUT_UNPACKED; // legacy volume -> legacy shader (pathtraced_fragment.wgsl)
 	l.prev_light = h->r_light[h->r_swap ^ 1]; // group 1 of the render pass: last frame's targets (1519-1555, 1787)
 	l.prev_depth = h->r_depth[h->r_swap ^ 1];
-	static const bool aux_off = getenv("CA3D_RENDER_AUX") && atoi(getenv("CA3D_RENDER_AUX")) == 0; // tuning: everything on one stream
-	if (!aux_off && h->render_mode == 0 && h->render_sched && !trace_path)
+	if (L)
+	{
+		l.aux = L->aux;
+		l.ev_fork = L->fork;
+		l.ev_join = L->join;
+	}
+	else if (!aux_off && h->render_mode == 0 && h->render_sched && !trace_path)
 	{
 		if (!h->r_aux)
 		{
@@ -1861,20 +1945,22 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 	{
 		size_t o0, o1, o2;
 		const size_t need = stream_scratch_bytes(width, height, spp, &o0, &o1, &o2);
-		if (h->r_stream_bytes < need)
+		void *&scratch = L ? L->scratch : h->r_stream;
+		size_t &scratch_bytes = L ? L->scratch_bytes : h->r_stream_bytes;
+		if (scratch_bytes < need)
 		{
-			HIP_TRY(hipStreamSynchronize(h->stream));
-			if (h->r_stream) HIP_TRY(hipFree(h->r_stream));
-			h->r_stream = nullptr;
-			h->r_stream_bytes = 0;
-			HIP_TRY(hipMalloc(&h->r_stream, need));
-			h->r_stream_bytes = need;
+			HIP_TRY(hipStreamSynchronize(rs));
+			if (scratch) HIP_TRY(hipFree(scratch));
+			scratch = nullptr;
+			scratch_bytes = 0;
+			HIP_TRY(hipMalloc(&scratch, need));
+			scratch_bytes = need;
 		}
-		l.stream_scratch = h->r_stream;
+		l.stream_scratch = scratch;
 		l.stream_check = h->render_stream_check != 0;
 		// the check below reads the passes' control words after the frame: zero them here, for a frame whose stream passes do not run
 		// (volume off screen or outside the band) would otherwise report an earlier frame's counts — or, on fresh scratch, noise
-		if (l.stream_check) HIP_TRY(hipMemsetAsync(h->r_stream, 0, 4096, h->stream));
+		if (l.stream_check) HIP_TRY(hipMemsetAsync(scratch, 0, 4096, rs));
 	}
 	if (h->render_frame_bricks && frame_bricks_applies(h->G) && (h->render_mode == 1 || l.stream_scratch))
 	{
@@ -1882,6 +1968,8 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 		if (h->r_bricks_bytes != need)
 		{
 			HIP_TRY(hipStreamSynchronize(h->stream));
+			for (auto &fl : h->lanes)
+				if (fl.s) HIP_TRY(hipStreamSynchronize(fl.s));
 			if (h->r_bricks) HIP_TRY(hipFree(h->r_bricks));
 			h->r_bricks = nullptr;
 			h->r_bricks_bytes = 0;
@@ -1893,8 +1981,19 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 		l.bricks_valid = !memcmp(state_key, h->r_bricks_key, sizeof state_key);
 		l.bricks_built = &bricks_built;
 	}
-	HIP_TRY(hipEventRecord(h->rev_start, h->stream));
-	hipError_t e = launch_render(l, h->stream);
+	if (L)
+	{
+		ca3d_engine::FrameLane &other = h->lanes[h->lane_next ^ 1];
+		if (other.used)
+		{
+			l.after = other.done; // the presentation surface is shared: this frame's pixels after the other lane's
+			// the occupancy bits and the bricks are shared too: a frame that rebuilds them waits for the one that may still be reading them
+			const bool occ_rebuild = l.occ && !l.occ_valid, bricks_rebuild = l.bricks && !l.bricks_valid;
+			if (occ_rebuild || bricks_rebuild) HIP_TRY(hipStreamWaitEvent(rs, other.done, 0));
+		}
+	}
+	HIP_TRY(hipEventRecord(L ? L->start : h->rev_start, rs));
+	hipError_t e = launch_render(l, rs);
 	if (e != hipSuccess)
 	{
 		h->r_occ_key[0] = h->r_bricks_key[0] = 0; // whatever was half built is not to be trusted
@@ -1903,8 +2002,15 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 	// the derived buffers this call rebuilt now describe this state; the ones it did not touch keep the key of the state they were built from
 	if (occ_built) memcpy(h->r_occ_key, state_key, sizeof state_key);
 	if (bricks_built) memcpy(h->r_bricks_key, state_key, sizeof state_key);
-	HIP_TRY(hipEventRecord(h->rev_stop, h->stream));
+	HIP_TRY(hipEventRecord(L ? L->stop : h->rev_stop, rs));
 	h->rev_valid = true;
+	h->last_lane = L ? h->lane_next : -1;
+	if (L)
+	{
+		HIP_TRY(hipEventRecord(L->done, rs));
+		L->pending = L->used = true;
+		h->lane_next ^= 1;
+	}
 	if (trace_path)
 	{
 		std::vector<unsigned long long> t(counter_words);
@@ -1941,11 +2047,13 @@ int ca3d_get_render_stats(ca3d_t *h, ca3d_render_stats *out) CA3D_API_TRY
 	if (!h->rev_valid) return fail(CA3D_ERR_NOT_CONFIGURED, "ca3d_render has not been called yet");
 	int rc = bind_device(h);
 	if (rc) return rc;
-	HIP_TRY(hipEventSynchronize(h->rev_stop));
+	// the last frame's events and counters: the engine's, or those of the lane it ran on (two frames in flight)
+	const ca3d_engine::FrameLane *L = h->last_lane >= 0 ? &h->lanes[h->last_lane] : nullptr;
+	HIP_TRY(hipEventSynchronize(L ? L->stop : h->rev_stop));
 	float ms = 0.f;
-	HIP_TRY(hipEventElapsedTime(&ms, h->rev_start, h->rev_stop));
+	HIP_TRY(hipEventElapsedTime(&ms, L ? L->start : h->rev_start, L ? L->stop : h->rev_stop));
 	unsigned long long c[3] = {0, 0, 0};
-	HIP_TRY(hipMemcpy(c, h->r_counters, sizeof c, hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(c, L ? L->counters : h->r_counters, sizeof c, hipMemcpyDeviceToHost));
 	h->rstats.gpu_ms = ms;
 	h->rstats.shadow_rays = c[0];
 	h->rstats.primary_cell_visits = c[1];
@@ -2024,6 +2132,7 @@ int ca3d_set_option(ca3d_t *h, const char *name, int64_t value) CA3D_API_TRY
 	}
 	if (!strcmp(name, "render_frame_bricks")) { h->render_frame_bricks = value ? 1 : 0; return CA3D_OK; }
 	if (!strcmp(name, "render_stream")) { h->render_stream = value ? 1 : 0; return CA3D_OK; }
+	if (!strcmp(name, "render_pipeline")) { h->render_pipeline = value ? 1 : 0; return CA3D_OK; } // two converged frames in flight (FrameLane)
 	if (!strcmp(name, "render_stream_check")) { h->render_stream_check = value ? 1 : 0; return CA3D_OK; }
 	if (!strcmp(name, "render_row_begin") || !strcmp(name, "render_row_end"))
 	{

@@ -1058,6 +1058,12 @@ hipError_t launch_render(const RenderLaunch &l, hipStream_t stream)
 		{
 			hipError_t e = hipEventRecord(l.ev_fork, stream);
 			if (e == hipSuccess) e = hipStreamWaitEvent(l.aux, l.ev_fork, 0);
+			if (e == hipSuccess && l.after) e = hipStreamWaitEvent(l.aux, l.after, 0); // the side kernels write pixels: after the frame before
+			if (e != hipSuccess) return e;
+		}
+		else if (l.after)
+		{
+			hipError_t e = hipStreamWaitEvent(stream, l.after, 0);
 			if (e != hipSuccess) return e;
 		}
 		if (tiles)
@@ -1070,7 +1076,7 @@ hipError_t launch_render(const RenderLaunch &l, hipStream_t stream)
 			const bool streamed = l.stream_scratch && !P.legacy && !P.trace;
 			if (streamed)
 			{
-				hipError_t e = launch_render_stream(&P, l.stream_scratch, l.W, l.H, l.stream_check, l.bricks, l.bricks_valid, stream, l.bricks_built);
+				hipError_t e = launch_render_stream(&P, l.stream_scratch, l.W, l.H, l.stream_check, l.bricks, l.bricks_valid, stream, l.bricks_built, l.after);
 				if (e != hipSuccess) return e;
 			}
 			if (one)

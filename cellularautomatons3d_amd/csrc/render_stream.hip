@@ -1391,7 +1391,7 @@ size_t stream_scratch_bytes(uint32_t W, uint32_t H, uint32_t spp, size_t *hit_of
 
 // The dense-volume part of a frame over the rectangle P.rx0 .. P.ry1 (render.hip's volume_rect), on `stream`. The caller has
 // cleared P.counters and, when there is one, run the occupancy pass (the passes here test its count on the device).
-hipError_t launch_render_stream(const void *params, void *scratch, uint32_t W, uint32_t H, bool check, uint32_t *bricks, bool bricks_valid, hipStream_t stream, bool *bricks_built)
+hipError_t launch_render_stream(const void *params, void *scratch, uint32_t W, uint32_t H, bool check, uint32_t *bricks, bool bricks_valid, hipStream_t stream, bool *bricks_built, hipEvent_t before_resolve)
 {
 	StreamParams S;
 	S.R = *static_cast<const RenderParams *>(params);
@@ -1484,6 +1484,11 @@ hipError_t launch_render_stream(const void *params, void *scratch, uint32_t W, u
 	}
 	else if (p2) { if (check) launch_walks<kRowsP2, true>(S, wgs, job_blocks, stream); else launch_walks<kRowsP2, false>(S, wgs, job_blocks, stream); }
 	else { if (check) launch_walks<kRowsAny, true>(S, wgs, job_blocks, stream); else launch_walks<kRowsAny, false>(S, wgs, job_blocks, stream); }
+	if (before_resolve) // (two frames in flight: the frame before this one must have written the shared presentation surface first)
+	{
+		hipError_t ew = hipStreamWaitEvent(stream, before_resolve, 0);
+		if (ew != hipSuccess) return ew;
+	}
 	hipLaunchKernelGGL(ca_stream_resolve, dim3((S.chunks * (per / P.spp) + 255u) / 256u), dim3(256), 0, stream, S);
 	if (S.trace)
 	{

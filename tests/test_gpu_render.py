@@ -735,3 +735,70 @@ def test_legacy_renderer_over_the_unpacked_volume(eng):
     eng.upload_state(packed)
     _, _, d2 = eng.render(u, W, H, 1)
     assert (np.abs(d2.astype(np.float32)[..., 0] - depth.astype(np.float32)[..., 0]) <= 2e-3).mean() >= 0.999
+
+
+def _targets(eng):
+    """The engine's three render targets as they stand on the device (after everything enqueued)."""
+    import ctypes
+
+    hip = ctypes.CDLL("libamdhip64.so")
+    out = []
+    for which in (0, 1, 2):
+        ptr, nbytes = eng.render_target(which)
+        eng.synchronize()
+        buf = np.empty(nbytes, dtype=np.uint8)
+        assert hip.hipMemcpy(ctypes.c_void_p(buf.ctypes.data), ctypes.c_void_p(ptr), ctypes.c_size_t(nbytes), 2) == 0
+        out.append(buf)
+    return out
+
+
+def test_two_frames_in_flight(eng):
+    """Converged frames that stay on the device alternate between two streams of the engine (option render_pipeline, default on), so that
+    one frame's walks fill the idle tail of the other's. What must not change: the targets after a run of such frames are those of the LAST
+    frame asked for — camera moving from frame to frame, the state stepped and uploaded between frames (a frame in flight reads the state it
+    was asked for; the step behind it waits) — byte for byte the frame an engine without the pipeline leaves there."""
+    G, W, H, spp = 128, 640, 360, 4
+    eng.configure(G)
+    set_rules(eng, rules("default"))
+    cells = host.random_fill(host.words_per_buffer(G), seed=11, and_rounds=4)
+    poses = [host.orbit_camera(1.4 + 0.02 * i, (1.0, 1.0, 0.0), 0.6 + 0.05 * i) for i in range(7)]
+
+    def run(pipe):
+        eng.set_option("render_pipeline", pipe)
+        eng.upload_state(cells)
+        got = []
+        # a run of frames, the camera moving: the last one counts
+        for vm in poses:
+            eng.render(host.uniform_block(W, H, vm), W, H, spp, readback=False)
+        got.append(_targets(eng))
+        st = eng.render_stats()
+        got.append([np.array([st.primary_rays, st.shadow_rays, st.primary_cell_visits, st.shadow_cell_visits], dtype=np.uint64).view(np.uint8)])
+        # steps between frames: every frame shows the state of its moment, the last one the last state
+        for i, vm in enumerate(poses):
+            eng.render(host.uniform_block(W, H, vm), W, H, spp, readback=False)
+            eng.step(1 + (i & 1))
+        eng.render(host.uniform_block(W, H, poses[0]), W, H, spp, readback=False)
+        got.append(_targets(eng))
+        # a batch of steps right behind a frame in flight: the frame in the targets is the one of the state BEFORE them
+        eng.render(host.uniform_block(W, H, poses[5]), W, H, spp, readback=False)
+        eng.step(24)
+        got.append(_targets(eng))
+        # an upload right behind a frame in flight, then two frames
+        eng.upload_state(cells[::-1].copy())
+        eng.render(host.uniform_block(W, H, poses[1]), W, H, spp, readback=False)
+        eng.render(host.uniform_block(W, H, poses[2]), W, H, spp, readback=False)
+        got.append(_targets(eng))
+        # a frame read back through host pointers behind frames in flight (it joins them), and a literal frame behind those
+        eng.render(host.uniform_block(W, H, poses[3]), W, H, spp, readback=False)
+        pres, light, depth = eng.render(host.uniform_block(W, H, poses[4]), W, H, spp)
+        got.append([pres.view(np.uint8).ravel(), light.view(np.uint8).ravel(), depth.view(np.uint8).ravel()])
+        return got
+
+    try:
+        a, b = run(0), run(1)
+    finally:
+        eng.set_option("render_pipeline", 1)
+    for fa, fb in zip(a, b):
+        for x, y in zip(fa, fb):
+            np.testing.assert_array_equal(x, y)
+    assert a[0][1].any()  # the scene is not empty

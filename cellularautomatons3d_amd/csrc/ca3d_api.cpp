@@ -236,8 +236,9 @@ struct ca3d_engine
 	// Only on the engine's own stream: a caller who set a stream of their own expects every frame ordered on it.
 	struct FrameLane
 	{
-		hipStream_t s = nullptr, aux = nullptr;
-		hipEvent_t fork = nullptr, join = nullptr, start = nullptr, stop = nullptr, done = nullptr;
+		hipStream_t s = nullptr;
+		hipEvent_t start = nullptr, stop = nullptr, done = nullptr;
+		bool need_state = true; // the engine's stream has had work since this lane's last frame: wait for ev_state first
 		void *scratch = nullptr;
 		size_t scratch_bytes = 0;
 		unsigned long long *counters = nullptr;
@@ -245,6 +246,8 @@ struct ca3d_engine
 		bool used = false;    // `done` has been recorded at least once
 	} lanes[2];
 	hipEvent_t ev_state = nullptr; // "everything the engine's stream held when the frame was asked for"
+	bool main_touched = true;      // an entry point other than a pipelined ca3d_render has run since ev_state was recorded (bind_device)
+	std::vector<hipStream_t> lane_spares; // streams that turned out to share a hardware queue with lane 0 (kept: destroying one hands its queue to the next)
 	int render_pipeline = 1;
 	int lane_next = 0;
 	int last_lane = -1; // the lane of the last frame (-1: it went down the engine's stream) — whose events and counters ca3d_get_render_stats reads
@@ -330,6 +333,7 @@ int join_frames(ca3d_engine *h)
 int bind_device(ca3d_engine *h, bool join = true)
 {
 	HIP_TRY(hipSetDevice(h->device));
+	if (join) h->main_touched = true; // (whatever the caller is about to put on the engine's stream: the next pipelined frame waits for it)
 	if (join && (h->lanes[0].pending || h->lanes[1].pending)) return join_frames(h);
 	return CA3D_OK;
 }
@@ -1005,12 +1009,12 @@ int ca3d_destroy(ca3d_t *h) CA3D_API_TRY
 	for (auto &L : h->lanes)
 	{
 		if (L.s) { hipStreamSynchronize(L.s); hipStreamDestroy(L.s); }
-		if (L.aux) hipStreamDestroy(L.aux);
-		for (hipEvent_t e : {L.fork, L.join, L.start, L.stop, L.done})
+		for (hipEvent_t e : {L.start, L.stop, L.done})
 			if (e) hipEventDestroy(e);
 		if (L.scratch) hipFree(L.scratch);
 		if (L.counters) hipFree(L.counters);
 	}
+	for (hipStream_t sp : h->lane_spares) hipStreamDestroy(sp);
 	if (h->ev_state) hipEventDestroy(h->ev_state);
 	if (h->r_aux) hipStreamDestroy(h->r_aux);
 	if (h->r_fork) hipEventDestroy(h->r_fork);
@@ -1857,23 +1861,48 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 	ca3d_engine::FrameLane *L = nullptr;
 	hipStream_t rs = h->stream;
 	unsigned long long *counters = h->r_counters;
-	if (pipelined)
+	if (pipelined && !h->lanes[1].s)
+	{
+		// first pipelined frame: the lanes. Two streams that the runtime has put on DIFFERENT hardware queues (probed: ca_diag.hip) — two
+		// streams on one queue run in order and the second frame would only queue up behind the first. No such pair: no pipeline.
+		ca3d_engine::FrameLane &A = h->lanes[0], &B = h->lanes[1];
+		if (!A.s) HIP_TRY(hipStreamCreateWithFlags(&A.s, hipStreamNonBlocking));
+		hipStream_t cand = nullptr;
+		for (int tries = 0; tries < 6 && !B.s; tries++)
+		{
+			HIP_TRY(hipStreamCreateWithFlags(&cand, hipStreamNonBlocking));
+			bool side_by_side = false;
+			HIP_TRY(streams_concurrent(A.s, cand, &side_by_side));
+			if (side_by_side) B.s = cand;
+			else h->lane_spares.push_back(cand);
+		}
+		if (!B.s) h->render_pipeline = 0;
+		else
+			for (auto &fl : h->lanes)
+			{
+				HIP_TRY(hipEventCreateWithFlags(&fl.done, hipEventDisableTiming));
+				HIP_TRY(hipEventCreate(&fl.start));
+				HIP_TRY(hipEventCreate(&fl.stop));
+				HIP_TRY(hipMalloc((void **)&fl.counters, 8u * sizeof(unsigned long long)));
+			}
+		if (!h->ev_state) HIP_TRY(hipEventCreateWithFlags(&h->ev_state, hipEventDisableTiming));
+	}
+	if (pipelined && h->render_pipeline)
 	{
 		L = &h->lanes[h->lane_next];
-		if (!L->s)
+		if (h->main_touched)
 		{
-			HIP_TRY(hipStreamCreateWithFlags(&L->s, hipStreamNonBlocking));
-			HIP_TRY(hipStreamCreateWithFlags(&L->aux, hipStreamNonBlocking));
-			HIP_TRY(hipEventCreateWithFlags(&L->fork, hipEventDisableTiming));
-			HIP_TRY(hipEventCreateWithFlags(&L->join, hipEventDisableTiming));
-			HIP_TRY(hipEventCreateWithFlags(&L->done, hipEventDisableTiming));
-			HIP_TRY(hipEventCreate(&L->start));
-			HIP_TRY(hipEventCreate(&L->stop));
-			HIP_TRY(hipMalloc((void **)&L->counters, 8u * sizeof(unsigned long long)));
+			// the steps and uploads in front of this frame — recorded only when an entry point has touched the engine's stream since the last
+			// record (a marker behind another lane's frames on a shared hardware queue would make this frame wait for them)
+			HIP_TRY(hipEventRecord(h->ev_state, h->stream));
+			h->main_touched = false;
+			h->lanes[0].need_state = h->lanes[1].need_state = true;
 		}
-		if (!h->ev_state) HIP_TRY(hipEventCreateWithFlags(&h->ev_state, hipEventDisableTiming));
-		HIP_TRY(hipEventRecord(h->ev_state, h->stream)); // the steps and uploads in front of this frame
-		HIP_TRY(hipStreamWaitEvent(L->s, h->ev_state, 0));
+		if (L->need_state)
+		{
+			HIP_TRY(hipStreamWaitEvent(L->s, h->ev_state, 0));
+			L->need_state = false;
+		}
 		rs = L->s;
 		counters = L->counters;
 	}
@@ -1923,12 +1952,7 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 	l.legacy = h->layout == CA3D_LAYOUT_UNPACKED; // legacy volume -> legacy shader (pathtraced_fragment.wgsl)
 	l.prev_light = h->r_light[h->r_swap ^ 1]; // group 1 of the render pass: last frame's targets (1519-1555, 1787)
 	l.prev_depth = h->r_depth[h->r_swap ^ 1];
-	if (L)
-	{
-		l.aux = L->aux;
-		l.ev_fork = L->fork;
-		l.ev_join = L->join;
-	}
+	if (L) {} // (a lane is ONE stream: its side kernels run behind its stream passes, the other lane's frame fills the chip meanwhile)
 	else if (!aux_off && h->render_mode == 0 && h->render_sched && !trace_path)
 	{
 		if (!h->r_aux)

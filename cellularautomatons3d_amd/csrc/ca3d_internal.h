@@ -182,6 +182,8 @@ struct RenderLaunch
 
 // ca_diag.hip: float4 device-to-device copy (measurement only)
 hipError_t launch_copy_f4(const void *in, void *out, size_t bytes, hipStream_t stream);
+// ca_diag.hip: do two (idle) streams run side by side, i.e. sit on different hardware queues? (probe: ~2 ms)
+hipError_t streams_concurrent(hipStream_t a, hipStream_t b, bool *out);
 // render.hip
 hipError_t launch_render(const RenderLaunch &l, hipStream_t stream);
 // render_stream.hip: bytes of scratch a frame of this size needs at most (and where its three arrays start); the passes themselves

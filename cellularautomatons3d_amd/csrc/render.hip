@@ -1061,11 +1061,7 @@ hipError_t launch_render(const RenderLaunch &l, hipStream_t stream)
 			if (e == hipSuccess && l.after) e = hipStreamWaitEvent(l.aux, l.after, 0); // the side kernels write pixels: after the frame before
 			if (e != hipSuccess) return e;
 		}
-		else if (l.after)
-		{
-			hipError_t e = hipStreamWaitEvent(stream, l.after, 0);
-			if (e != hipSuccess) return e;
-		}
+
 		if (tiles)
 		{
 			int dev = 0, cus = 256;
@@ -1089,6 +1085,13 @@ hipError_t launch_render(const RenderLaunch &l, hipStream_t stream)
 				if (!streamed) hipLaunchKernelGGL((ca_render_packed_sched<false, 64, kSchedChunk, kSchedWaves>), dim3(wgs), dim3(256), 0, stream, P);
 				if (P.occ) hipLaunchKernelGGL((ca_render_packed_sched<true, 64, kSchedChunk, kSchedWaves>), dim3(wgs), dim3(256), 0, side, P);
 			}
+		}
+		if (!beside && l.after)
+		{
+			// two frames in flight, one stream per frame: the side kernels below write pixels — after the frame before (the stream passes'
+			// resolve has waited for the same event; a frame without stream passes has not)
+			hipError_t e = hipStreamWaitEvent(stream, l.after, 0);
+			if (e != hipSuccess) return e;
 		}
 		P.outside_only = tiles ? 1u : 0u;
 		if (around) hipLaunchKernelGGL(ca_render_packed<false>, grid, dim3(256), 0, side, P);

@@ -34,7 +34,7 @@ if a.literal:
     eng.set_render_mode(True)
     eng.reset_render_history()
 frame_u = lambda i: host.uniform_block(W, H, vm, elapsed_time=0.5 + 0.01 * i, prev_view_mat=vm) if a.literal else host.uniform_block(W, H, vm)
-for i in range(3 if a.literal else 1):
+for i in range(3):
     eng.render(frame_u(i), W, H, a.spp, readback=False)
 eng.synchronize()
 t0 = time.perf_counter()

@@ -91,8 +91,17 @@ __global__ __launch_bounds__(256, 4) void ca_render_packed_spread(RenderParams P
 	u32 shadow = 0, pvis = 0, svis = 0;
 	const float inv = 1.0f / (float)spp;
 	const float ig = P.legacy ? 1.0f / 2.2f : 1.0f / P.u[U_GAMMA];
+	// bg: only the tiles something can be seen in — the live box's rectangle and the light gizmo's (16-aligned: a tile lies inside or
+	// outside as a whole); ca_render_background fills the others (same test there)
+	PixRect live_rect;
+	const bool rects = P.bg != 0u && live_rect_load(P, live_rect);
 	for (u32 t = blockIdx.x; t < ntx * nty; t += gridDim.x)
 	{
+		if (rects)
+		{
+			const u32 ox = ((t % ntx) * tw) & ~15u, oy = P.row0 + (((t / ntx) * th) & ~15u);
+			if (!in_pix_rect(live_rect, ox, oy) && !(ox >= P.gx0 && ox < P.gx1 && oy >= P.gy0 && oy < P.gy1)) continue;
+		}
 		const u32 px = (t % ntx) * tw + p % tw, py = P.row0 + (t / ntx) * th + p / tw;
 		const bool live = px < P.W && py < P.row1;
 		Sample s{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0u};
@@ -137,6 +146,91 @@ __global__ __launch_bounds__(256, 4) void ca_render_packed_spread(RenderParams P
 	}
 }
 
+// Round 5: the pixels nothing can be seen in (RenderParams::bg). One lane per pixel, 16 x 16 tiles over the band. Which kernel owns a
+// tile is decided from the same words on every side (the volume's rectangle from the host, the occupancy count and the live box's
+// rectangle on the device): dense or scattered volume — the tiles of the volume's rectangle belong to the stream passes / the
+// scheduled kernel, this kernel takes the rest; small live box — the tiles of the live box's and the gizmo's rectangles belong to
+// ca_render_packed_spread, this kernel takes the rest. What it writes is what the plain kernel writes there, bit for bit:
+//   outside the volume's rectangle   every view ray misses the volume: colour 0, alpha 1, depth 0 (the gizmo's tiles are traced: sample by sample,
+//                                    as the plain kernel does — there is no volume to walk, only the gizmo's slab test)
+//   inside it, outside the live box's a missed sample's colour 0, alpha 1, and the depth of sample 0 — the far side of the volume —
+//                                    by the same float operations (shade_sample_with, MissTracer)
+__global__ void ca_live_rect(RenderParams P)
+{
+	if (threadIdx.x != 0u) return;
+	PixRect r;
+	const bool ok = live_box_pix_rect(P, r);
+	u32 *w = reinterpret_cast<u32 *>(P.counters + 4);
+	w[1] = r.x0 | (r.x1 << 16); // (targets are at most 16 384 pixels wide and high: ca3d_render)
+	w[2] = r.y0 | (r.y1 << 16);
+	w[0] = ok ? 1u : 2u;
+}
+
+__global__ __launch_bounds__(256) void ca_render_background(RenderParams P)
+{
+	const bool skip = !P.legacy && occ_skip_enabled(P);
+	const bool small = skip && live_box_small(P);
+	const u32 tx = blockIdx.x * 16u, ty = P.row0 + blockIdx.y * 16u;
+	const bool in_vol = tx >= P.rx0 && tx < P.rx1 && ty >= P.ry0 && ty < P.ry1;
+	const bool in_giz = tx >= P.gx0 && tx < P.gx1 && ty >= P.gy0 && ty < P.gy1;
+	bool far_side = false;
+	if (!small)
+	{
+		if (in_vol) return;
+	}
+	else
+	{
+		PixRect live_rect;
+		if (!live_rect_load(P, live_rect) || in_giz || in_pix_rect(live_rect, tx, ty)) return; // the spread kernel's tile
+		far_side = in_vol;
+	}
+	const u32 px = tx + (threadIdx.x & 15u), py = ty + (threadIdx.x >> 4);
+	if (px >= P.W || py >= P.row1) return;
+	float r = 0.0f, g = 0.0f, b = 0.0f, a = 1.0f, d0 = 0.0f;
+	if (in_giz)
+	{
+		r = g = b = a = 0.0f;
+		u32 pvis = 0, svis = 0;
+		for (u32 k = 0; k < P.spp; k++)
+		{
+			const float ox = P.spp == 1u ? 0.5f : ((k & 1u) ? 0.75f : 0.25f);
+			const float oy = P.spp == 1u ? 0.5f : ((k & 2u) ? 0.75f : 0.25f);
+			const float vu = ((float)px + ox) / (float)P.W, vv = 1.0f - ((float)py + oy) / (float)P.H;
+			const Sample s = shade_sample<false>(P, vu, vv, pvis, svis); // (outside the volume's rectangle: nothing to walk, nothing to skip)
+			r += s.r; g += s.g; b += s.b; a += s.a;
+			if (k == 0) d0 = s.depth;
+		}
+		const float inv = 1.0f / (float)P.spp;
+		r *= inv; g *= inv; b *= inv; a *= inv;
+	}
+	else if (far_side)
+	{
+		const float ox = P.spp == 1u ? 0.5f : 0.25f, oy = ox;
+		const float vu = ((float)px + ox) / (float)P.W, vv = 1.0f - ((float)py + oy) / (float)P.H;
+		MissTracer tr;
+		d0 = shade_sample_with(P, vu, vv, tr).depth;
+	}
+	const size_t i = (size_t)py * P.W + px;
+	if (P.light)
+	{
+		const __half2 rg = __floats2half2_rn(r, g), ba = __floats2half2_rn(b, 1.0f);
+		uint2 v;
+		v.x = *reinterpret_cast<const u32 *>(&rg);
+		v.y = *reinterpret_cast<const u32 *>(&ba);
+		P.light[i] = v;
+	}
+	if (P.depth)
+	{
+		const __half2 d = __floats2half2_rn(d0, 1.0f);
+		P.depth[i] = *reinterpret_cast<const u32 *>(&d);
+	}
+	if (P.presentation)
+	{
+		const float ig = 1.0f / P.u[U_GAMMA];
+		P.presentation[i] = unorm8(powf(r, ig)) | (unorm8(powf(g, ig)) << 8) | (unorm8(powf(b, ig)) << 16) | (unorm8(a) << 24);
+	}
+}
+
 // ================================================================================================ scheduled form
 // The same frame as ca_render_packed, bit for bit, with the rays of a wave scheduled dynamically. In the plain
 // kernel a lane walks its pixel's samples one after the other and the wave waits for its longest walk every time:
@@ -176,7 +270,7 @@ struct SampleCtx
 	__device__ __forceinline__ v3 ray() const { return V(get(kCtxRay), get(kCtxRay + 1), get(kCtxRay + 2)); }
 };
 
-__device__ __forceinline__ void walk_begin(const RenderParams &P, RayState &w, v3 start, v3 dir, float t0, float tmax)
+__device__ __forceinline__ void walk_begin(const RenderParams &P, RayState &w, v3 start, v3 dir, float t0, float tmax, bool clip)
 {
 	const int G = (int)P.G;
 	const float cs = 1.0f / (float)P.G;
@@ -202,6 +296,9 @@ __device__ __forceinline__ void walk_begin(const RenderParams &P, RayState &w, v
 	w.word = 0;
 	w.wkey = -1;
 	w.guard = 0;
+	// sparse-volume variant: the walk clipped to the live box (render_device.inc, live_box_clip — what walk() does); a ray that stays
+	// outside it ends at its first step, before it visits a cell
+	if (clip && P.live_box && !live_box_clip(P, start, dir, w.inv, t0, w.tmax, w.ix, w.iy, w.iz, w.t, w.tx, w.ty, w.tz)) w.tmax = -1.0f;
 }
 
 // One cell of `walk` above. 0: keep walking, 1: hit (tnear_out), 2: the ray left the volume / ran out of range.
@@ -351,7 +448,7 @@ __device__ bool sample_begin(const RenderParams &P, RayState &st, const SampleCt
 		const v3 exitp = cam + ray * tf;
 		if (cam_dist >= 0.0f) enter = cam + ray * tn;
 		const v3 seg = exitp - enter;
-		walk_begin(P, st, enter, norm3(seg), 0.0f, len3(seg));
+		walk_begin(P, st, enter, norm3(seg), 0.0f, len3(seg), skip_box);
 		if (skip_box && misses_live_box(P, cam, ray)) st.tmax = -1.0f; // the walk ends at its first step, before it visits a cell: no hit
 		ctx.set(kCtxRay, ray.x); ctx.set(kCtxRay + 1, ray.y); ctx.set(kCtxRay + 2, ray.z);
 		ctx.set(kCtxVu, vu);
@@ -364,7 +461,7 @@ __device__ bool sample_begin(const RenderParams &P, RayState &st, const SampleCt
 }
 
 // shade_sample between the primary walk and the shadow walk. true: complete (nothing to light at the end point).
-__device__ bool sample_after_primary(const RenderParams &P, RayState &st, const SampleCtx &ctx, bool hit, float tnear, Sample &s)
+__device__ bool sample_after_primary(const RenderParams &P, RayState &st, const SampleCtx &ctx, bool hit, float tnear, Sample &s, bool skip_box)
 {
 	const float *u = P.u;
 	const v3 ray = ctx.ray();
@@ -392,7 +489,7 @@ __device__ bool sample_after_primary(const RenderParams &P, RayState &st, const 
 		ray_cube(p, ldir, V(0.0f, 0.0f, 0.0f), half, vn, vf);
 		const v3 vexit = p + ldir * vf;
 		const v3 sseg = vexit - p;
-		walk_begin(P, st, p, norm3(sseg), 0.0025f, len3(sseg));
+		walk_begin(P, st, p, norm3(sseg), 0.0025f, len3(sseg), skip_box);
 		st.cx = cx; st.cy = cy; st.cz = cz; // (the shaded point is st.start from here on)
 		st.phase = 2;
 		return false;
@@ -604,7 +701,7 @@ __global__ __launch_bounds__(256, WPE) void ca_render_packed_sched(RenderParams 
 				{
 					Sample s;
 					bool done = true;
-					if (st.phase == 1) done = sample_after_primary(P, st, ctx, term == 1, tnear, s);
+					if (st.phase == 1) done = sample_after_primary(P, st, ctx, term == 1, tnear, s, SKIP);
 					else sample_after_shadow(P, st, ctx, term == 1, s);
 					if (done) complete(s);
 				}
@@ -1025,6 +1122,7 @@ hipError_t launch_render(const RenderLaunch &l, hipStream_t stream)
 	P.row0 = l.row0;
 	P.row1 = l.row1 ? l.row1 : l.H;
 	P.rx0 = P.rx1 = P.ry0 = P.ry1 = P.outside_only = 0;
+	P.bg = P.gx0 = P.gx1 = P.gy0 = P.gy1 = 0;
 	const dim3 grid((l.W + 15u) / 16u, (l.mode == 1 ? l.H + 15u : P.row1 - P.row0 + 15u) / 16u);
 	if (l.mode == 1)
 	{
@@ -1052,6 +1150,22 @@ hipError_t launch_render(const RenderLaunch &l, hipStream_t stream)
 		// tests the occupancy count before it touches the tile queue) — goes to a second stream when there is one: it then runs
 		// BESIDE the scheduled launch, which is persistent and ends in a tail with most CUs idle, and joins this stream before the
 		// frame is done. The kernels write disjoint pixels. The fork sits behind the counters' memset and the occupancy pass.
+		// Pixels nothing can be seen in are filled, not traced (ca_render_background) — unless the depth overlay colours them (:880-883),
+		// the volume is the legacy one, or the light gizmo's cube has a corner beside or behind the camera (no rectangle for it).
+		static const bool bg_off = getenv("CA3D_RENDER_BG") && atoi(getenv("CA3D_RENDER_BG")) == 0; // tuning / A-B: trace every pixel
+		if (!bg_off && !P.legacy && !(P.u[U_SHOWDEPTH] == 1.0f))
+		{
+			const double lo[3] = {(double)P.u[U_LIGHT] - 0.005, (double)P.u[U_LIGHT + 1] - 0.005, (double)P.u[U_LIGHT + 2] - 0.005};
+			const double hi[3] = {(double)P.u[U_LIGHT] + 0.005, (double)P.u[U_LIGHT + 1] + 0.005, (double)P.u[U_LIGHT + 2] + 0.005};
+			PixRect gr;
+			if (box_pix_rect(P.u, P.cot_half_fov, P.W, P.H, P.row0, P.row1, lo, hi, gr))
+			{
+				P.bg = 1u;
+				P.gx0 = gr.x0; P.gx1 = gr.x1; P.gy0 = gr.y0; P.gy1 = gr.y1;
+			}
+		}
+		// the live box's screen rectangle, once per frame, for the kernels that own or skip tiles by it (behind the occupancy pass, before the fork)
+		if (P.bg && P.occ && P.live_box) hipLaunchKernelGGL(ca_live_rect, dim3(1), dim3(64), 0, stream, P);
 		const bool beside = tiles && l.aux && l.ev_fork && l.ev_join;
 		hipStream_t side = beside ? l.aux : stream;
 		if (beside)
@@ -1094,7 +1208,8 @@ hipError_t launch_render(const RenderLaunch &l, hipStream_t stream)
 			if (e != hipSuccess) return e;
 		}
 		P.outside_only = tiles ? 1u : 0u;
-		if (around) hipLaunchKernelGGL(ca_render_packed<false>, grid, dim3(256), 0, side, P);
+		if (P.bg) hipLaunchKernelGGL(ca_render_background, grid, dim3(256), 0, side, P);
+		else if (around) hipLaunchKernelGGL(ca_render_packed<false>, grid, dim3(256), 0, side, P);
 		if (P.occ && P.live_box)
 		{
 			// a sparse volume with a small live box: its frame belongs to the spread kernel (a persistent launch: it costs a dense frame
@@ -1104,7 +1219,7 @@ hipError_t launch_render(const RenderLaunch &l, hipStream_t stream)
 			P.spread = 1u;
 			hipLaunchKernelGGL(ca_render_packed_spread<true>, dim3((u32)cus * 4u), dim3(256), 0, side, P);
 		}
-		if (P.occ && around) hipLaunchKernelGGL(ca_render_packed<true>, grid, dim3(256), 0, side, P);
+		if (P.occ && around && !P.bg) hipLaunchKernelGGL(ca_render_packed<true>, grid, dim3(256), 0, side, P);
 		if (beside)
 		{
 			hipError_t e = hipEventRecord(l.ev_join, l.aux);

@@ -85,7 +85,7 @@ def parse(argv=None):
                          "off by default (on for --config 5) so that the scaling run times the CA step alone")
     ap.add_argument("--render-size", default="")
     ap.add_argument("--render-spp", type=int, default=4)
-    ap.add_argument("--render-frames", type=int, default=10)
+    ap.add_argument("--render-frames", type=int, default=40)
     ap.add_argument("--overlap", choices=["auto", "on", "off"], default="",
                     help="N>1: run the halo exchange under the interior phase of each batch (auto: by slab size, see slab.py)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="gloo = rehearsal transport through host memory")
@@ -305,17 +305,40 @@ def render_leg(eng, G, a, size=None, sparse=True, literal=True):
     W, H = (int(v) for v in (size or a.render_size).lower().split("x"))
     cells = host.random_fill(host.words_per_buffer(G), seed=0xCA3D0001, and_rounds=4)
     eng.upload_state(cells)
+    # The CA legs run the engine on a torch stream (torch events bracket them). The render legs hand the engine its own stream back:
+    # frames are only put in flight side by side on a stream the engine owns (a caller's stream promises the caller in-order frames);
+    # the timed regions here end in torch.cuda.synchronize(), which waits for every stream of the device.
+    bench_stream = getattr(eng, "bench_stream", None)
+    eng.use_own_stream()
+    try:
+        return _render_leg_on_own_stream(eng, G, a, W, H, literal, sparse)
+    finally:
+        if bench_stream is not None:
+            eng.set_stream(bench_stream.cuda_stream)
+
+
+def _render_leg_on_own_stream(eng, G, a, W, H, literal, sparse):
+    from cellularautomatons3d_amd import host
+
+    # one frame at a time first (render_pipeline 0: what a frame costs from its first kernel to its last), then the engine's default — converged
+    # frames that stay on the device alternate between two streams, the next frame's walks fill the idle tail of this one's
+    eng.set_option("render_pipeline", 0)
+    dt1, st1 = time_frames(eng, host.uniform_block(W, H, host.orbit_camera()), W, H, a.render_spp, a.render_frames)
+    eng.set_option("render_pipeline", 1)
     dt, st = time_frames(eng, host.uniform_block(W, H, host.orbit_camera()), W, H, a.render_spp, a.render_frames)
     rays = st.primary_rays + st.shadow_rays
     dense = {"metric": f"Mray/s path-trace {'1080p' if H == 1080 else f'{W}x{H}'}", "value": round(rays * a.render_frames / dt / 1e6, 2), "unit": "Mray/s",
-             "ms_per_frame": round(dt * 1e3 / a.render_frames, 4), "kernel_ms": round(st.gpu_ms, 4),
+             "ms_per_frame": round(dt * 1e3 / a.render_frames, 4), "kernel_ms": round(st1.gpu_ms, 4),
+             "frames_in_flight": 2, "one_frame_at_a_time": {"ms_per_frame": round(dt1 * 1e3 / a.render_frames, 4), "value": round(rays * a.render_frames / dt1 / 1e6, 2),
+                                                            "note": "ca3d_set_option(render_pipeline, 0): a frame's kernels from first to last with nothing beside them; kernel_ms is this form's"},
              "primary_rays": int(st.primary_rays), "shadow_rays": int(st.shadow_rays),
              "cell_visits_per_primary_ray": round(st.primary_cell_visits / max(1, st.primary_rays), 2),
              "cell_visits_per_shadow_ray": round(st.shadow_cell_visits / max(1, st.shadow_rays), 2),
              "config": {"workload": f"{G}^3 packed volume, hashed fill density 2^-5, {W}x{H} @ {a.render_spp} spp, oblique pose "
-                                    "(0.6 rad about (1,1,0), distance 1.4), exact DDA walk + shadow ray + Cook-Torrance; ray-stream passes (render_stream.hip)"}}
+                                    "(0.6 rad about (1,1,0), distance 1.4), exact DDA walk + shadow ray + Cook-Torrance; ray-stream passes (render_stream.hip); "
+                                    "frames stay on the device, two in flight (the engine's default for converged frames without host pointers)"}}
     if H == 1080 and a.render_spp == 4:
-        pmc = render_pmc_record(st.gpu_ms)
+        pmc = render_pmc_record(st1.gpu_ms)
         if pmc:
             dense["pmc"] = pmc
     if literal:
@@ -346,12 +369,16 @@ def render_leg(eng, G, a, size=None, sparse=True, literal=True):
         # the reference UI's own start-up scene (SURVEY 8(d) "sparse"): the single seed evolved 30 steps, default pose
         eng.upload_state(host.initial_state(G))
         eng.step(30)
+        eng.set_option("render_pipeline", 0)
+        dts1, _ = time_frames(eng, host.uniform_block(W, H, host.camera_matrix()), W, H, a.render_spp, a.render_frames)
+        eng.set_option("render_pipeline", 1)
         dts, sts = time_frames(eng, host.uniform_block(W, H, host.camera_matrix()), W, H, a.render_spp, a.render_frames)
-        dense["sparse_scene"] = {"ms_per_frame": round(dts * 1e3 / a.render_frames, 4),
+        dense["sparse_scene"] = {"ms_per_frame": round(dts * 1e3 / a.render_frames, 4), "ms_per_frame_one_at_a_time": round(dts1 * 1e3 / a.render_frames, 4),
                                  "value": round((sts.primary_rays + sts.shadow_rays) * a.render_frames / dts / 1e6, 2), "unit": "Mray/s",
                                  "cell_visits_per_primary_ray": round(sts.primary_cell_visits / max(1, sts.primary_rays), 2),
                                  "workload": f"{G}^3, single seed after 30 default-rule steps, default pose, {W}x{H} @ {a.render_spp} spp, "
-                                             "empty-space skipping over two levels of occupancy blocks"}
+                                             "empty-space skipping over two levels of occupancy blocks, walks clipped to the live box, "
+                                             "pixels outside the live box's screen rectangle filled (ca_render_background)"}
     return dense
 
 

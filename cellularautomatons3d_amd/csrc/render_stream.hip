@@ -1203,7 +1203,7 @@ __global__ __launch_bounds__(kW2Threads, kW2PerSimd) void ca_stream_walk2(Stream
 		}
 		const bool refillable = more || idcount != 0u || qavail != 0u;
 		const int leave_at = __builtin_amdgcn_readfirstlane(refillable ? 64 - pop_at : 0);
-		if (S.tail_batch && !refillable)
+		if (S.tail_batch == 2 || (S.tail_batch && !refillable))
 		{
 			// nothing left to refill from: few waves are left on the chip, their rays are the long ones and lie
 			// all over the volume — an iteration is one memory round trip that nothing hides. Four cells per round trip (walk_batch).
@@ -1230,20 +1230,40 @@ __global__ __launch_bounds__(kW2Threads, kW2PerSimd) void ca_stream_walk2(Stream
 			// loop body's exec mask and the count the loop ends on)
 			// A lane that finds its hit advances like the others (its walk state is not needed again; the hit cell is kept in hpos): the
 			// body has ONE nested exec region, the live cells' filter, instead of a second one around the advance.
+			// The NEXT cell's word is asked for before this cell is looked at: which cell comes next depends on the boundary times only, so
+			// the advance is split — axis, next position, read issued; then this cell's bit and, rarely, its filter (on the boundary times
+			// of THIS cell, not yet touched); then the times are moved on. A wave's pass through the loop was read -> ~800 cycles -> 45
+			// instructions (per-wave trace: 857 cycles a pass, five waves to a SIMD: 171 cycles per pass and SIMD against ~105 of pure
+			// issue); now the read of cell k + 1 is in flight while cell k is tested and the other four waves issue.
 			int st = (job >= 0 && term == 0) ? 0 : 3;
+			const char *vol = reinterpret_cast<const char *>(S.volume);
+			u32 cur = 0u;
+			if (st == 0) cur = *reinterpret_cast<const u32 *>(vol + ((w.pos >> 3) & ~3u));
 			do
 			{
 				visits += (u32)walking;
 				if (st == 0)
 				{
-					const u32 cur = *reinterpret_cast<const u32 *>(reinterpret_cast<const char *>(S.volume) + ((w.pos >> 3) & ~3u));
+					const float tmin = fminf(fminf(w.tx, w.ty), w.tz);
+					const bool mx = w.tx == tmin, my = !mx && w.ty == tmin, mz = !mx && !my;
+					const u32 gmx = pg.mx, gmy = pg.my, gmz = pg.mz;
+					const u32 m = mx ? gmx : (my ? gmy : gmz);
+					const bool leaving = ((w.pos ^ w.edge) & m) == 0u; // the moving axis stands on the last cell inside the grid
+					const u32 q = (w.pos | ~m) + (m & w.neg);
+					const u32 npos = (q & m) | (w.pos & ~m); // (a lane that leaves wraps to the far side of the grid: a valid address, never used)
+					const u32 nxt = *reinterpret_cast<const u32 *>(vol + ((npos >> 3) & ~3u));
 					bool hit = false;
 					if (__builtin_amdgcn_ubfe(cur, w.pos, 1u) != 0u) // (the shift takes bits 0-4 of pos: the bit in the word)
 					{
 						if (walk_hit_test_p<SHADOW, CHECK>(S, pg, w, vhalf, k0, k1, eps_a, ctx, stride)) { hit = true; hpos = w.pos; }
 					}
-					const bool over = walk_advance_p(pg, w);
-					st = hit ? 1 : (over ? 2 : 0);
+					w.t = tmin;
+					w.tx += mx ? w.dx : 0.0f;
+					w.ty += my ? w.dy : 0.0f;
+					w.tz += mz ? w.dz : 0.0f;
+					w.pos = npos;
+					cur = nxt;
+					st = hit ? 1 : ((leaving || tmin >= w.tmax) ? 2 : 0);
 				}
 				walking = __builtin_popcountll(__builtin_amdgcn_ballot_w64(st == 0));
 			} while (walking > leave_at);
@@ -1459,7 +1479,7 @@ hipError_t launch_render_stream(const void *params, void *scratch, uint32_t W, u
 		static const int pop_env = getenv("CA3D_STREAM_POP") ? atoi(getenv("CA3D_STREAM_POP")) : 0;
 		S.refill2 = pop_env >= 1 && pop_env <= 64 ? pop_env : 16;
 		static const int tb_env = getenv("CA3D_STREAM_TAIL_BATCH") ? atoi(getenv("CA3D_STREAM_TAIL_BATCH")) : 1;
-		S.tail_batch = tb_env ? 1 : 0;
+		S.tail_batch = tb_env == 2 ? 2 : (tb_env ? 1 : 0); // (2, tuning: the batched loop from the first cell on)
 		const u32 wgs2 = min(S.chunks, (u32)cus * (u32)kW2PerSimd * 4u / (u32)kW2Waves);
 		const bool form2 = form_env == 2 && per >= 128u && bricks_env == 1; // (a chunk holds at least 64 tickets of two jobs)
 		if (form2) trace_waves = (unsigned long long)wgs2 * (unsigned)kW2Waves;

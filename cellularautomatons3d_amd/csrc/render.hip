@@ -227,7 +227,9 @@ __global__ __launch_bounds__(256) void ca_render_background(RenderParams P)
 	if (P.presentation)
 	{
 		const float ig = 1.0f / P.u[U_GAMMA];
-		P.presentation[i] = unorm8(powf(r, ig)) | (unorm8(powf(g, ig)) << 8) | (unorm8(powf(b, ig)) << 16) | (unorm8(a) << 24);
+		// (pow(+0, y) is +0 for every y > 0: the three powf of a black pixel — 300 of this kernel's 375 instructions — are skipped)
+		if (r == 0.0f && g == 0.0f && b == 0.0f && ig > 0.0f) P.presentation[i] = unorm8(a) << 24;
+		else P.presentation[i] = unorm8(powf(r, ig)) | (unorm8(powf(g, ig)) << 8) | (unorm8(powf(b, ig)) << 16) | (unorm8(a) << 24);
 	}
 }
 

@@ -72,7 +72,10 @@ __global__ __launch_bounds__(256) void ca_brick_volume(const u32 *__restrict__ c
 }
 
 // the same for any G that is a multiple of 32 (rows of C = G / 32 words, G / 8 bricks per edge)
-__global__ __launch_bounds__(256) void ca_brick_volume_any(const u32 *__restrict__ cells, u32 *__restrict__ bricks, u32 G)
+// Bricks per edge are padded to a power of two in the ADDRESS (brick (bx, by, bz) at ((bz << lnbp) + by << lnbp) + bx, lnbp = ceil log2 (G / 8)):
+// the brick index is then shifts and the stream walks carry a cell as one packed word (render_stream.hip, kBricksPacked) on these grids
+// too. The padding is address space, never written and never read for a cell of the grid (992^3: 128^3 instead of 124^3 bricks).
+__global__ __launch_bounds__(256) void ca_brick_volume_any(const u32 *__restrict__ cells, u32 *__restrict__ bricks, u32 G, u32 lnbp)
 {
 	__shared__ u32 src[64u * kBrickMaxC]; // [z & 7][y & 7][word]
 	const u32 C = G >> 5, nb = G >> 3;
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(256) void ca_brick_volume_any(const u32 *__restrict
 		src[i] = cells[xw + ((size_t)((bz << 3) + (r >> 3)) * G + ((by << 3) + (r & 7u))) * C];
 	}
 	__syncthreads();
-	uint4 *dst = reinterpret_cast<uint4 *>(bricks + (size_t)blockIdx.x * nb * 16u);
+	uint4 *dst = reinterpret_cast<uint4 *>(bricks + ((size_t)((bz << lnbp) + by) << (lnbp + 4u)));
 	const u32 quads = nb * 4u;
 	for (u32 q = threadIdx.x; q < quads; q += 256u)
 	{
@@ -108,7 +111,7 @@ template <bool P2>
 struct BrickVolume
 {
 	const u32 *bricks;
-	u32 lg; // log2 G (P2)
+	u32 lg; // log2 G (P2); (!P2) bits of a brick coordinate in the address, ceil log2 (G / 8)
 	u32 G;  // (!P2)
 	// word index and bit of cell (x, y, z), every coordinate modulo the grid (:268-290)
 	__device__ __forceinline__ u32 word_of(u32 x, u32 y, u32 z, u32 &bit) const
@@ -123,9 +126,8 @@ struct BrickVolume
 		if (__builtin_expect(x >= G, 0)) x %= G;
 		if (__builtin_expect(y >= G, 0)) y %= G;
 		if (__builtin_expect(z >= G, 0)) z %= G;
-		const u32 nb = G >> 3; // <= 256: the products below stay under 2^24
 		bit = (x & 7u) | ((y & 3u) << 3);
-		return ((__umul24(__umul24(z >> 3, nb) + (y >> 3), nb) + (x >> 3)) << 4) + ((z & 7u) << 1) + ((y & 7u) >> 2);
+		return ((((((z >> 3) << lg) + (y >> 3)) << lg) + (x >> 3)) << 4) + ((z & 7u) << 1) + ((y & 7u) >> 2);
 	}
 	__device__ __forceinline__ u32 state(u32 x, u32 y, u32 z) const
 	{
@@ -393,7 +395,13 @@ __global__ __launch_bounds__(256, 4) void ca_render_frame_bricks(FrameBricks B)
 
 } // namespace
 
-size_t frame_bricks_bytes(uint32_t G) { return (size_t)G * G * G / 8u; }
+static u32 brick_bits(uint32_t G) // bits of a brick coordinate in the address
+{
+	u32 l = 0;
+	while ((1u << l) < (G >> 3)) l++;
+	return l;
+}
+size_t frame_bricks_bytes(uint32_t G) { return (size_t)64u << (3u * brick_bits(G)); } // (a power-of-two grid: G^3 / 8)
 
 bool frame_bricks_applies(uint32_t G) { return G >= 32u && G <= 2048u && (G & 31u) == 0u; } // (ca_brick_volume stages rows of up to 64 words)
 
@@ -407,7 +415,7 @@ hipError_t launch_brick_volume(const uint32_t *cells, uint32_t *bricks, uint32_t
 		while ((1u << lg) < G) lg++;
 		hipLaunchKernelGGL(ca_brick_volume, dim3(nb * nb), dim3(256), 0, stream, cells, bricks, lg);
 	}
-	else hipLaunchKernelGGL(ca_brick_volume_any, dim3(nb * nb), dim3(256), 0, stream, cells, bricks, G);
+	else hipLaunchKernelGGL(ca_brick_volume_any, dim3(nb * nb), dim3(256), 0, stream, cells, bricks, G, brick_bits(G));
 	return hipGetLastError();
 }
 
@@ -420,6 +428,7 @@ hipError_t launch_render_frame_bricks(const void *frame_params, uint32_t *bricks
 	B.bricks = bricks;
 	B.lg = 0;
 	while ((1u << B.lg) < P.G) B.lg++;
+	if ((P.G & (P.G - 1u)) != 0u) B.lg = brick_bits(P.G); // (BrickVolume<false> reads it as the bits of a brick coordinate)
 	if (!bricks_valid)
 	{
 		hipError_t eb = launch_brick_volume(P.cells, bricks, P.G, stream);

@@ -169,8 +169,8 @@ struct Walker
 // kBricksRead: bricks, and the walker reads its cell's word at every cell instead of keeping the last word in a register (no key to
 // compare, no branch around the read; the default). Measured on top of each other (1080p / 4K, 4 samples, ms per frame): rows 0.88 /
 // 2.32, bricks 0.80 / 1.98, bricks + a read per cell 0.785 / 1.94; a whole 8 x 8 z-slice per lane in two registers 0.805 / 2.11.
-// kBricksReadAny: the same over the bricks of a grid that is not a power of two (96, 160, ..., 992): G / 8 bricks per edge, the brick index by
-// two 24-bit multiply-adds (full rate) instead of shifts.
+// kBricksReadAny: the same over the bricks of a grid that is not a power of two (96, 160, ..., 992): G / 8 bricks per edge, padded to a power
+// of two in the address (render_frame.hip, ca_brick_volume_any), so the brick index is shifts there too.
 // kProbe*: timing probes of the stepping loop (CA3D_STREAM_PROBE=1..4; the frame is garbage: no cell is ever taken for live, every walk runs to
 // the end of the volume, so the four differ ONLY in what the read costs): no read at all / every lane reads word 0 (one cache line per
 // wave-level read) / word key & 1023 (a 4 KiB footprint, as many lines per read as the real walk) / the real word.
@@ -181,7 +181,7 @@ __device__ __forceinline__ int word_key(const StreamParams &S, int ix, int iy, i
 {
 	if (LAYOUT == kBricksReadAny)
 	{
-		const u32 b = __umul24(__umul24((u32)iz >> 3, S.nb) + ((u32)iy >> 3), S.nb) + ((u32)ix >> 3); // nb <= 256: under 2^24
+		const u32 b = (((((u32)iz >> 3) << S.lnbp) + ((u32)iy >> 3)) << S.lnbp) + ((u32)ix >> 3); // (bricks per edge padded to a power of two in the address)
 		return (int)((b << 4) + (((u32)iz & 7u) << 1) + (((u32)iy & 7u) >> 2));
 	}
 	if (LAYOUT == kBricks || LAYOUT == kBricksRead || LAYOUT >= kProbeNone)
@@ -1493,7 +1493,7 @@ hipError_t launch_render_stream(const void *params, void *scratch, uint32_t W, u
 			else if (probe_env == 3) launch_walks<kProbeSmall, false>(S, wgs, job_blocks, stream);
 			else launch_walks<kProbeFull, false>(S, wgs, job_blocks, stream);
 		}
-		else if (form2 && p2 && packed_env && P.G <= 1024u && (unsigned long long)S.chunks * per < (1ull << 28)) { if (check) launch_walks2<kBricksPacked, true>(S, wgs2, job_blocks, stream); else launch_walks2<kBricksPacked, false>(S, wgs2, job_blocks, stream); }
+		else if (form2 && packed_env && P.G <= 1024u && (unsigned long long)S.chunks * per < (1ull << 28)) { if (check) launch_walks2<kBricksPacked, true>(S, wgs2, job_blocks, stream); else launch_walks2<kBricksPacked, false>(S, wgs2, job_blocks, stream); }
 		else if (form2 && !p2) { if (check) launch_walks2<kBricksReadAny, true>(S, wgs2, job_blocks, stream); else launch_walks2<kBricksReadAny, false>(S, wgs2, job_blocks, stream); }
 		else if (form2) { if (check) launch_walks2<kBricksRead, true>(S, wgs2, job_blocks, stream); else launch_walks2<kBricksRead, false>(S, wgs2, job_blocks, stream); }
 		else if (!p2) { if (check) launch_walks<kBricksReadAny, true>(S, wgs, job_blocks, stream); else launch_walks<kBricksReadAny, false>(S, wgs, job_blocks, stream); }

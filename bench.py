@@ -395,7 +395,7 @@ def interactive_leg(eng, G, a, frames=200):
     vm = host.orbit_camera()
     eng.set_option("queue", 0)
     eng.set_render_mode(True)
-    out = {"frames": frames, "size": f"{W}x{H}", "per_frame": "ca3d_step(1) + ca3d_render(render_mode 1, 1 sample per pixel), one submission per frame, no read-back",
+    out = {"frames": frames, "passes": "best of 3", "size": f"{W}x{H}", "per_frame": "ca3d_step(1) + ca3d_render(render_mode 1, 1 sample per pixel), one submission per frame, no read-back",
            "reference_loop": "main_pathtraced.js:1821-1854 (_computePass + _renderPass per requestAnimationFrame)"}
     try:
         for name, start in (("startup_scene", None), ("dense_scene", host.random_fill(host.words_per_buffer(G), seed=0xCA3D0001, and_rounds=4))):
@@ -410,12 +410,14 @@ def interactive_leg(eng, G, a, frames=200):
                 eng.render(host.uniform_block(W, H, vm, elapsed_time=0.3 + 0.016 * i, prev_view_mat=vm), W, H, 1, readback=False)
             torch.cuda.synchronize()
             us = [host.uniform_block(W, H, vm, elapsed_time=0.5 + 0.016 * i, prev_view_mat=vm) for i in range(frames)]  # the host's uniform upload, prepared
-            t0 = time.perf_counter()
-            for i in range(frames):
-                eng.step(1)
-                eng.render(us[i], W, H, 1, readback=False)
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
+            dt = 1e30
+            for _ in range(3):  # the best of three passes of `frames` frames: a pass is ~25 ms of wall clock, one host hiccup doubles it
+                t0 = time.perf_counter()
+                for i in range(frames):
+                    eng.step(1)
+                    eng.render(us[i], W, H, 1, readback=False)
+                torch.cuda.synchronize()
+                dt = min(dt, time.perf_counter() - t0)
             gpu_ms = eng.render_stats().gpu_ms
             eng.set_option("resident", 0)  # (ca3d_get_info names the kernel the rules select for LONG batches; a one-step submission is below
             step_kernel = eng.info().kernel_name.decode()  # resident_min = 8 and takes the per-step kernel: the name with the resident form off)
@@ -433,12 +435,14 @@ def interactive_leg(eng, G, a, frames=200):
                     eng.step(1)
                     eng.render(usm[i], W, H, 1, readback=False)
                 torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for i in range(frames):
-                    eng.step(1)
-                    eng.render(usm[i], W, H, 1, readback=False)
-                torch.cuda.synchronize()
-                dtm = time.perf_counter() - t0
+                dtm = 1e30
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    for i in range(frames):
+                        eng.step(1)
+                        eng.render(usm[i], W, H, 1, readback=False)
+                    torch.cuda.synchronize()
+                    dtm = min(dtm, time.perf_counter() - t0)
                 out[name + "_moving_camera"] = {"ms_per_frame": round(dtm * 1e3 / frames, 4), "frames_per_second": round(frames / dtm, 1),
                                                 "last_render_kernel_ms": round(eng.render_stats().gpu_ms, 4),
                                                 "camera": "orbit, 0.01 rad per frame; prevViewMat / prevProjViewMatInv = the previous frame's"}

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Compile one of the run-time (hiprtc) kernel programs exactly as ca_jit.cpp does — no GPU needed — and print per
 entry point: VGPR / SGPR counts and the instruction mix. Usage:
-  tools/jit_disasm.py roll --cvl 2 [--rule clustered] [--dump DIR]      (also: class, vn)"""
+  tools/jit_disasm.py roll --cvl 2 [--rule clustered] [--dump DIR]      (also: rollnp2 --cv 5, class, rclass)"""
 import argparse
 import collections
 import os
@@ -18,8 +18,9 @@ TABLES = {"clustered": (2, "true", "true", (0x000000F0, 0x000000E0, 0x0038, 0x00
           "moore": (2, "false", "false", (0x000000F0, 0x000000E0, 0, 0, 0, 0))}
 
 ap = argparse.ArgumentParser()
-ap.add_argument("program", choices=["roll", "class", "rclass"])
+ap.add_argument("program", choices=["roll", "rollnp2", "class", "rclass"])
 ap.add_argument("--cvl", type=int, default=2)
+ap.add_argument("--cv", type=int, default=5, help="rollnp2: uint4 per row (3, 5, 6, 7)")
 ap.add_argument("--rule", default="clustered")
 ap.add_argument("--dump", default="")
 ap.add_argument("--extra", default="")
@@ -31,6 +32,8 @@ defines += [b"-DCA3D_JIT_%s=%du" % (n, t) for n, t in zip([b"TS0", b"TB0", b"TS1
 defines += [x.encode() for x in a.extra.split()]
 if a.program == "roll":
     code = T._compile(T._hiprtc(), T.ROLL_PROGRAM, b"ca3d_jit_roll.hip", defines + [b"-DCA3D_JIT_CVL=%d" % a.cvl], *([T.CLUSTERED_RULE_FN] if a.rule == "clustered" and a.synth else []))
+elif a.program == "rollnp2":
+    code = T._compile(T._hiprtc(), T.ROLL_PROGRAM, b"ca3d_jit_roll_np2.hip", defines + [b"-DCA3D_JIT_CV_NP2=%d" % a.cv], *([T.CLUSTERED_RULE_FN] if a.rule == "clustered" and a.synth else []))
 elif a.program == "rclass":
     code = T._compile(T._hiprtc(), T.RESIDENT_CLASS_PROGRAM, b"ca3d_jit_resident_class.hip", defines, *([T.CLUSTERED_RULE_FN] if a.rule == "clustered" and a.synth else []))
 else:

@@ -381,7 +381,18 @@ int ca3d_get_render_stats(ca3d_t *h, ca3d_render_stats *out);
  * scheduling inside each wave of the renderer (on by default; the frame is the same bit for bit);
  * "render_reset_history"; "render_indirect" 0/1 adds the one-bounce neighbour lighting of calculateIndirectLighting
  * (pathtraced_fragment_clustered.wgsl:307-377 — present in the reference, its call commented out at :424; off by
- * default like there; converged-frame mode, packed layout). */
+ * default like there; converged-frame mode, packed layout); "render_stream" 0/1 the converged frame of a dense packed volume as
+ * ray-stream passes (render_stream.hip; on by default; 0: the in-wave scheduled kernel; the same frame bit for bit);
+ * "render_stream_check" 0/1 diagnostics: the stream passes count where their interval filter and the slab test disagree and which
+ * answers were looked up unset — ca3d_render fails with CA3D_ERR_DEVICE if any (off by default; takes the frame off the pipeline);
+ * "render_pipeline" 0/1 two converged frames in flight (on by default): frames that stay on the device (no host pointers), are drawn
+ * by the stream passes and go down the engine's OWN stream alternate between two internal streams, so that one frame's walks fill the
+ * idle tail of the other's; the engine's stream waits for them at the next call that touches the state, a render target
+ * (ca3d_render_target, ca3d_get_render_stats) or the stream. Each frame is the frame of one-at-a-time rendering, bit for bit; a
+ * caller on a stream of its own (ca3d_set_stream), a frame with host pointers, a band or a literal frame is never pipelined;
+ * "render_frame_bricks" 0/1 the literal frame as a batched march over the bricked volume (on by default; 0: the statement-by-
+ * statement form, the same frame bit for bit); "rows" 0/1 the run-time compiled rows kernel on grids that are not a power of two (on by
+ * default; 0: the kernels that served them before — tests, tuning). */
 int ca3d_set_option(ca3d_t *h, const char *name, int64_t value);
 
 #ifdef __cplusplus

@@ -77,3 +77,17 @@ def test_product_does_not_reference_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h", ".js", ".c", "Makefile")):
                 txt = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "libca3d_oracle" not in txt and "oracle_lib" not in txt and "ca3d_oracle_" not in txt, f
+
+
+def test_every_option_is_documented_in_the_header():
+    """ca3d_set_option / ca3d_group_set_option names are strings, not symbols: every name the engine compares against appears (quoted) in
+    include/ca3d.h, so a host author finds it there and not only in the source."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "ca3d.h")).read()
+    for src in ("ca3d_api.cpp", "ca3d_group.cpp"):
+        text = open(os.path.join(root, "cellularautomatons3d_amd", "csrc", src)).read()
+        names = set(re.findall(r'strcmp\(name, "([a-z_0-9]+)"\)', text))
+        assert names, src
+        missing = sorted(n for n in names if f'"{n}"' not in header)
+        assert not missing, f"{src}: options not documented in include/ca3d.h: {missing}"

@@ -121,6 +121,7 @@ SYMBOLS = [
     ("ca3d_get_stats", C.c_int, [_H, C.POINTER(Stats)]),
     ("ca3d_set_option", C.c_int, [_H, C.c_char_p, C.c_int64]),
     ("ca3d_render", C.c_int, [_H, C.POINTER(C.c_float), C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("ca3d_get_render_pipeline", C.c_int, [_H, C.POINTER(C.c_int32)]),
     ("ca3d_get_render_stats", C.c_int, [_H, C.POINTER(RenderStats)]),
 ]
 

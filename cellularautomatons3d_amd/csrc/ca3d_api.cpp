@@ -226,14 +226,15 @@ struct ca3d_engine
 	hipEvent_t r_fork = nullptr, r_join = nullptr;
 	bool rev_valid = false;
 	ca3d_render_stats rstats{};
-	// Two converged frames in flight (option "render_pipeline", default 1). A frame's two persistent walk launches each end in a tail with
+	// Converged frames in flight (option "render_pipeline", default 1: three of them). A frame's two persistent walk launches each end in a tail with
 	// most of the chip idle (render_stream.hip: a third to a half of a 1080p launch) and its passes depend on each other — but not on
 	// the frame before: a converged frame has no history. Frames that stay on the device (no host pointers) and are drawn by the stream
-	// passes alternate between two LANES — a stream, a side stream, scratch, counters and events each — so that the next frame's walks
+	// passes alternate between LANES — a stream, scratch, counters and events each — so that the next frames' walks
 	// fill the tails of this one's. A lane waits for the engine's stream at the moment of the call (steps, uploads before the frame);
 	// the engine's stream waits for the lanes LAZILY: the next call that touches the state, a target or the stream joins them
 	// (bind_device). The presentation surface is shared: a frame's pixel-writing kernels wait for the frame before (RenderLaunch::after).
 	// Only on the engine's own stream: a caller who set a stream of their own expects every frame ordered on it.
+	static constexpr int kMaxLanes = 4;
 	struct FrameLane
 	{
 		hipStream_t s = nullptr;
@@ -244,12 +245,14 @@ struct ca3d_engine
 		unsigned long long *counters = nullptr;
 		bool pending = false; // frames on this lane the engine's stream has not been made to wait for
 		bool used = false;    // `done` has been recorded at least once
-	} lanes[2];
+	} lanes[kMaxLanes];
+	int n_lanes = 0; // lanes created (streams on pairwise different hardware queues); 0: not tried yet
 	hipEvent_t ev_state = nullptr; // "everything the engine's stream held when the frame was asked for"
 	bool main_touched = true;      // an entry point other than a pipelined ca3d_render has run since ev_state was recorded (bind_device)
 	std::vector<hipStream_t> lane_spares; // streams that turned out to share a hardware queue with lane 0 (kept: destroying one hands its queue to the next)
-	int render_pipeline = 1;
+	int render_pipeline = 1; // 0: off; 1: the default depth (kDefaultLanes frames in flight); 2 .. kMaxLanes: that many
 	int lane_next = 0;
+	bool lanes_exhausted = false; // the probe found fewer side-by-side streams than asked for
 	int last_lane = -1; // the lane of the last frame (-1: it went down the engine's stream) — whose events and counters ca3d_get_render_stats reads
 
 	size_t buffer_words() const { return plane_words * nplanes; }
@@ -319,6 +322,15 @@ void free_buffers(ca3d_engine *h)
 }
 
 // the engine's stream waits for the frames in flight on the lanes (nothing is waited for on the host)
+// Converged frames in flight when option render_pipeline is 1: three. Measured on the bench's dense 512^3 scene (ms per frame, 0 / 2 / 3 / 4
+// lanes): 1080p 4 spp 0.627 / 0.505 / 0.481 / 0.484, 1080p 1 spp 0.444 / 0.278 / 0.240 / 0.237, 3840 x 2160 1.539 / 1.396 / 1.390 / 1.392.
+// CA3D_RENDER_LANES=2..4 (tuning) moves the default.
+int render_default_lanes()
+{
+	static const int env = getenv("CA3D_RENDER_LANES") ? atoi(getenv("CA3D_RENDER_LANES")) : 0;
+	return env >= 2 && env <= ca3d_engine::kMaxLanes ? env : 3;
+}
+
 int join_frames(ca3d_engine *h)
 {
 	for (auto &L : h->lanes)
@@ -334,7 +346,9 @@ int bind_device(ca3d_engine *h, bool join = true)
 {
 	HIP_TRY(hipSetDevice(h->device));
 	if (join) h->main_touched = true; // (whatever the caller is about to put on the engine's stream: the next pipelined frame waits for it)
-	if (join && (h->lanes[0].pending || h->lanes[1].pending)) return join_frames(h);
+	if (join)
+		for (auto &L : h->lanes)
+			if (L.pending) return join_frames(h);
 	return CA3D_OK;
 }
 
@@ -1814,7 +1828,7 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 	if (width == 0 || height == 0 || width > 16384u || height > 16384u) return fail(CA3D_ERR_INVALID_ARGUMENT, "bad target size %ux%u", width, height);
 	if (spp != 1 && spp != 4) return fail(CA3D_ERR_INVALID_ARGUMENT, "spp must be 1 or 4");
 	if (h->render_mode == 1 && spp != 1) return fail(CA3D_ERR_INVALID_ARGUMENT, "the literal frame mode takes one jittered sample per pixel (spp = 1)");
-	// two frames in flight (FrameLane): converged frames of a packed volume that stay on the device and go down the stream passes
+	// frames in flight (FrameLane): converged frames of a packed volume that stay on the device and go down the stream passes
 	static const char *trace_path = getenv("CA3D_RENDER_TRACE");
 	static const bool aux_off = getenv("CA3D_RENDER_AUX") && atoi(getenv("CA3D_RENDER_AUX")) == 0; // tuning: everything on one stream
 	const bool pipelined = h->render_pipeline && h->render_mode == 0 && !presentation_rgba8 && !light_rgba16f && !depth_rg16f && h->stream == h->own_stream &&
@@ -1861,25 +1875,31 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 	ca3d_engine::FrameLane *L = nullptr;
 	hipStream_t rs = h->stream;
 	unsigned long long *counters = h->r_counters;
-	if (pipelined && !h->lanes[1].s)
+	const int kDefaultLanes = render_default_lanes();
+	const int want_lanes = h->render_pipeline >= 2 ? (h->render_pipeline < ca3d_engine::kMaxLanes ? h->render_pipeline : ca3d_engine::kMaxLanes) : kDefaultLanes;
+	if (pipelined && h->n_lanes < want_lanes && h->n_lanes >= 0 && !h->lanes_exhausted)
 	{
-		// first pipelined frame: the lanes. Two streams that the runtime has put on DIFFERENT hardware queues (probed: ca_diag.hip) — two
-		// streams on one queue run in order and the second frame would only queue up behind the first. No such pair: no pipeline.
-		ca3d_engine::FrameLane &A = h->lanes[0], &B = h->lanes[1];
-		if (!A.s) HIP_TRY(hipStreamCreateWithFlags(&A.s, hipStreamNonBlocking));
-		hipStream_t cand = nullptr;
-		for (int tries = 0; tries < 6 && !B.s; tries++)
+		// the lanes: streams that the runtime has put on pairwise DIFFERENT hardware queues (probed: ca_diag.hip) — two streams on one queue
+		// run in order and a frame would only queue up behind the other. Fewer than two such streams: no pipeline.
+		for (auto &fl : h->lanes)
+			if (fl.s && fl.pending) HIP_TRY(hipStreamSynchronize(fl.s)); // (the probe needs idle streams)
+		if (!h->lanes[0].s) { HIP_TRY(hipStreamCreateWithFlags(&h->lanes[0].s, hipStreamNonBlocking)); h->n_lanes = 1; }
+		for (int tries = 0; tries < 10 && h->n_lanes < want_lanes; tries++)
 		{
+			hipStream_t cand = nullptr;
 			HIP_TRY(hipStreamCreateWithFlags(&cand, hipStreamNonBlocking));
-			bool side_by_side = false;
-			HIP_TRY(streams_concurrent(A.s, cand, &side_by_side));
-			if (side_by_side) B.s = cand;
+			bool side_by_side = true;
+			for (int i = 0; i < h->n_lanes && side_by_side; i++) HIP_TRY(streams_concurrent(h->lanes[i].s, cand, &side_by_side));
+			if (side_by_side) h->lanes[h->n_lanes++].s = cand;
 			else h->lane_spares.push_back(cand);
 		}
-		if (!B.s) h->render_pipeline = 0;
+		if (h->n_lanes < want_lanes) h->lanes_exhausted = true; // the runtime has no more queues to give: do not probe again on every frame
+		if (h->n_lanes < 2) h->render_pipeline = 0;
 		else
-			for (auto &fl : h->lanes)
+			for (int i = 0; i < h->n_lanes; i++)
 			{
+				ca3d_engine::FrameLane &fl = h->lanes[i];
+				if (fl.done) continue;
 				HIP_TRY(hipEventCreateWithFlags(&fl.done, hipEventDisableTiming));
 				HIP_TRY(hipEventCreate(&fl.start));
 				HIP_TRY(hipEventCreate(&fl.stop));
@@ -1887,8 +1907,10 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 			}
 		if (!h->ev_state) HIP_TRY(hipEventCreateWithFlags(&h->ev_state, hipEventDisableTiming));
 	}
-	if (pipelined && h->render_pipeline)
+	const int active_lanes = h->n_lanes < want_lanes ? h->n_lanes : want_lanes;
+	if (pipelined && h->render_pipeline && active_lanes >= 2)
 	{
+		if (h->lane_next >= active_lanes) h->lane_next = 0;
 		L = &h->lanes[h->lane_next];
 		if (h->main_touched)
 		{
@@ -1896,7 +1918,7 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 			// record (a marker behind another lane's frames on a shared hardware queue would make this frame wait for them)
 			HIP_TRY(hipEventRecord(h->ev_state, h->stream));
 			h->main_touched = false;
-			h->lanes[0].need_state = h->lanes[1].need_state = true;
+			for (auto &fl : h->lanes) fl.need_state = true;
 		}
 		if (L->need_state)
 		{
@@ -2007,14 +2029,13 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 	}
 	if (L)
 	{
-		ca3d_engine::FrameLane &other = h->lanes[h->lane_next ^ 1];
-		if (other.used)
-		{
-			l.after = other.done; // the presentation surface is shared: this frame's pixels after the other lane's
-			// the occupancy bits and the bricks are shared too: a frame that rebuilds them waits for the one that may still be reading them
-			const bool occ_rebuild = l.occ && !l.occ_valid, bricks_rebuild = l.bricks && !l.bricks_valid;
-			if (occ_rebuild || bricks_rebuild) HIP_TRY(hipStreamWaitEvent(rs, other.done, 0));
-		}
+		// the presentation surface is shared: this frame's pixels after those of the frame before it (which waited for the one before that)
+		if (h->last_lane >= 0 && h->last_lane != h->lane_next && h->lanes[h->last_lane].used) l.after = h->lanes[h->last_lane].done;
+		// the occupancy bits and the bricks are shared too: a frame that rebuilds them waits for the frames that may still be reading them
+		const bool occ_rebuild = l.occ && !l.occ_valid, bricks_rebuild = l.bricks && !l.bricks_valid;
+		if (occ_rebuild || bricks_rebuild)
+			for (auto &fl : h->lanes)
+				if (&fl != L && fl.used) HIP_TRY(hipStreamWaitEvent(rs, fl.done, 0));
 	}
 	HIP_TRY(hipEventRecord(L ? L->start : h->rev_start, rs));
 	hipError_t e = launch_render(l, rs);
@@ -2033,7 +2054,7 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 	{
 		HIP_TRY(hipEventRecord(L->done, rs));
 		L->pending = L->used = true;
-		h->lane_next ^= 1;
+		h->lane_next = (h->lane_next + 1) % active_lanes;
 	}
 	if (trace_path)
 	{
@@ -2071,7 +2092,7 @@ int ca3d_get_render_stats(ca3d_t *h, ca3d_render_stats *out) CA3D_API_TRY
 	if (!h->rev_valid) return fail(CA3D_ERR_NOT_CONFIGURED, "ca3d_render has not been called yet");
 	int rc = bind_device(h);
 	if (rc) return rc;
-	// the last frame's events and counters: the engine's, or those of the lane it ran on (two frames in flight)
+	// the last frame's events and counters: the engine's, or those of the lane it ran on (frames in flight)
 	const ca3d_engine::FrameLane *L = h->last_lane >= 0 ? &h->lanes[h->last_lane] : nullptr;
 	HIP_TRY(hipEventSynchronize(L ? L->stop : h->rev_stop));
 	float ms = 0.f;
@@ -2083,6 +2104,20 @@ int ca3d_get_render_stats(ca3d_t *h, ca3d_render_stats *out) CA3D_API_TRY
 	h->rstats.primary_cell_visits = c[1];
 	h->rstats.shadow_cell_visits = c[2];
 	*out = h->rstats;
+	return CA3D_OK;
+}
+CA3D_API_CATCH
+
+int ca3d_get_render_pipeline(ca3d_t *h, int32_t *frames_in_flight) CA3D_API_TRY
+{
+	if (!h || !frames_in_flight) return fail(CA3D_ERR_INVALID_ARGUMENT, "ca3d_get_render_pipeline: NULL argument");
+	int n = 0;
+	if (h->render_pipeline && h->n_lanes >= 2)
+	{
+		const int want = h->render_pipeline >= 2 ? h->render_pipeline : render_default_lanes();
+		n = h->n_lanes < want ? h->n_lanes : want;
+	}
+	*frames_in_flight = n;
 	return CA3D_OK;
 }
 CA3D_API_CATCH
@@ -2156,7 +2191,12 @@ int ca3d_set_option(ca3d_t *h, const char *name, int64_t value) CA3D_API_TRY
 	}
 	if (!strcmp(name, "render_frame_bricks")) { h->render_frame_bricks = value ? 1 : 0; return CA3D_OK; }
 	if (!strcmp(name, "render_stream")) { h->render_stream = value ? 1 : 0; return CA3D_OK; }
-	if (!strcmp(name, "render_pipeline")) { h->render_pipeline = value ? 1 : 0; return CA3D_OK; } // two converged frames in flight (FrameLane)
+	if (!strcmp(name, "render_pipeline")) // converged frames in flight (FrameLane): 0 off, 1 the default depth, 2 .. kMaxLanes that many
+	{
+		if (value < 0 || value > ca3d_engine::kMaxLanes) return fail(CA3D_ERR_INVALID_ARGUMENT, "render_pipeline must be 0 (off), 1 (default depth) or 2 .. %d frames in flight", ca3d_engine::kMaxLanes);
+		h->render_pipeline = (int)value;
+		return CA3D_OK;
+	}
 	if (!strcmp(name, "render_stream_check")) { h->render_stream_check = value ? 1 : 0; return CA3D_OK; }
 	if (!strcmp(name, "render_row_begin") || !strcmp(name, "render_row_end"))
 	{

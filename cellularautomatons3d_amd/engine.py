@@ -237,6 +237,12 @@ class Engine:
         _capi.check(self._lib.ca3d_get_render_stats(self._h, C.byref(s)))
         return s
 
+    def render_pipeline(self) -> int:
+        """Converged frames the engine keeps in flight (option render_pipeline): 0 before the first pipelined frame or when off."""
+        n = C.c_int32(0)
+        _capi.check(self._lib.ca3d_get_render_pipeline(self._h, C.byref(n)))
+        return int(n.value)
+
     def info(self) -> Info:
         i = Info()
         _capi.check(self._lib.ca3d_get_info(self._h, C.byref(i)))

@@ -380,6 +380,20 @@ static napi_value js_render_stats(napi_env env, napi_callback_info info)
 	return o;
 }
 
+static napi_value js_render_pipeline(napi_env env, napi_callback_info info)
+{
+	napi_value argv[1];
+	if (!get_args(env, info, 1, argv)) return NULL;
+	ca3d_t *h = get_handle(env, argv[0]);
+	if (!h) return NULL;
+	int32_t n = 0;
+	int rc = ca3d_get_render_pipeline(h, &n);
+	if (rc) return throw_ca3d(env, rc);
+	napi_value v;
+	napi_create_int32(env, n, &v);
+	return v;
+}
+
 static napi_value js_set_option(napi_env env, napi_callback_info info)
 {
 	napi_value argv[3];
@@ -863,7 +877,7 @@ static napi_value init(napi_env env, napi_value exports)
 	    {"configure", js_configure}, {"configureSlab", js_configure_slab}, {"setRules", js_set_rules},
 	    {"uploadState", js_upload_state}, {"readState", js_read_state}, {"step", js_step}, {"flush", js_flush}, {"slabStep", js_slab_step}, {"slabStepPhase", js_slab_step_phase},
 	    {"synchronize", js_synchronize}, {"info", js_info}, {"stats", js_stats}, {"render", js_render},
-	    {"renderStats", js_render_stats}, {"setOption", js_set_option},
+	    {"renderStats", js_render_stats}, {"renderPipeline", js_render_pipeline}, {"setOption", js_set_option},
 	    {"commUniqueId", js_comm_unique_id}, {"slabCommInit", js_slab_comm_init}, {"slabRun", js_slab_run}, {"slabExchange", js_slab_exchange},
 	    {"slabGather", js_slab_gather},
 	    {"recoveredLaunches", js_recovered_launches},

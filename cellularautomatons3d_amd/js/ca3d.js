@@ -273,6 +273,7 @@ class Engine
 	info() { this._idle("info"); return this._a.info(this._h); }
 	stats() { this._idle("stats"); return this._a.stats(this._h); }
 	renderStats() { this._idle("renderStats"); return this._a.renderStats(this._h); }
+	renderPipeline() { this._idle("renderPipeline"); return this._a.renderPipeline(this._h); } // converged frames in flight (option render_pipeline)
 	setOption(name, value) { this._idle("setOption"); this._a.setOption(this._h, name, value); }
 	/** resident launches that timed out and were re-run through the per-step kernels (include/ca3d.h) */
 	recoveredLaunches() { this._idle("recoveredLaunches"); return this._a.recoveredLaunches(this._h); }

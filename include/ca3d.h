@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define CA3D_ABI_VERSION 6 /* 5: + ca3d_get_kernel_variant; 6: + ca3d_selftest_exception, the kernel cache (ca3d_get_jit_log reports it) */
+#define CA3D_ABI_VERSION 7 /* 5: + ca3d_get_kernel_variant; 6: + ca3d_selftest_exception, the kernel cache (ca3d_get_jit_log reports it); 7: + ca3d_get_render_pipeline */
 #define CA3D_LUT_LEN 81 /* 3 rule-sets x 27 slots (main_pathtraced.js:10, 155-159) */
 
 typedef struct ca3d_engine ca3d_t;
@@ -353,6 +353,11 @@ typedef struct ca3d_render_stats
 } ca3d_render_stats;
 int ca3d_get_render_stats(ca3d_t *h, ca3d_render_stats *out);
 
+/* How many converged frames the engine keeps in flight (option "render_pipeline" below): the number of internal streams — on pairwise
+ * different hardware queues, probed when the first pipelined frame is drawn — that such frames alternate between; 0 before that frame,
+ * with the option off, or when the runtime gave the engine no two streams that run side by side. Does not wait for the GPU. */
+int ca3d_get_render_pipeline(ca3d_t *h, int32_t *frames_in_flight);
+
 /* Options (not part of the reference surface): "queue" n: queued submission (see ca3d_step; 0 = off); "graph" 0/1 hipGraph batching; "stats" 0/1: record the event pair
  * ca3d_get_stats reads around every ca3d_step batch (on by default; a host that steps in small batches and never asks
  * for stats saves two marker packets per call); "graph_prepare" n builds now the
@@ -385,11 +390,12 @@ int ca3d_get_render_stats(ca3d_t *h, ca3d_render_stats *out);
  * ray-stream passes (render_stream.hip; on by default; 0: the in-wave scheduled kernel; the same frame bit for bit);
  * "render_stream_check" 0/1 diagnostics: the stream passes count where their interval filter and the slab test disagree and which
  * answers were looked up unset — ca3d_render fails with CA3D_ERR_DEVICE if any (off by default; takes the frame off the pipeline);
- * "render_pipeline" 0/1 two converged frames in flight (on by default): frames that stay on the device (no host pointers), are drawn
- * by the stream passes and go down the engine's OWN stream alternate between two internal streams, so that one frame's walks fill the
- * idle tail of the other's; the engine's stream waits for them at the next call that touches the state, a render target
- * (ca3d_render_target, ca3d_get_render_stats) or the stream. Each frame is the frame of one-at-a-time rendering, bit for bit; a
- * caller on a stream of its own (ca3d_set_stream), a frame with host pointers, a band or a literal frame is never pipelined;
+ * "render_pipeline" 0 / 1 / 2-4 converged frames in flight (1, the default: three; 0: none; 2-4: that many): frames that stay on the
+ * device (no host pointers), are drawn by the stream passes and go down the engine's OWN stream alternate between that many internal
+ * streams, so that one frame's walks fill the idle tails of the others'; the engine's stream waits for them at the next call that
+ * touches the state, a render target (ca3d_render_target, ca3d_get_render_stats) or the stream. Each frame is the frame of
+ * one-at-a-time rendering, bit for bit; a caller on a stream of its own (ca3d_set_stream), a frame with host pointers, a band or a
+ * literal frame is never pipelined; ca3d_get_render_pipeline reports the depth in use;
  * "render_frame_bricks" 0/1 the literal frame as a batched march over the bricked volume (on by default; 0: the statement-by-
  * statement form, the same frame bit for bit); "rows" 0/1 the run-time compiled rows kernel on grids that are not a power of two (on by
  * default; 0: the kernels that served them before — tests, tuning). */

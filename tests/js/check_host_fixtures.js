@@ -42,6 +42,6 @@ for (const G of Object.keys(g.dispatch))
 }
 // the addon loads and exports the ABI; without a GPU engine creation must throw, not fall back
 const a = c.loadAddon();
-assert.strictEqual(a.abiVersion(), 6);
+assert.strictEqual(a.abiVersion(), 7);
 for (const f of ["create", "destroy", "configure", "configureSlab", "setRules", "uploadState", "readState", "step", "slabStep", "synchronize", "info", "stats", "render", "renderStats", "setOption", "deviceCount"]) { assert.strictEqual(typeof a[f], "function", f); }
 console.log("ok");

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_abi_version():
-    assert _capi.load().ca3d_abi_version() == 6
+    assert _capi.load().ca3d_abi_version() == 7
 
 
 def test_no_exception_crosses_the_c_abi():

@@ -752,9 +752,9 @@ def _targets(eng):
     return out
 
 
-def test_two_frames_in_flight(eng):
-    """Converged frames that stay on the device alternate between two streams of the engine (option render_pipeline, default on), so that
-    one frame's walks fill the idle tail of the other's. What must not change: the targets after a run of such frames are those of the LAST
+def test_frames_in_flight(eng):
+    """Converged frames that stay on the device alternate between three streams of the engine (option render_pipeline, default on; 2 - 4:
+    that many), so that one frame's walks fill the idle tails of the others'. What must not change: the targets after a run of such frames are those of the LAST
     frame asked for — camera moving from frame to frame, the state stepped and uploaded between frames (a frame in flight reads the state it
     was asked for; the step behind it waits) — byte for byte the frame an engine without the pipeline leaves there."""
     G, W, H, spp = 128, 640, 360, 4
@@ -795,10 +795,16 @@ def test_two_frames_in_flight(eng):
         return got
 
     try:
-        a, b = run(0), run(1)
+        a = run(0)
+        assert eng.render_pipeline() == 0
+        deep = {}
+        for pipe in (1, 2, 4):  # the default depth (three frames in flight), two, four
+            deep[pipe] = run(pipe)
+            assert eng.render_pipeline() == (3 if pipe == 1 else pipe), (pipe, eng.render_pipeline())
     finally:
         eng.set_option("render_pipeline", 1)
-    for fa, fb in zip(a, b):
-        for x, y in zip(fa, fb):
-            np.testing.assert_array_equal(x, y)
+    for pipe, b in deep.items():
+        for fa, fb in zip(a, b):
+            for x, y in zip(fa, fb):
+                np.testing.assert_array_equal(x, y, err_msg=f"render_pipeline {pipe}")
     assert a[0][1].any()  # the scene is not empty

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Soak of the resident multi-step kernels against the per-step kernels (which the test suite pins to the oracle): two engines
 step the same seeded state, one through the resident path (batches of uneven lengths, queued and flushed), one kernel per
-step; the full states are compared after every round. Start-up rule at 512^3, von Neumann B2,4 / S1,3,5 at 512^3 / 256^3, clustered rule-set at 512^3 / 256^3."""
+step; the full states are compared after every round. Start-up rule at 512^3, von Neumann B2,4 / S1,3,5 at 512^3 / 256^3 / 64^3 (the one-workgroup form), clustered rule-set at 512^3 / 256^3."""
 import os
 import sys
 import time
@@ -15,7 +15,7 @@ rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 CLUSTERED = ("moore", "5-7", "4-7", "4", "3-5", "3", "2-4")
 VN_B24_S135 = ("von neumann", "2,4", "1,3,5")  # keeps changing (the start-up rule B1,3 / S0-6 freezes from a random fill)
 total_bad = 0
-for G, rule, per_round in ((512, (), 20000), (512, VN_B24_S135, 20000), (256, VN_B24_S135, 40000), (512, CLUSTERED, 4000), (256, CLUSTERED, 12000)):
+for G, rule, per_round in ((512, (), 20000), (512, VN_B24_S135, 20000), (256, VN_B24_S135, 40000), (64, VN_B24_S135, 100000), (512, CLUSTERED, 4000), (256, CLUSTERED, 12000)):
     a, b = Engine(0), Engine(0)
     for e in (a, b):
         e.configure(G)

@@ -85,7 +85,7 @@ def parse(argv=None):
                          "off by default (on for --config 5) so that the scaling run times the CA step alone")
     ap.add_argument("--render-size", default="")
     ap.add_argument("--render-spp", type=int, default=4)
-    ap.add_argument("--render-frames", type=int, default=40)
+    ap.add_argument("--render-frames", type=int, default=100)
     ap.add_argument("--overlap", choices=["auto", "on", "off"], default="",
                     help="N>1: run the halo exchange under the interior phase of each batch (auto: by slab size, see slab.py)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="gloo = rehearsal transport through host memory")
@@ -321,7 +321,7 @@ def _render_leg_on_own_stream(eng, G, a, W, H, literal, sparse):
     from cellularautomatons3d_amd import host
 
     # one frame at a time first (render_pipeline 0: what a frame costs from its first kernel to its last), then the engine's default — converged
-    # frames that stay on the device alternate between three streams, the next frames' walks fill the idle tails of this one's
+    # frames that stay on the device alternate between up to four streams and run side by side, each frame's walks on a share of the chip
     eng.set_option("render_pipeline", 0)
     dt1, st1 = time_frames(eng, host.uniform_block(W, H, host.orbit_camera()), W, H, a.render_spp, a.render_frames)
     eng.set_option("render_pipeline", 1)

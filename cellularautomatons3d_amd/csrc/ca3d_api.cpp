@@ -226,7 +226,7 @@ struct ca3d_engine
 	hipEvent_t r_fork = nullptr, r_join = nullptr;
 	bool rev_valid = false;
 	ca3d_render_stats rstats{};
-	// Converged frames in flight (option "render_pipeline", default 1: three of them). A frame's two persistent walk launches each end in a tail with
+	// Converged frames in flight (option "render_pipeline", default 1: four of them up to 16 M samples a frame, three above). A frame's two persistent walk launches each end in a tail with
 	// most of the chip idle (render_stream.hip: a third to a half of a 1080p launch) and its passes depend on each other — but not on
 	// the frame before: a converged frame has no history. Frames that stay on the device (no host pointers) and are drawn by the stream
 	// passes alternate between LANES — a stream, scratch, counters and events each — so that the next frames' walks
@@ -250,8 +250,9 @@ struct ca3d_engine
 	hipEvent_t ev_state = nullptr; // "everything the engine's stream held when the frame was asked for"
 	bool main_touched = true;      // an entry point other than a pipelined ca3d_render has run since ev_state was recorded (bind_device)
 	std::vector<hipStream_t> lane_spares; // streams that turned out to share a hardware queue with lane 0 (kept: destroying one hands its queue to the next)
-	int render_pipeline = 1; // 0: off; 1: the default depth (kDefaultLanes frames in flight); 2 .. kMaxLanes: that many
+	int render_pipeline = 1; // 0: off; 1: the default depth (render_default_lanes: by frame size); 2 .. kMaxLanes: that many
 	int lane_next = 0;
+	int lanes_in_use = 0; // depth of the last pipelined frame (ca3d_get_render_pipeline)
 	bool lanes_exhausted = false; // the probe found fewer side-by-side streams than asked for
 	int last_lane = -1; // the lane of the last frame (-1: it went down the engine's stream) — whose events and counters ca3d_get_render_stats reads
 
@@ -322,13 +323,25 @@ void free_buffers(ca3d_engine *h)
 }
 
 // the engine's stream waits for the frames in flight on the lanes (nothing is waited for on the host)
-// Converged frames in flight when option render_pipeline is 1: three. Measured on the bench's dense 512^3 scene (ms per frame, 0 / 2 / 3 / 4
-// lanes): 1080p 4 spp 0.627 / 0.505 / 0.481 / 0.484, 1080p 1 spp 0.444 / 0.278 / 0.240 / 0.237, 3840 x 2160 1.539 / 1.396 / 1.390 / 1.392.
-// CA3D_RENDER_LANES=2..4 (tuning) moves the default.
-int render_default_lanes()
+// Converged frames in flight when option render_pipeline is 1, and the share of the chip's wave slots each frame's persistent walk launches
+// ask for while other frames are in flight beside it. Measured on the bench's dense 512^3 scene (tools/sweep_stream_wgs.sh, ms per frame;
+// lanes x share): 1080p 4 spp   3 x 100 % 0.485 | 3 x 34 % 0.393 | 4 x 25 % 0.367 | 4 x 17 % 0.397      (one frame at a time: 0.627)
+//                 2560 x 1440   3 x 100 % 0.746 | 3 x 34 % 0.641 | 4 x 25 % 0.612
+//                 3840 x 2160   3 x 100 % 1.389 | 3 x 67 % 1.370 | 3 x 34 % 1.419 | 4 x 25 % 1.466      (one frame at a time: 1.539)
+// — frames whose walks run SIDE BY SIDE on their shares beat frames that fill the chip one after the other and overlap only tail to head,
+// as long as a frame's walks are short against their tails; at 3840 x 2160 (33 M jobs) the shares only get in the way of the frame's
+// other, full-width passes. So: up to 16 M samples four frames on a quarter each, above that three on two thirds each.
+// CA3D_RENDER_LANES=2..4 / CA3D_STREAM_WGS_PCT (tuning) override both.
+int render_default_lanes(size_t samples)
 {
 	static const int env = getenv("CA3D_RENDER_LANES") ? atoi(getenv("CA3D_RENDER_LANES")) : 0;
-	return env >= 2 && env <= ca3d_engine::kMaxLanes ? env : 3;
+	if (env >= 2 && env <= ca3d_engine::kMaxLanes) return env;
+	return samples <= (16u << 20) ? 4 : 3;
+}
+int render_walk_share(size_t samples, int lanes)
+{
+	if (lanes < 2) return 100;
+	return samples <= (16u << 20) ? 100 / lanes : (samples <= (28u << 20) ? 50 : 67);
 }
 
 int join_frames(ca3d_engine *h)
@@ -1873,10 +1886,11 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 	}
 	// where this frame runs: the engine's stream, or the next lane
 	ca3d_engine::FrameLane *L = nullptr;
+	int walk_share = 100;
 	hipStream_t rs = h->stream;
 	unsigned long long *counters = h->r_counters;
-	const int kDefaultLanes = render_default_lanes();
-	const int want_lanes = h->render_pipeline >= 2 ? (h->render_pipeline < ca3d_engine::kMaxLanes ? h->render_pipeline : ca3d_engine::kMaxLanes) : kDefaultLanes;
+	const size_t frame_samples = (size_t)width * height * spp;
+	const int want_lanes = h->render_pipeline >= 2 ? (h->render_pipeline < ca3d_engine::kMaxLanes ? h->render_pipeline : ca3d_engine::kMaxLanes) : render_default_lanes(frame_samples);
 	if (pipelined && h->n_lanes < want_lanes && h->n_lanes >= 0 && !h->lanes_exhausted)
 	{
 		// the lanes: streams that the runtime has put on pairwise DIFFERENT hardware queues (probed: ca_diag.hip) — two streams on one queue
@@ -1912,6 +1926,18 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 	{
 		if (h->lane_next >= active_lanes) h->lane_next = 0;
 		L = &h->lanes[h->lane_next];
+		h->lanes_in_use = active_lanes;
+		// is another frame still in flight beside this one? Then this frame's walks take their share of the chip (render_walk_share); a
+		// frame that finds the lanes idle — a host that draws one frame per display refresh — takes the whole chip and is done sooner.
+		bool beside = false;
+		for (int i = 0; i < active_lanes && !beside; i++)
+			if (&h->lanes[i] != L && h->lanes[i].used)
+			{
+				const hipError_t q = hipEventQuery(h->lanes[i].done);
+				if (q == hipErrorNotReady) { beside = true; (void)hipGetLastError(); }
+				else if (q != hipSuccess) HIP_TRY(q);
+			}
+		walk_share = beside ? render_walk_share(frame_samples, active_lanes) : 100;
 		if (h->main_touched)
 		{
 			// the steps and uploads in front of this frame — recorded only when an entry point has touched the engine's stream since the last
@@ -1931,6 +1957,7 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 	HIP_TRY(hipMemsetAsync(counters, 0, (trace_path ? counter_words : 8u) * sizeof(unsigned long long), rs)); // [3]: the tile queue's head
 	RenderLaunch l;
 	l.trace = trace_path != nullptr;
+	l.walk_share_pct = walk_share;
 	l.cells = h->buf[h->cur];
 	l.G = h->G;
 	l.W = width;
@@ -2114,8 +2141,7 @@ int ca3d_get_render_pipeline(ca3d_t *h, int32_t *frames_in_flight) CA3D_API_TRY
 	int n = 0;
 	if (h->render_pipeline && h->n_lanes >= 2)
 	{
-		const int want = h->render_pipeline >= 2 ? h->render_pipeline : render_default_lanes();
-		n = h->n_lanes < want ? h->n_lanes : want;
+		n = h->lanes_in_use; // of the last pipelined frame (the default depth follows the frame's size)
 	}
 	*frames_in_flight = n;
 	return CA3D_OK;

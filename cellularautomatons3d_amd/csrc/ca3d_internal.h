@@ -177,6 +177,7 @@ struct RenderLaunch
 	// two frames in flight (ca3d_api.cpp, FrameLane): the frame before this one runs on another stream; everything of THIS frame that
 	// writes a target both share (the presentation surface) waits for this event first. Null: nothing to wait for.
 	hipEvent_t after = nullptr;
+	int walk_share_pct = 100; // frames in flight: the share of the chip's wave slots each persistent walk launch of this frame asks for (100: the frame has the chip to itself)
 	bool stream_check = false; // diagnostics: every live-cell decision of the interval filter is checked against the slab test and contradictions counted
 };
 
@@ -194,7 +195,7 @@ size_t frame_bricks_bytes(uint32_t G);
 bool frame_bricks_applies(uint32_t G);
 hipError_t launch_render_frame_bricks(const void *frame_params, uint32_t *bricks, bool bricks_valid, hipStream_t stream, bool *bricks_built = nullptr);
 hipError_t launch_brick_volume(const uint32_t *cells, uint32_t *bricks, uint32_t G, hipStream_t stream);
-hipError_t launch_render_stream(const void *params, void *scratch, uint32_t W, uint32_t H, bool check, uint32_t *bricks, bool bricks_valid, hipStream_t stream, bool *bricks_built = nullptr, hipEvent_t before_resolve = nullptr);
+hipError_t launch_render_stream(const void *params, void *scratch, uint32_t W, uint32_t H, bool check, uint32_t *bricks, bool bricks_valid, hipStream_t stream, bool *bricks_built = nullptr, hipEvent_t before_resolve = nullptr, int walk_share_pct = 100);
 
 // ca_packed.hip / ca_unpacked.hip
 hipError_t launch_packed_step(const PackedLaunch &l, hipStream_t stream, const char **kernel_name);

@@ -1188,7 +1188,7 @@ hipError_t launch_render(const RenderLaunch &l, hipStream_t stream)
 			const bool streamed = l.stream_scratch && !P.legacy && !P.trace;
 			if (streamed)
 			{
-				hipError_t e = launch_render_stream(&P, l.stream_scratch, l.W, l.H, l.stream_check, l.bricks, l.bricks_valid, stream, l.bricks_built, l.after);
+				hipError_t e = launch_render_stream(&P, l.stream_scratch, l.W, l.H, l.stream_check, l.bricks, l.bricks_valid, stream, l.bricks_built, l.after, l.walk_share_pct);
 				if (e != hipSuccess) return e;
 			}
 			if (one)

@@ -1411,7 +1411,7 @@ size_t stream_scratch_bytes(uint32_t W, uint32_t H, uint32_t spp, size_t *hit_of
 
 // The dense-volume part of a frame over the rectangle P.rx0 .. P.ry1 (render.hip's volume_rect), on `stream`. The caller has
 // cleared P.counters and, when there is one, run the occupancy pass (the passes here test its count on the device).
-hipError_t launch_render_stream(const void *params, void *scratch, uint32_t W, uint32_t H, bool check, uint32_t *bricks, bool bricks_valid, hipStream_t stream, bool *bricks_built, hipEvent_t before_resolve)
+hipError_t launch_render_stream(const void *params, void *scratch, uint32_t W, uint32_t H, bool check, uint32_t *bricks, bool bricks_valid, hipStream_t stream, bool *bricks_built, hipEvent_t before_resolve, int walk_share_pct)
 {
 	StreamParams S;
 	S.R = *static_cast<const RenderParams *>(params);
@@ -1480,7 +1480,12 @@ hipError_t launch_render_stream(const void *params, void *scratch, uint32_t W, u
 		S.refill2 = pop_env >= 1 && pop_env <= 64 ? pop_env : 16;
 		static const int tb_env = getenv("CA3D_STREAM_TAIL_BATCH") ? atoi(getenv("CA3D_STREAM_TAIL_BATCH")) : 1;
 		S.tail_batch = tb_env == 2 ? 2 : (tb_env ? 1 : 0); // (2, tuning: the batched loop from the first cell on)
-		const u32 wgs2 = min(S.chunks, (u32)cus * (u32)kW2PerSimd * 4u / (u32)kW2Waves);
+		// A persistent walk launch asks for the wave slots of the whole chip — unless other frames are in flight beside this one (ca3d_api.cpp,
+		// FrameLane): then for its share of them, so that the frames' walks run side by side from their first workgroup on instead of one
+		// launch filling the chip and the next one seeping into its tail (tools/sweep_stream_wgs.sh; CA3D_STREAM_WGS_PCT overrides: tuning).
+		static const int wgs_env = getenv("CA3D_STREAM_WGS_PCT") ? atoi(getenv("CA3D_STREAM_WGS_PCT")) : 0;
+		const u32 pct = (u32)(wgs_env >= 10 && wgs_env <= 100 ? wgs_env : (walk_share_pct >= 10 && walk_share_pct <= 100 ? walk_share_pct : 100));
+		const u32 wgs2 = max(8u, min(S.chunks, (u32)cus * (u32)kW2PerSimd * 4u / (u32)kW2Waves * pct / 100u));
 		const bool form2 = form_env == 2 && per >= 128u && bricks_env == 1; // (a chunk holds at least 64 tickets of two jobs)
 		if (form2) trace_waves = (unsigned long long)wgs2 * (unsigned)kW2Waves;
 		static const int probe_env = getenv("CA3D_STREAM_PROBE") ? atoi(getenv("CA3D_STREAM_PROBE")) : 0;

@@ -390,12 +390,15 @@ int ca3d_get_render_pipeline(ca3d_t *h, int32_t *frames_in_flight);
  * ray-stream passes (render_stream.hip; on by default; 0: the in-wave scheduled kernel; the same frame bit for bit);
  * "render_stream_check" 0/1 diagnostics: the stream passes count where their interval filter and the slab test disagree and which
  * answers were looked up unset — ca3d_render fails with CA3D_ERR_DEVICE if any (off by default; takes the frame off the pipeline);
- * "render_pipeline" 0 / 1 / 2-4 converged frames in flight (1, the default: three; 0: none; 2-4: that many): frames that stay on the
- * device (no host pointers), are drawn by the stream passes and go down the engine's OWN stream alternate between that many internal
- * streams, so that one frame's walks fill the idle tails of the others'; the engine's stream waits for them at the next call that
+ * "render_pipeline" 0 / 1 / 2-4 converged frames in flight (1, the default: four up to 16 M samples a frame, three above; 0: none;
+ * 2-4: that many): frames that stay on the device (no host pointers), are drawn by the stream passes and go down the engine's OWN
+ * stream alternate between that many internal streams; a frame that finds another one still in flight sizes its persistent walk
+ * launches for its share of the chip, so that the frames' walks run side by side (a frame that finds the engine idle takes the whole
+ * chip: a host that draws one frame per display refresh loses nothing); the engine's stream waits for them at the next call that
  * touches the state, a render target (ca3d_render_target, ca3d_get_render_stats) or the stream. Each frame is the frame of
  * one-at-a-time rendering, bit for bit; a caller on a stream of its own (ca3d_set_stream), a frame with host pointers, a band or a
- * literal frame is never pipelined; ca3d_get_render_pipeline reports the depth in use;
+ * literal frame is never pipelined; ca3d_get_render_pipeline reports the depth in use; the first pipelined frame of an engine probes
+ * the runtime's streams for separate hardware queues (a few milliseconds per pair, once);
  * "render_frame_bricks" 0/1 the literal frame as a batched march over the bricked volume (on by default; 0: the statement-by-
  * statement form, the same frame bit for bit); "rows" 0/1 the run-time compiled rows kernel on grids that are not a power of two (on by
  * default; 0: the kernels that served them before — tests, tuning). */

@@ -753,7 +753,7 @@ def _targets(eng):
 
 
 def test_frames_in_flight(eng):
-    """Converged frames that stay on the device alternate between three streams of the engine (option render_pipeline, default on; 2 - 4:
+    """Converged frames that stay on the device alternate between up to four streams of the engine (option render_pipeline, default on; 2 - 4:
     that many), so that one frame's walks fill the idle tails of the others'. What must not change: the targets after a run of such frames are those of the LAST
     frame asked for — camera moving from frame to frame, the state stepped and uploaded between frames (a frame in flight reads the state it
     was asked for; the step behind it waits) — byte for byte the frame an engine without the pipeline leaves there."""
@@ -798,10 +798,10 @@ def test_frames_in_flight(eng):
         a = run(0)
         assert eng.render_pipeline() == 0
         deep = {}
-        for pipe in (1, 2, 4):  # the default depth (three frames in flight), two, four
+        for pipe in (1, 2, 3):  # the default depth (four frames in flight at this size), two, three
             deep[pipe] = run(pipe)
             # (the depth in use is what the runtime's hardware queues allow: streams that do not run side by side are not used as lanes)
-            want, got = (3 if pipe == 1 else pipe), eng.render_pipeline()
+            want, got = (4 if pipe == 1 else pipe), eng.render_pipeline()  # (default depth: four frames up to 16 M samples a frame)
             assert got == want or (got < want and got != 1), (pipe, got)
     finally:
         eng.set_option("render_pipeline", 1)

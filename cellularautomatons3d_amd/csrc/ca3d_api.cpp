@@ -226,7 +226,7 @@ struct ca3d_engine
 	hipEvent_t r_fork = nullptr, r_join = nullptr;
 	bool rev_valid = false;
 	ca3d_render_stats rstats{};
-	// Converged frames in flight (option "render_pipeline", default 1: four of them up to 16 M samples a frame, three above). A frame's two persistent walk launches each end in a tail with
+	// Converged frames in flight (option "render_pipeline", default 1: four of them up to 24 M samples a frame, three above). A frame's two persistent walk launches each end in a tail with
 	// most of the chip idle (render_stream.hip: a third to a half of a 1080p launch) and its passes depend on each other — but not on
 	// the frame before: a converged frame has no history. Frames that stay on the device (no host pointers) and are drawn by the stream
 	// passes alternate between LANES — a stream, scratch, counters and events each — so that the next frames' walks
@@ -327,22 +327,21 @@ void free_buffers(ca3d_engine *h)
 // ask for while other frames are in flight beside it. Measured on the bench's dense 512^3 scene (tools/sweep_stream_wgs.sh, ms per frame;
 // lanes x share): 1080p 4 spp   3 x 100 % 0.485 | 3 x 34 % 0.393 | 4 x 25 % 0.367 | 4 x 17 % 0.397      (one frame at a time: 0.627)
 //                 2560 x 1440   3 x 100 % 0.746 | 3 x 34 % 0.641 | 4 x 25 % 0.612
-//                 3840 x 2160   3 x 100 % 1.389 | 3 x 67 % 1.370 | 3 x 34 % 1.419 | 4 x 25 % 1.466      (one frame at a time: 1.539)
-// — frames whose walks run SIDE BY SIDE on their shares beat frames that fill the chip one after the other and overlap only tail to head,
-// as long as a frame's walks are short against their tails; at 3840 x 2160 (33 M jobs) the shares only get in the way of the frame's
-// other, full-width passes. So: up to 16 M samples four frames on a quarter each, above that three on two thirds each.
+//                 3200 x 1800   3 x 100 % 1.054 | 3 x 34 % 0.968 | 4 x 25 % 0.936
+//                 3840 x 2160   2 x 100 % 1.386 | 2 x 50 % 1.35-1.40 | 3 x 100 % 1.389 | 3 x 67 % 1.37-1.38 | 3 x 34 % 1.419 | 4 x 25 % 1.466   (one at a time: 1.539)
+// — frames whose walks run SIDE BY SIDE on equal shares of the chip beat frames that fill the chip one after the other and overlap only
+// tail to head; how many of them depends on the frame: small frames want many narrow ones (their walks are short against their tails),
+// at 3840 x 2160 (33 M samples, 0.7 GB of scratch per frame in flight) narrow walks only get in the way of the frame's other, full-width
+// passes and nothing is more than 2 % from anything else.
+// So: up to 24 M samples a frame four frames on a quarter of the chip each, above that three on two thirds each.
 // CA3D_RENDER_LANES=2..4 / CA3D_STREAM_WGS_PCT (tuning) override both.
 int render_default_lanes(size_t samples)
 {
 	static const int env = getenv("CA3D_RENDER_LANES") ? atoi(getenv("CA3D_RENDER_LANES")) : 0;
 	if (env >= 2 && env <= ca3d_engine::kMaxLanes) return env;
-	return samples <= (16u << 20) ? 4 : 3;
+	return samples <= (24u << 20) ? 4 : 3;
 }
-int render_walk_share(size_t samples, int lanes)
-{
-	if (lanes < 2) return 100;
-	return samples <= (16u << 20) ? 100 / lanes : (samples <= (28u << 20) ? 50 : 67);
-}
+int render_walk_share(size_t samples, int lanes) { return lanes < 2 ? 100 : (samples <= (24u << 20) ? 100 / lanes : 67); }
 
 int join_frames(ca3d_engine *h)
 {

@@ -390,7 +390,7 @@ int ca3d_get_render_pipeline(ca3d_t *h, int32_t *frames_in_flight);
  * ray-stream passes (render_stream.hip; on by default; 0: the in-wave scheduled kernel; the same frame bit for bit);
  * "render_stream_check" 0/1 diagnostics: the stream passes count where their interval filter and the slab test disagree and which
  * answers were looked up unset — ca3d_render fails with CA3D_ERR_DEVICE if any (off by default; takes the frame off the pipeline);
- * "render_pipeline" 0 / 1 / 2-4 converged frames in flight (1, the default: four up to 16 M samples a frame, three above; 0: none;
+ * "render_pipeline" 0 / 1 / 2-4 converged frames in flight (1, the default: four up to 24 M samples a frame, three above; 0: none;
  * 2-4: that many): frames that stay on the device (no host pointers), are drawn by the stream passes and go down the engine's OWN
  * stream alternate between that many internal streams; a frame that finds another one still in flight sizes its persistent walk
  * launches for its share of the chip, so that the frames' walks run side by side (a frame that finds the engine idle takes the whole

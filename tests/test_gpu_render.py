@@ -801,7 +801,7 @@ def test_frames_in_flight(eng):
         for pipe in (1, 2, 3):  # the default depth (four frames in flight at this size), two, three
             deep[pipe] = run(pipe)
             # (the depth in use is what the runtime's hardware queues allow: streams that do not run side by side are not used as lanes)
-            want, got = (4 if pipe == 1 else pipe), eng.render_pipeline()  # (default depth: four frames up to 16 M samples a frame)
+            want, got = (4 if pipe == 1 else pipe), eng.render_pipeline()  # (default depth: four frames up to 24 M samples a frame)
             assert got == want or (got < want and got != 1), (pipe, got)
     finally:
         eng.set_option("render_pipeline", 1)

@@ -249,6 +249,7 @@ struct ca3d_engine
 	int n_lanes = 0; // lanes created (streams on pairwise different hardware queues); 0: not tried yet
 	hipEvent_t ev_state = nullptr; // "everything the engine's stream held when the frame was asked for"
 	bool main_touched = true;      // an entry point other than a pipelined ca3d_render has run since ev_state was recorded (bind_device)
+	bool state_touched = true;     // an entry point other than ca3d_render has run since the last frame: the next frame is not pipelined (ca3d_render)
 	std::vector<hipStream_t> lane_spares; // streams that turned out to share a hardware queue with lane 0 (kept: destroying one hands its queue to the next)
 	int render_pipeline = 1; // 0: off; 1: the default depth (render_default_lanes: by frame size); 2 .. kMaxLanes: that many
 	int lane_next = 0;
@@ -357,7 +358,7 @@ int join_frames(ca3d_engine *h)
 int bind_device(ca3d_engine *h, bool join = true)
 {
 	HIP_TRY(hipSetDevice(h->device));
-	if (join) h->main_touched = true; // (whatever the caller is about to put on the engine's stream: the next pipelined frame waits for it)
+	if (join) h->main_touched = h->state_touched = true; // (whatever the caller is about to put on the engine's stream: the next pipelined frame waits for it)
 	if (join)
 		for (auto &L : h->lanes)
 			if (L.pending) return join_frames(h);
@@ -1843,7 +1844,12 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 	// frames in flight (FrameLane): converged frames of a packed volume that stay on the device and go down the stream passes
 	static const char *trace_path = getenv("CA3D_RENDER_TRACE");
 	static const bool aux_off = getenv("CA3D_RENDER_AUX") && atoi(getenv("CA3D_RENDER_AUX")) == 0; // tuning: everything on one stream
-	const bool pipelined = h->render_pipeline && h->render_mode == 0 && !presentation_rgba8 && !light_rgba16f && !depth_rg16f && h->stream == h->own_stream &&
+	// The first frame after a step, an upload or any other call on the engine's stream is drawn ON that stream: it has to wait for that call,
+	// which waited for every earlier frame — nothing can be in flight beside it, and on a lane it would only pay two cross-stream hand-offs
+	// (a host that steps between frames: 0.628 against 0.564 ms per step + frame, tools/run_render_step_loop.py). The frames behind it go
+	// down the lanes.
+	const bool first_after_touch = h->state_touched;
+	const bool pipelined = !first_after_touch && h->render_pipeline && h->render_mode == 0 && !presentation_rgba8 && !light_rgba16f && !depth_rg16f && h->stream == h->own_stream &&
 	                       h->layout == CA3D_LAYOUT_PACKED32 && h->render_stream && h->render_sched && !h->render_indirect && !h->render_stream_check && !trace_path &&
 	                       !aux_off && !h->render_row0 && !h->render_row1 && width == h->rw && height == h->rh;
 	int rc = bind_device(h, !pipelined);
@@ -1928,8 +1934,10 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 		h->lanes_in_use = active_lanes;
 		// is another frame still in flight beside this one? Then this frame's walks take their share of the chip (render_walk_share); a
 		// frame that finds the lanes idle — a host that draws one frame per display refresh — takes the whole chip and is done sooner.
+		// (A frame that has to wait for the engine's stream — a step or an upload since the last frame — starts after every earlier frame:
+		// the engine's stream joined them before that call's work. It runs alone whatever is still in flight now.)
 		bool beside = false;
-		for (int i = 0; i < active_lanes && !beside; i++)
+		for (int i = 0; i < active_lanes && !beside && !h->main_touched; i++)
 			if (&h->lanes[i] != L && h->lanes[i].used)
 			{
 				const hipError_t q = hipEventQuery(h->lanes[i].done);
@@ -2108,6 +2116,7 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 	if (depth_rg16f) HIP_TRY(hipMemcpyAsync(depth_rg16f, h->r_depth[h->r_swap], px * 4, hipMemcpyDeviceToHost, h->stream));
 	if (presentation_rgba8 || light_rgba16f || depth_rg16f) HIP_TRY(hipStreamSynchronize(h->stream));
 	h->r_swap ^= 1;
+	h->state_touched = false; // (set again by the next entry point that is not a frame: bind_device)
 	return CA3D_OK;
 }
 CA3D_API_CATCH

@@ -394,7 +394,8 @@ int ca3d_get_render_pipeline(ca3d_t *h, int32_t *frames_in_flight);
  * 2-4: that many): frames that stay on the device (no host pointers), are drawn by the stream passes and go down the engine's OWN
  * stream alternate between that many internal streams; a frame that finds another one still in flight sizes its persistent walk
  * launches for its share of the chip, so that the frames' walks run side by side (a frame that finds the engine idle takes the whole
- * chip: a host that draws one frame per display refresh loses nothing); the engine's stream waits for them at the next call that
+ * chip: a host that draws one frame per display refresh loses nothing; the first frame after a step, an upload or any other call
+ * on the engine's stream is drawn on that stream); the engine's stream waits for them at the next call that
  * touches the state, a render target (ca3d_render_target, ca3d_get_render_stats) or the stream. Each frame is the frame of
  * one-at-a-time rendering, bit for bit; a caller on a stream of its own (ca3d_set_stream), a frame with host pointers, a band or a
  * literal frame is never pipelined; ca3d_get_render_pipeline reports the depth in use; the first pipelined frame of an engine probes

@@ -1896,7 +1896,7 @@ int ca3d_render(ca3d_t *h, const float uniforms[128], uint32_t width, uint32_t h
 	unsigned long long *counters = h->r_counters;
 	const size_t frame_samples = (size_t)width * height * spp;
 	const int want_lanes = h->render_pipeline >= 2 ? (h->render_pipeline < ca3d_engine::kMaxLanes ? h->render_pipeline : ca3d_engine::kMaxLanes) : render_default_lanes(frame_samples);
-	if (pipelined && h->n_lanes < want_lanes && h->n_lanes >= 0 && !h->lanes_exhausted)
+	if (pipelined && h->n_lanes < want_lanes && !h->lanes_exhausted)
 	{
 		// the lanes: streams that the runtime has put on pairwise DIFFERENT hardware queues (probed: ca_diag.hip) — two streams on one queue
 		// run in order and a frame would only queue up behind the other. Fewer than two such streams: no pipeline.
@@ -2146,12 +2146,7 @@ CA3D_API_CATCH
 int ca3d_get_render_pipeline(ca3d_t *h, int32_t *frames_in_flight) CA3D_API_TRY
 {
 	if (!h || !frames_in_flight) return fail(CA3D_ERR_INVALID_ARGUMENT, "ca3d_get_render_pipeline: NULL argument");
-	int n = 0;
-	if (h->render_pipeline && h->n_lanes >= 2)
-	{
-		n = h->lanes_in_use; // of the last pipelined frame (the default depth follows the frame's size)
-	}
-	*frames_in_flight = n;
+	*frames_in_flight = h->render_pipeline && h->n_lanes >= 2 ? h->lanes_in_use : 0; // of the last pipelined frame (the default depth follows the frame's size)
 	return CA3D_OK;
 }
 CA3D_API_CATCH

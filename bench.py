@@ -269,6 +269,21 @@ def render_pmc_record(kernel_ms):
             rec["l2_request_gbs"] = round(tot["TCC_REQ_sum"] * 128.0 / (kernel_ms * 1e-3) / 1e9, 1)   # 128-B lines requested of the L2 per second (this run's kernel time)
         if tot.get("TCC_EA0_RDREQ_sum") and kernel_ms:
             rec["fabric_read_gbs"] = round(tot["TCC_EA0_RDREQ_sum"] * 64.0 * 2.0 / (kernel_ms * 1e-3) / 1e9, 1)  # = FETCH_SIZE, doubled as the guide prescribes
+        rec["geometry"] = ("walk launches sized for the WHOLE chip — a frame alone (rocprofv3 collects counters one dispatch at a time: every frame of a "
+                           "PMC pass finds the engine idle); the frames of this line's default figure run side by side on a share each: in_flight_geometry")
+        # the same scene with the walk launches a frame IN FLIGHT gets (a quarter of the chip at this size): CA3D_STREAM_WGS_PCT=25 tools/pmc_render.sh
+        for g in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_render_share25.json")), reverse=True):
+            try:
+                q = json.load(open(g))
+            except Exception:
+                continue
+            walks = {k: v for k, v in q.items() if "ca_stream_walk" in k and v.get("SQ_ACTIVE_INST_VALU")}
+            if walks:
+                rec["in_flight_geometry"] = {"counter_source": os.path.relpath(g, ROOT), "walk_share_of_chip": 0.25,
+                                             "per_kernel": {k: {"lanes_active_frac": round(v["SQ_THREAD_CYCLES_VALU"] / (v["SQ_ACTIVE_INST_VALU"] * 64.0), 4),
+                                                                "valu_wave_instructions": int(v["SQ_INSTS_VALU"]),
+                                                                "valu_wave_instructions_whole_chip": int(d[k]["SQ_INSTS_VALU"]) if k in d else None} for k, v in walks.items()}}
+                break
         return rec
     return None
 

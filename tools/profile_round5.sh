@@ -62,8 +62,11 @@ if [ "$what" = render ] || [ "$what" = all ]; then
   echo "pmc render done"
   bash tools/pmc_render.sh ${tag}_render_literal --literal 1 > "$out/${tag}_pmc_render_literal.json" 2>/dev/null
   echo "pmc render literal done"
-  rm -rf "$out"/${tag}_render_pmc_* "$out"/${tag}_render_literal_pmc_*
-  cp "$out/${tag}_pmc_render.json" "$out/${tag}_pmc_render_literal.json" profiles/
+  # the walk launches of a frame IN FLIGHT (a quarter of the chip at 1080p): counter collection runs one dispatch at a time, so the share is forced
+  CA3D_STREAM_WGS_PCT=25 bash tools/pmc_render.sh ${tag}_render_share25 > "$out/${tag}_pmc_render_share25.json" 2>/dev/null
+  echo "pmc render share25 done"
+  rm -rf "$out"/${tag}_render_pmc_* "$out"/${tag}_render_literal_pmc_* "$out"/${tag}_render_share25_pmc_*
+  cp "$out/${tag}_pmc_render.json" "$out/${tag}_pmc_render_literal.json" "$out/${tag}_pmc_render_share25.json" profiles/
 fi
 if [ "$what" = stats ] || [ "$what" = all ]; then
   python3 $DRV > "$out/${tag}_bench512_driver_cmd.json"

@@ -395,6 +395,20 @@ def _render_leg_on_own_stream(eng, G, a, W, H, literal, sparse):
                                  "workload": f"{G}^3, single seed after 30 default-rule steps, default pose, {W}x{H} @ {a.render_spp} spp, "
                                              "empty-space skipping over two levels of occupancy blocks, walks clipped to the live box, "
                                              "pixels outside the live box's screen rectangle filled (ca_render_background)"}
+        # ... and what the bench scene (hashed fill, density 2^-5) is kind to: the same frame over THINNER volumes. Down to ~2^-12 a volume is
+        # still dense by the block count (the stream passes draw it, every walk is longer); below that it is a scattered sparse volume, drawn
+        # by the in-wave scheduled kernel with block skipping — the renderer's worst case. 1080p frames only.
+        if H == 1080:
+            thin = {}
+            for rounds in (8, 12):
+                eng.upload_state(host.random_fill(host.words_per_buffer(G), seed=0xCA3D0001, and_rounds=rounds))
+                dtt, stt = time_frames(eng, host.uniform_block(W, H, host.orbit_camera()), W, H, a.render_spp, max(10, a.render_frames // 4))
+                n = max(10, a.render_frames // 4)
+                thin[f"density_2^-{rounds + 1}"] = {"ms_per_frame": round(dtt * 1e3 / n, 4), "value": round((stt.primary_rays + stt.shadow_rays) * n / dtt / 1e6, 2), "unit": "Mray/s",
+                                                   "cell_visits_per_primary_ray": round(stt.primary_cell_visits / max(1, stt.primary_rays), 2)}
+            thin["note"] = ("hashed fills thinner than the headline scene's 2^-5, same pose and size, the engine's default path: 2^-9 is drawn by the stream passes "
+                            "(longer walks), 2^-13 by ca_render_packed_sched with block skipping — no stream form yet")
+            dense["thinner_scenes"] = thin
     return dense
 
 

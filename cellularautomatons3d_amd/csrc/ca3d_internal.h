@@ -195,7 +195,8 @@ size_t frame_bricks_bytes(uint32_t G);
 bool frame_bricks_applies(uint32_t G);
 hipError_t launch_render_frame_bricks(const void *frame_params, uint32_t *bricks, bool bricks_valid, hipStream_t stream, bool *bricks_built = nullptr);
 hipError_t launch_brick_volume(const uint32_t *cells, uint32_t *bricks, uint32_t G, hipStream_t stream);
-hipError_t launch_render_stream(const void *params, void *scratch, uint32_t W, uint32_t H, bool check, uint32_t *bricks, bool bricks_valid, hipStream_t stream, bool *bricks_built = nullptr, hipEvent_t before_resolve = nullptr, int walk_share_pct = 100);
+hipError_t launch_render_stream(const void *params, void *scratch, uint32_t W, uint32_t H, bool check, uint32_t *bricks, bool bricks_valid, hipStream_t stream, bool *bricks_built = nullptr, hipEvent_t before_resolve = nullptr, int walk_share_pct = 100,
+                                bool *sparse_too = nullptr); // *sparse_too: the passes launched draw scattered sparse volumes as well (render.hip then leaves its scheduled kernel out)
 
 // ca_packed.hip / ca_unpacked.hip
 hipError_t launch_packed_step(const PackedLaunch &l, hipStream_t stream, const char **kernel_name);

@@ -1186,20 +1186,21 @@ hipError_t launch_render(const RenderLaunch &l, hipStream_t stream)
 			// the dense-volume kernel: the ray-stream passes (render_stream.hip) when the engine has given them scratch, else the
 			// in-wave scheduled kernel (legacy volumes, traces, option render_stream 0)
 			const bool streamed = l.stream_scratch && !P.legacy && !P.trace;
+			bool stream_sparse = false; // the stream passes draw the scattered sparse volume too (ca_stream_walk2<.., SKIP>): no scheduled launch for it
 			if (streamed)
 			{
-				hipError_t e = launch_render_stream(&P, l.stream_scratch, l.W, l.H, l.stream_check, l.bricks, l.bricks_valid, stream, l.bricks_built, l.after, l.walk_share_pct);
+				hipError_t e = launch_render_stream(&P, l.stream_scratch, l.W, l.H, l.stream_check, l.bricks, l.bricks_valid, stream, l.bricks_built, l.after, l.walk_share_pct, &stream_sparse);
 				if (e != hipSuccess) return e;
 			}
 			if (one)
 			{
 				if (!streamed) hipLaunchKernelGGL((ca_render_packed_sched<false, 256, 1, kSchedWaves>), dim3(wgs), dim3(256), 0, stream, P);
-				if (P.occ) hipLaunchKernelGGL((ca_render_packed_sched<true, 256, 1, kSchedWaves>), dim3(wgs), dim3(256), 0, side, P);
+				if (P.occ && !stream_sparse) hipLaunchKernelGGL((ca_render_packed_sched<true, 256, 1, kSchedWaves>), dim3(wgs), dim3(256), 0, side, P);
 			}
 			else
 			{
 				if (!streamed) hipLaunchKernelGGL((ca_render_packed_sched<false, 64, kSchedChunk, kSchedWaves>), dim3(wgs), dim3(256), 0, stream, P);
-				if (P.occ) hipLaunchKernelGGL((ca_render_packed_sched<true, 64, kSchedChunk, kSchedWaves>), dim3(wgs), dim3(256), 0, side, P);
+				if (P.occ && !stream_sparse) hipLaunchKernelGGL((ca_render_packed_sched<true, 64, kSchedChunk, kSchedWaves>), dim3(wgs), dim3(256), 0, side, P);
 			}
 		}
 		if (!beside && l.after)

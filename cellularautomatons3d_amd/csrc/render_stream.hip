@@ -67,11 +67,17 @@ struct StreamParams
 	int refill;          // lanes without a ray at which a wave leaves the stepping loop to take new jobs (tuning: CA3D_STREAM_REFILL)
 	u32 lb;              // log2 of a chunk's pixel-block edge; jobs per chunk = spp << (2 lb)
 	u32 qmap;            // 0: queue q owns a contiguous eighth of the chunks (a band of the image); 1: every eighth chunk
+	u32 skip_ok;         // 1: sparse (scattered) volumes are drawn by the stream passes too — ca_stream_walk2<.., SKIP = true> (round 5, late)
 	u32 check;           // diagnostics build: answers were pre-set to kUnanswered and whoever looks one up counts those still unset in ctl[3]
 	unsigned long long *trace; // diagnostics (CA3D_STREAM_TRACE=<file>): 8 words per wave and walk pass — start, end (s_memrealtime, 100 MHz),
 	                           // refill rounds, stepping iterations, chunks taken, ticks spent refilling, jobs started, 0
 };
 constexpr u32 kQueueWords = 512, kNoChunk = 0xFFFFFFFFu;
+
+// Which frames the stream passes draw: dense volumes; and, with skip_ok, sparse volumes whose live cells are scattered (the block-skipping
+// walk inside ca_stream_walk2<.., true>). A sparse volume with a small live box stays with render.hip's spread kernel.
+__device__ __forceinline__ bool stream_sparse_frame(const StreamParams &S) { return S.skip_ok && occ_skip_enabled(S.R) && !live_box_small(S.R); }
+__device__ __forceinline__ bool stream_owns_frame(const StreamParams &S) { return !occ_skip_enabled(S.R) || stream_sparse_frame(S); }
 
 __device__ __forceinline__ u32 job_shift(const RenderParams &P) { return P.spp == 4u ? 2u : 0u; }
 
@@ -887,13 +893,21 @@ __device__ __forceinline__ void walker_prepare(const RenderParams &P, Walker &w,
 	c6[3] = 1.0f / dir.x; c6[4] = 1.0f / dir.y; c6[5] = 1.0f / dir.z;
 }
 
-template <bool SHADOW, int LAYOUT, bool CHECK>
+// SKIP (round 5, late): the walk of a SPARSE volume — walk<.., true> of render_device.inc, cell for cell: clipped to the live box at set-up
+// (live_box_clip), and a walker that enters a block the occupancy bits call empty (coarse 128 x 32 x 32, then fine 32 x 8 x 8; the last
+// occupied block remembered) jumps to the block's exit and re-seeds its boundary times in closed form (block_jump) — which needs the
+// ray's direction next to its origin and reciprocal (nine floats of context per lane instead of six, twenty words per queued ray instead
+// of sixteen: its start time too, which the clip may have moved). A pass of the stepping loop is a jump or a cell for a lane, and
+// counts as a visit either way, as in walk(). Cells are read cell by cell from the bricked copy; no batched tail.
+template <bool SHADOW, int LAYOUT, bool CHECK, bool SKIP = false>
 __global__ __launch_bounds__(kW2Threads, kW2PerSimd) void ca_stream_walk2(StreamParams S)
 {
 	const RenderParams &P = S.R;
-	if (occ_skip_enabled(P)) return; // a sparse volume: the skipping kernels of render.hip draw the frame
-	__shared__ float ctx_lds[6][kW2Threads];
-	__shared__ u32 rec_lds[kRecWords][kW2Threads]; // a wave's queue: rec_lds[field][64 * wave + slot]
+	if (SKIP ? !stream_sparse_frame(S) : occ_skip_enabled(P)) return; // (a sparse volume with a small live box: render.hip's spread kernel draws the frame)
+	constexpr int kCtx = SKIP ? 9 : 6, kRec = SKIP ? kRecWords + 4 : kRecWords;
+	static_assert(!SKIP || (LAYOUT == kBricksRead || LAYOUT == kBricksReadAny), "the skipping walk reads bricks cell by cell");
+	__shared__ float ctx_lds[kCtx][kW2Threads];
+	__shared__ u32 rec_lds[kRec][kW2Threads]; // a wave's queue: rec_lds[field][64 * wave + slot]
 	__shared__ u32 ids_lds[kW2Waves][kIdCap];      // a wave's list of job ids waiting for their set-up
 	const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	float *ctx = &ctx_lds[0][tid];
@@ -958,6 +972,7 @@ __global__ __launch_bounds__(kW2Threads, kW2PerSimd) void ca_stream_walk2(Stream
 	w.ix = w.iy = w.iz = 0; w.sx = w.sy = w.sz = 1; w.wkey = -1; w.word = 0;
 	w.pos = 0u; w.neg = 0x49u; w.edge = 0u;
 	u32 hpos = 0u;               // kBricksPacked: the cell a walk ended its hit on
+	int okey = -1;               // SKIP: the block the walker was last found in an occupied block of (walk(): okey)
 	u32 visits = 0;              // wave-uniform
 	u32 idcount = 0;             // wave-uniform: ids waiting in ids[]
 	u32 qhead = 0, qavail = 0;   // wave-uniform: prepared rays rec[.][qhead .. qhead + qavail)
@@ -1035,6 +1050,7 @@ __global__ __launch_bounds__(kW2Threads, kW2PerSimd) void ca_stream_walk2(Stream
 				tr_rounds++;
 				const u32 n = min(idcount, 64u);
 				bool pushed = false, ap = false, ex = false;
+				v3 sdir = V(0.0f, 0.0f, 0.0f); // SKIP: the ray's direction (block_jump divides by it)
 				Walker nw;
 				float c6[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 				u32 nj = 0;
@@ -1059,6 +1075,14 @@ __global__ __launch_bounds__(kW2Threads, kW2PerSimd) void ca_stream_walk2(Stream
 							{
 								walker_prepare(P, nw, ap, c6, tr.enter, tr.dir, 0.0f, tr.len);
 								pushed = true;
+								if (SKIP)
+								{
+									sdir = tr.dir;
+									// walk(): the live-box clip in front of the loop — false: the ray stays outside the box, no walk; it may move the start and the end
+									if (P.live_box && !live_box_clip(P, tr.enter, tr.dir, V(c6[3], c6[4], c6[5]), 0.0f, nw.tmax, nw.ix, nw.iy, nw.iz, nw.t, nw.tx, nw.ty, nw.tz)) pushed = false;
+									else if (nw.t >= nw.tmax) pushed = false; // (the loop's first `t >= tmax`)
+									if (!pushed) S.hit[j] = kNoHit;
+								}
 							}
 						}
 					}
@@ -1077,10 +1101,18 @@ __global__ __launch_bounds__(kW2Threads, kW2PerSimd) void ca_stream_walk2(Stream
 						if (0.0025f >= slen) S.occl[j] = kOcclNone;
 						else
 						{
-							walker_prepare(P, nw, ap, c6, p, norm3(sseg), 0.0025f, slen);
+							const v3 sd = norm3(sseg);
+							walker_prepare(P, nw, ap, c6, p, sd, 0.0025f, slen);
+							pushed = true;
+							if (SKIP)
+							{
+								sdir = sd;
+								if (P.live_box && !live_box_clip(P, p, sd, V(c6[3], c6[4], c6[5]), 0.0025f, nw.tmax, nw.ix, nw.iy, nw.iz, nw.t, nw.tx, nw.ty, nw.tz)) pushed = false;
+								else if (nw.t >= nw.tmax) pushed = false;
+								if (!pushed) S.occl[j] = kOcclNone;
+							}
 							const int cx = (int)floorf(to_cells(P, p.x)), cy = (int)floorf(to_cells(P, p.y)), cz = (int)floorf(to_cells(P, p.z));
 							ex = nw.ix == cx && nw.iy == cy && nw.iz == cz; // any(cell != startCell) :664
-							pushed = true;
 						}
 					}
 				}
@@ -1145,6 +1177,11 @@ __global__ __launch_bounds__(kW2Threads, kW2PerSimd) void ca_stream_walk2(Stream
 						}
 #pragma unroll
 						for (int q = 0; q < 6; q++) r[(10 + q) * kW2Threads] = __float_as_uint(c6[q]);
+						if (SKIP)
+						{
+							r[16 * kW2Threads] = __float_as_uint(nw.t);
+							r[17 * kW2Threads] = __float_as_uint(sdir.x); r[18 * kW2Threads] = __float_as_uint(sdir.y); r[19 * kW2Threads] = __float_as_uint(sdir.z);
+						}
 					}
 					qavail = (u32)__popcll(m);
 					qhead = 0u;
@@ -1188,6 +1225,13 @@ __global__ __launch_bounds__(kW2Threads, kW2PerSimd) void ca_stream_walk2(Stream
 					term = 0;
 #pragma unroll
 					for (int q = 0; q < 6; q++) ctx[q * stride] = __uint_as_float(r[(10 + q) * kW2Threads]);
+					if (SKIP)
+					{
+						w.t = __uint_as_float(r[16 * kW2Threads]);
+#pragma unroll
+						for (int q = 0; q < 3; q++) ctx[(6 + q) * stride] = __uint_as_float(r[(17 + q) * kW2Threads]);
+						okey = -1;
+					}
 				}
 			}
 			qhead += take;
@@ -1203,7 +1247,7 @@ __global__ __launch_bounds__(kW2Threads, kW2PerSimd) void ca_stream_walk2(Stream
 		}
 		const bool refillable = more || idcount != 0u || qavail != 0u;
 		const int leave_at = __builtin_amdgcn_readfirstlane(refillable ? 64 - pop_at : 0);
-		if (S.tail_batch == 2 || (S.tail_batch && !refillable))
+		if (!SKIP && (S.tail_batch == 2 || (S.tail_batch && !refillable)))
 		{
 			// nothing left to refill from: few waves are left on the chip, their rays are the long ones and lie
 			// all over the volume — an iteration is one memory round trip that nothing hides. Four cells per round trip (walk_batch).
@@ -1269,6 +1313,39 @@ __global__ __launch_bounds__(kW2Threads, kW2PerSimd) void ca_stream_walk2(Stream
 			} while (walking > leave_at);
 			if (st != 3) term = st;
 		}
+		else if (SKIP)
+		{
+			do
+			{
+				visits += (u32)walking;
+				if (job >= 0 && term == 0)
+				{
+					// walk(): the block of the cell — coarse bits first, then fine — unless it is the block last found occupied
+					int empty = 0;
+					const int bk = (w.ix >> 5) + ((w.iy >> 3) + (w.iz >> 3) * ((int)P.G >> 3)) * (int)P.cols;
+					if (bk != okey)
+					{
+						if (P.occ_coarse && !coarse_occupied(P, w.ix, w.iy, w.iz)) empty = 1;
+						else if (!block_occupied(P, w.ix, w.iy, w.iz)) empty = 2;
+						else okey = bk;
+					}
+					if (empty)
+					{
+						const v3 start = V(ctx[0 * stride], ctx[1 * stride], ctx[2 * stride]), dir = V(ctx[6 * stride], ctx[7 * stride], ctx[8 * stride]);
+						const bool on = empty == 1 ? block_jump<7, 5, 5>(P, start, dir, w.tmax, w.ix, w.iy, w.iz, w.t, w.tx, w.ty, w.tz)
+						                           : block_jump<5, 3, 3>(P, start, dir, w.tmax, w.ix, w.iy, w.iz, w.t, w.tx, w.ty, w.tz);
+						if (!on) term = 2;
+						exempt = false; // (the walk has left the cell it started in)
+					}
+					else
+					{
+						const int key = word_key<LAYOUT>(S, w.ix, w.iy, w.iz);
+						term = walk_cell<SHADOW, LAYOUT, CHECK, true>(S, w, key, exempt, vhalf, k0, k1, eps_a, ctx, stride);
+					}
+				}
+				walking = __builtin_amdgcn_readfirstlane(__popcll(__ballot(job >= 0 && term == 0)));
+			} while (walking > leave_at);
+		}
 		else
 		{
 			do
@@ -1292,7 +1369,7 @@ __global__ __launch_bounds__(kW2Threads, kW2PerSimd) void ca_stream_walk2(Stream
 __global__ __launch_bounds__(256) void ca_stream_shadow_rays(StreamParams S)
 {
 	const RenderParams &P = S.R;
-	if (occ_skip_enabled(P)) return;
+	if (!stream_owns_frame(S)) return;
 	const u32 j = blockIdx.x * 256u + threadIdx.x;
 	const u32 lj = 2u * S.lb + job_shift(P); // log2 jobs per chunk
 	const u32 c = j >> lj;
@@ -1327,7 +1404,7 @@ __global__ __launch_bounds__(256) void ca_stream_shadow_rays(StreamParams S)
 __global__ __launch_bounds__(256) void ca_stream_resolve(StreamParams S)
 {
 	const RenderParams &P = S.R;
-	if (occ_skip_enabled(P)) return;
+	if (!stream_owns_frame(S)) return;
 	if (blockIdx.x == 0 && threadIdx.x < 3u && P.counters)
 	{
 		// the frame's statistics: the slots the passes before this one added to (stream order: they are complete)
@@ -1380,12 +1457,16 @@ __global__ __launch_bounds__(256) void ca_stream_resolve(StreamParams S)
 	}
 }
 
+// (S.skip_ok: the walks of a scattered sparse volume too — each of the two kernels of a pass returns at once on the frames of the other)
 template <int P2, bool CHECK>
 void launch_walks2(const StreamParams &S, u32 wgs2, u32 job_blocks, hipStream_t stream)
 {
+	constexpr int PS = kBricksReadAny; // the skipping walk reads bricks cell by cell (not the packed positions); the brick index by the padded bit count — every grid's
 	hipLaunchKernelGGL((ca_stream_walk2<false, P2, CHECK>), dim3(wgs2), dim3(kW2Threads), 0, stream, S);
+	if (S.skip_ok) hipLaunchKernelGGL((ca_stream_walk2<false, PS, CHECK, true>), dim3(wgs2), dim3(kW2Threads), 0, stream, S);
 	hipLaunchKernelGGL(ca_stream_shadow_rays, dim3(job_blocks), dim3(256), 0, stream, S);
 	hipLaunchKernelGGL((ca_stream_walk2<true, P2, CHECK>), dim3(wgs2), dim3(kW2Threads), 0, stream, S);
+	if (S.skip_ok) hipLaunchKernelGGL((ca_stream_walk2<true, PS, CHECK, true>), dim3(wgs2), dim3(kW2Threads), 0, stream, S);
 }
 
 template <int P2, bool CHECK, bool BATCHED = false>
@@ -1411,10 +1492,12 @@ size_t stream_scratch_bytes(uint32_t W, uint32_t H, uint32_t spp, size_t *hit_of
 
 // The dense-volume part of a frame over the rectangle P.rx0 .. P.ry1 (render.hip's volume_rect), on `stream`. The caller has
 // cleared P.counters and, when there is one, run the occupancy pass (the passes here test its count on the device).
-hipError_t launch_render_stream(const void *params, void *scratch, uint32_t W, uint32_t H, bool check, uint32_t *bricks, bool bricks_valid, hipStream_t stream, bool *bricks_built, hipEvent_t before_resolve, int walk_share_pct)
+hipError_t launch_render_stream(const void *params, void *scratch, uint32_t W, uint32_t H, bool check, uint32_t *bricks, bool bricks_valid, hipStream_t stream, bool *bricks_built, hipEvent_t before_resolve, int walk_share_pct, bool *sparse_too)
 {
 	StreamParams S;
 	S.R = *static_cast<const RenderParams *>(params);
+	S.skip_ok = 0u;
+	if (sparse_too) *sparse_too = false;
 	const RenderParams &P = S.R;
 	size_t hit_off, occl_off, rays_off;
 	stream_scratch_bytes(W, H, P.spp, &hit_off, &occl_off, &rays_off);
@@ -1487,6 +1570,10 @@ hipError_t launch_render_stream(const void *params, void *scratch, uint32_t W, u
 		const u32 pct = (u32)(wgs_env >= 10 && wgs_env <= 100 ? wgs_env : (walk_share_pct >= 10 && walk_share_pct <= 100 ? walk_share_pct : 100));
 		const u32 wgs2 = max(8u, min(S.chunks, (u32)cus * (u32)kW2PerSimd * 4u / (u32)kW2Waves * pct / 100u));
 		const bool form2 = form_env == 2 && per >= 128u && bricks_env == 1; // (a chunk holds at least 64 tickets of two jobs)
+		// scattered sparse volumes through the stream passes as well (ca_stream_walk2<.., SKIP>; CA3D_STREAM_SKIP=0: render.hip's scheduled kernel, tuning / A-B)
+		static const int skip_env = getenv("CA3D_STREAM_SKIP") ? atoi(getenv("CA3D_STREAM_SKIP")) : 1;
+		S.skip_ok = form2 && skip_env && P.occ && !getenv("CA3D_STREAM_PROBE") ? 1u : 0u;
+		if (sparse_too) *sparse_too = S.skip_ok != 0u;
 		if (form2) trace_waves = (unsigned long long)wgs2 * (unsigned)kW2Waves;
 		static const int probe_env = getenv("CA3D_STREAM_PROBE") ? atoi(getenv("CA3D_STREAM_PROBE")) : 0;
 		static const int packed_env = getenv("CA3D_STREAM_PACKED") ? atoi(getenv("CA3D_STREAM_PACKED")) : 1; // tuning: 0 = cell coordinates as three integers (kBricksRead)

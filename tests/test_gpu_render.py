@@ -144,6 +144,25 @@ def test_empty_space_skipping_on_a_sparse_volume(eng, G, W, H, spp):
         assert v_skip * 3 < v_plain, (v_skip, v_plain)
 
 
+@pytest.mark.parametrize("G,rounds,W,H,spp", [(128, 12, 320, 180, 4), (256, 13, 480, 270, 1), (96, 13, 320, 180, 4), (256, 15, 320, 180, 4)])
+def test_scattered_sparse_volume(eng, G, rounds, W, H, spp):
+    """Live cells everywhere, but in under a quarter of the 32 x 8 x 8 blocks (a hashed fill of density 2^-(rounds + 1)): the frame of the
+    block-skipping walks — walk<.., SKIP> in the plain kernel, the in-wave scheduled kernel (render_stream 0) and, the default since
+    round 5, the ray-stream passes (ca_stream_walk2<.., SKIP>: live-box clip at set-up, two-level block jumps inside the stepping loop) —
+    bit for bit the same from all three, cell-visit counts included, and within the file's tolerance of the oracle's cell-by-cell walk.
+    The scene must really be of that kind: far fewer visits than the unskipped walk, and a live box that is not small."""
+    cells = host.random_fill(host.words_per_buffer(G), seed=17 + G, and_rounds=rounds)
+    for pose in (host.camera_matrix(), host.orbit_camera(1.3, (1.0, 1.0, 0.0), 0.6)):
+        u = host.uniform_block(W, H, pose)
+        _compare(eng, cells, G, u, W, H, spp, min_ok=0.998)
+        v_skip = eng.render_stats().primary_cell_visits
+        eng.set_option("render_skip", 0)
+        eng.render(u, W, H, spp)
+        v_plain = eng.render_stats().primary_cell_visits
+        eng.set_option("render_skip", 1)
+        assert v_skip * 2 < v_plain, (v_skip, v_plain)
+
+
 @pytest.mark.parametrize("spp", [1, 4])
 def test_small_live_box_frame(eng, spp):
     """A sparse volume whose live cells sit in a small box (the reference's start-up seed a few steps on): view rays that miss

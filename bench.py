@@ -397,7 +397,7 @@ def _render_leg_on_own_stream(eng, G, a, W, H, literal, sparse):
                                              "pixels outside the live box's screen rectangle filled (ca_render_background)"}
         # ... and what the bench scene (hashed fill, density 2^-5) is kind to: the same frame over THINNER volumes. Down to ~2^-12 a volume is
         # still dense by the block count (the stream passes draw it, every walk is longer); below that it is a scattered sparse volume, drawn
-        # by the in-wave scheduled kernel with block skipping — the renderer's worst case. 1080p frames only.
+        # by the stream passes' block-skipping form — the renderer's worst case. 1080p frames only.
         if H == 1080:
             thin = {}
             for rounds in (8, 12):
@@ -407,7 +407,7 @@ def _render_leg_on_own_stream(eng, G, a, W, H, literal, sparse):
                 thin[f"density_2^-{rounds + 1}"] = {"ms_per_frame": round(dtt * 1e3 / n, 4), "value": round((stt.primary_rays + stt.shadow_rays) * n / dtt / 1e6, 2), "unit": "Mray/s",
                                                    "cell_visits_per_primary_ray": round(stt.primary_cell_visits / max(1, stt.primary_rays), 2)}
             thin["note"] = ("hashed fills thinner than the headline scene's 2^-5, same pose and size, the engine's default path: 2^-9 is drawn by the stream passes "
-                            "(longer walks), 2^-13 by ca_render_packed_sched with block skipping — no stream form yet")
+                            "(longer walks), 2^-13 — a scattered sparse volume — by their block-skipping form (ca_stream_walk2<.., SKIP>; the in-wave scheduled kernel until late in round 5: 4.7 ms)")
             dense["thinner_scenes"] = thin
     return dense
 

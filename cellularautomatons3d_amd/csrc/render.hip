@@ -316,9 +316,9 @@ __device__ __forceinline__ int walk_step(const RenderParams &P, RayState &w, v3 
 	if (SKIP)
 	{
 		if (P.occ_coarse && !coarse_occupied(P, w.ix, w.iy, w.iz))
-			return block_jump<7, 5, 5>(P, w.start, w.dir, w.tmax, w.ix, w.iy, w.iz, w.t, w.tx, w.ty, w.tz) ? 0 : 2;
+			return block_jump<7, 5, 5>(P, w.start, w.dir, w.inv, w.tmax, w.ix, w.iy, w.iz, w.t, w.tx, w.ty, w.tz) ? 0 : 2;
 		if (!block_occupied(P, w.ix, w.iy, w.iz))
-			return block_jump<5, 3, 3>(P, w.start, w.dir, w.tmax, w.ix, w.iy, w.iz, w.t, w.tx, w.ty, w.tz) ? 0 : 2;
+			return block_jump<5, 3, 3>(P, w.start, w.dir, w.inv, w.tmax, w.ix, w.iy, w.iz, w.t, w.tx, w.ty, w.tz) ? 0 : 2;
 	}
 	bool alive;
 	if (P.legacy) alive = P.cells[(size_t)w.ix + ((size_t)w.iy + (size_t)w.iz * G) * G] == 1u;
@@ -368,9 +368,9 @@ __device__ __forceinline__ int walk_probe(const RenderParams &P, RayState &w, bo
 	if (SKIP)
 	{
 		if (P.occ_coarse && !coarse_occupied(P, w.ix, w.iy, w.iz))
-			return block_jump<7, 5, 5>(P, w.start, w.dir, w.tmax, w.ix, w.iy, w.iz, w.t, w.tx, w.ty, w.tz) ? 4 : 2;
+			return block_jump<7, 5, 5>(P, w.start, w.dir, w.inv, w.tmax, w.ix, w.iy, w.iz, w.t, w.tx, w.ty, w.tz) ? 4 : 2;
 		if (!block_occupied(P, w.ix, w.iy, w.iz))
-			return block_jump<5, 3, 3>(P, w.start, w.dir, w.tmax, w.ix, w.iy, w.iz, w.t, w.tx, w.ty, w.tz) ? 4 : 2;
+			return block_jump<5, 3, 3>(P, w.start, w.dir, w.inv, w.tmax, w.ix, w.iy, w.iz, w.t, w.tx, w.ty, w.tz) ? 4 : 2;
 	}
 	bool alive;
 	if (P.legacy) alive = P.cells[(size_t)w.ix + ((size_t)w.iy + (size_t)w.iz * G) * G] == 1u;

@@ -1352,9 +1352,9 @@ __global__ __launch_bounds__(kW2Threads, kW2PerSimd) void ca_stream_walk2(Stream
 					}
 					if (empty)
 					{
-						const v3 start = V(ctx[0 * stride], ctx[1 * stride], ctx[2 * stride]), dir = V(ctx[6 * stride], ctx[7 * stride], ctx[8 * stride]);
-						const bool on = empty == 1 ? block_jump<7, 5, 5>(P, start, dir, w.tmax, w.ix, w.iy, w.iz, w.t, w.tx, w.ty, w.tz)
-						                           : block_jump<5, 3, 3>(P, start, dir, w.tmax, w.ix, w.iy, w.iz, w.t, w.tx, w.ty, w.tz);
+						const v3 start = V(ctx[0 * stride], ctx[1 * stride], ctx[2 * stride]), inv = V(ctx[3 * stride], ctx[4 * stride], ctx[5 * stride]), dir = V(ctx[6 * stride], ctx[7 * stride], ctx[8 * stride]);
+						const bool on = empty == 1 ? block_jump<7, 5, 5>(P, start, dir, inv, w.tmax, w.ix, w.iy, w.iz, w.t, w.tx, w.ty, w.tz)
+						                           : block_jump<5, 3, 3>(P, start, dir, inv, w.tmax, w.ix, w.iy, w.iz, w.t, w.tx, w.ty, w.tz);
 						if (!on) term = 2;
 						exempt = false; // (the walk has left the cell it started in)
 					}
